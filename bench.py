@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path on BASELINE.json's metric: MB/s of uncompressed input consumed by
+STARTC (CWINDOW=32, MATCH10, static tree), whole job, plus the compression ratio.
+
+Workload at N=1 = BASELINE configs[1]: 2^20 x 2 KiB synthetic blocks per GPU (families 1..4 of
+test_deflate.py:38-66, every block distinct, 2 GiB >> 256 MB Infinity Cache), resident in HBM before
+the timed region.  A "step" = one hdlz_compress_batch launch over all of the rank's blocks (+ for
+N>1 the RCCL all-gather of the per-block output lengths).  Weak scaling: per-GPU work
+is fixed, value = bytes all ranks consumed / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (k_compress): algorithmic bytes per launch (N_in + N_out + 4 per block,
+                  SURVEY 8(d)) / average launch duration measured with HIP events on the launch stream,
+                  against the 8 TB/s HBM3E peak
+  cpu_baseline -- the CPU oracle (a port: oracle/hdlz_oracle.c) timed on this box's host cores on a
+                  bounded sample of the same blocks (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=1 << 20, help="blocks per GPU")
+    ap.add_argument("--block-size", type=int, default=2048)
+    ap.add_argument("--cwindow", type=int, default=32)
+    ap.add_argument("--maxmatch", type=int, default=10)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
+    ap.add_argument("--verify", type=int, default=256, help="blocks checked against zlib outside the timed region")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import hdl_deflate_amd
+    from hdl_deflate_amd.data import make_blocks
+    from hdl_deflate_amd.shard import gather_lengths
+    from hdl_deflate_amd.constants import pitch_for
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, "launch with torchrun --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    eng = hdl_deflate_amd.Engine(dev)
+    B, n = a.blocks, a.block_size
+    nblocks_total = B * world
+    # rank r owns the contiguous block range [r*B, (r+1)*B) of the job (weak scaling)
+    d_in = make_blocks(B, n, dev, seed=0, first_block=rank * B)
+    pitch = pitch_for(n)
+    d_out = torch.empty((B, pitch), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        out, ol, st = eng.compress_batch(d_in, cwindow=a.cwindow, maxmatch=a.maxmatch, out=d_out, out_pitch=pitch)
+        all_len = gather_lengths(ol, nblocks_total) if world > 1 else ol
+        return ol, st, all_len
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ol, st, all_len = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- kernel-only duration of the dominant kernel: HIP events on the launch stream (= torch's
+    # current stream, which is the stream handed to the C-ABI), separate launches
+    evs = []
+    for _ in range(max(3, a.steps)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        eng.compress_batch(d_in, cwindow=a.cwindow, maxmatch=a.maxmatch, out=d_out, out_pitch=pitch)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    k_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    k_avg = sum(k_ms) / len(k_ms)
+
+    # ---- checks outside the timed region
+    bad = int((st != 0).sum().item())
+    out_bytes_local = int(ol.to(torch.int64).sum().item())
+    in_bytes_local = B * n
+    tot = torch.tensor([out_bytes_local, in_bytes_local, bad], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot)
+        assert int(all_len.to(torch.int64).sum().item()) == int(tot[0].item())
+    out_bytes, in_bytes, bad = (int(x) for x in tot.tolist())
+    assert bad == 0, "%d blocks failed" % bad
+    if rank == 0 and a.verify:
+        import zlib
+        idx = torch.linspace(0, B - 1, a.verify).long().unique()
+        hi = d_in[idx.to(dev)].cpu().numpy()
+        ho = d_out[idx.to(dev)].cpu().numpy()
+        hl = ol[idx.to(dev)].cpu().numpy()
+        for k in range(len(idx)):
+            assert zlib.decompress(ho[k, :hl[k]].tobytes()) == hi[k].tobytes(), "zlib round trip failed"
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = dt / a.steps * 1e3
+    value = in_bytes / (dt / a.steps) / 1e6                      # MB/s, whole job
+    algo_bytes = in_bytes_local + out_bytes_local + 4 * B        # per launch (one GPU)
+    achieved = algo_bytes / (k_avg * 1e-3) / 1e9
+    res = {
+        "metric": "compress_input_throughput (CWINDOW=%d, MATCH10=%s, static tree)" % (a.cwindow, a.maxmatch == 10),
+        "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %d x %d B blocks per GPU, families 1-4 (test_deflate.py:38-66), "
+                               "distinct blocks, HBM-resident" % (B, n),
+                   "cwindow": a.cwindow, "maxmatch": a.maxmatch, "blocks_per_gpu": B, "block_bytes": n,
+                   "parallelism": "block-shard x%d (length all-gather only)" % world},
+        "per_gpu_MBps": round(value / world, 1),
+        "compression_ratio_out_over_in": round(out_bytes / in_bytes, 4),
+        "roofline": {"bound": "hbm", "kernel": "k_compress<1>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg, 4),
+                     "kernel_ms_min": round(k_ms[0], 4),
+                     "note": "bytes = N_in + N_out + 4 per block; this path is VALU-issue bound, not HBM bound "
+                             "(DESIGN.md)"},
+    }
+    if world == 1 and a.cpu_seconds > 0:
+        res["cpu_baseline"] = cpu_baseline(d_in, n, a)
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(d_in, n, a):
+    """the CPU oracle (kind "port") on a bounded sample of the same blocks, all host cores"""
+    import numpy as np
+    from oracle import oracle as O          # cpu_baseline leg: the oracle is the thing timed here, as allowed
+    O.lib()
+    cores = os.cpu_count() or 1
+    B = d_in.shape[0]
+    probe = d_in[:min(B, 2048)].cpu().numpy()
+    off = (np.arange(probe.shape[0] + 1, dtype=np.uint64) * n)
+    t0 = time.perf_counter()
+    O.compress_batch(probe.reshape(-1), off, a.cwindow, a.maxmatch, nthreads=cores)
+    rate = probe.size / max(time.perf_counter() - t0, 1e-6)
+    S = int(min(B, max(2048, rate * a.cpu_seconds / n)))
+    sample = d_in[:S].cpu().numpy()
+    off = (np.arange(S + 1, dtype=np.uint64) * n)
+    t0 = time.perf_counter()
+    _, ol, st = O.compress_batch(sample.reshape(-1), off, a.cwindow, a.maxmatch, nthreads=cores)
+    dt = time.perf_counter() - t0
+    assert (st == 0).all()
+    t1 = time.perf_counter()
+    O.compress_batch(sample[:max(1, S // cores)].reshape(-1), off[:max(1, S // cores) + 1], a.cwindow, a.maxmatch, nthreads=1)
+    dt1 = time.perf_counter() - t1
+    return {"value": round(sample.size / dt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
+            "sample": "first %d blocks of the same workload (%.1f MiB), oracle/hdlz_oracle.c, %d threads, %.1f s"
+                      % (S, sample.size / 2 ** 20, cores, dt),
+            "single_thread_MBps": round(sample[:max(1, S // cores)].size / dt1 / 1e6, 1),
+            "reference_constants": {"fpga_100MHz_3cyc_per_byte_MBps": 33, "standin_sim_KBps": "0.5-1 (BASELINE.md)"}}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,26 @@
+"""Constants shared with include/hdlz.h (command codes: /root/reference/deflate.py:18)."""
+IDLE, WRITE, READ, STARTC, STARTD = range(5)
+
+(OK, E_SHORT_INPUT, E_OUT_CAPACITY, E_BAD_BTYPE, E_BAD_DISTANCE, E_NO_EOF, E_DYNAMIC_UNSUPPORTED,
+ E_BAD_SYMBOL, E_BAD_PARAM, E_HIP) = range(10)
+INFLATE_ASSUME_FIXED = 1
+
+STATUS_NAMES = {OK: "OK", E_SHORT_INPUT: "SHORT_INPUT", E_OUT_CAPACITY: "OUT_CAPACITY", E_BAD_BTYPE: "BAD_BTYPE",
+                E_BAD_DISTANCE: "BAD_DISTANCE", E_NO_EOF: "NO_EOF", E_DYNAMIC_UNSUPPORTED: "DYNAMIC_UNSUPPORTED",
+                E_BAD_SYMBOL: "BAD_SYMBOL", E_BAD_PARAM: "BAD_PARAM", E_HIP: "HIP_ERROR"}
+
+# reference defaults (deflate.py:34-76)
+CWINDOW = 32
+MAXMATCH = 10      # MATCH10 = True
+LMAX = 24
+
+
+def out_bound(n):
+    """worst-case compressed size: 6 + ceil((9n+10)/8)  (same as hdlz_out_bound)"""
+    return 6 + (9 * n + 10 + 7) // 8
+
+
+def pitch_for(n, align=16):
+    """an out_pitch >= out_bound(n) rounded up to `align` bytes"""
+    b = out_bound(n)
+    return (b + align - 1) // align * align

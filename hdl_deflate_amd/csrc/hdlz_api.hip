@@ -1,0 +1,99 @@
+// hdlz_api.hip -- the extern "C" surface of libhdlz.so (declared in include/hdlz.h).
+// Host-side parameter checks + kernel launches; no CPU compute path exists here by design.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "hdlz_device.h"
+
+namespace {
+thread_local char g_err[256] = "";
+
+int fail_param(const char* what) {
+    snprintf(g_err, sizeof(g_err), "bad parameter: %s", what);
+    return HDLZ_E_BAD_PARAM;
+}
+int fail_hip(hipError_t e, const char* where) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return HDLZ_E_HIP;
+}
+int check_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail_hip(e, "hipGetDeviceCount");
+    if (n <= 0) {
+        snprintf(g_err, sizeof(g_err), "no HIP device visible: libhdlz has no CPU path");
+        return HDLZ_E_HIP;
+    }
+    return HDLZ_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hdlz_version(void) { return HDLZ_VERSION; }
+
+const char* hdlz_last_error(void) { return g_err; }
+
+const char* hdlz_status_string(int s) {
+    switch (s) {
+        case HDLZ_OK: return "OK";
+        case HDLZ_E_SHORT_INPUT: return "SHORT_INPUT (N < 5)";
+        case HDLZ_E_OUT_CAPACITY: return "OUT_CAPACITY";
+        case HDLZ_E_BAD_BTYPE: return "BAD_BTYPE";
+        case HDLZ_E_BAD_DISTANCE: return "BAD_DISTANCE";
+        case HDLZ_E_NO_EOF: return "NO_EOF";
+        case HDLZ_E_DYNAMIC_UNSUPPORTED: return "DYNAMIC_UNSUPPORTED";
+        case HDLZ_E_BAD_SYMBOL: return "BAD_SYMBOL";
+        case HDLZ_E_BAD_PARAM: return "BAD_PARAM";
+        case HDLZ_E_HIP: return "HIP_ERROR";
+        default: return "?";
+    }
+}
+
+int hdlz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int good = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) good++;
+    }
+    return good;
+}
+
+size_t hdlz_out_bound(size_t n) { return 6 + (9 * n + 10 + 7) / 8; }
+
+int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
+                        uint64_t nblocks, int cwindow, int maxmatch, uint8_t* d_out, uint64_t out_pitch,
+                        uint32_t* d_out_len, uint32_t* d_status, void* stream) {
+    if (cwindow < 1 || cwindow > 256) return fail_param("cwindow must be in [1,256]");
+    if (maxmatch != 5 && maxmatch != 10) return fail_param("maxmatch must be 5 (MATCH10=False) or 10 (MATCH10=True)");
+    if (nblocks > 0x7FFFFFFFull) return fail_param("nblocks too large for one launch");
+    if (nblocks && (!d_in || !d_out || !d_out_len || !d_status)) return fail_param("null device pointer");
+    if ((out_pitch & 3u) || (reinterpret_cast<uintptr_t>(d_out) & 3u)) return fail_param("d_out / out_pitch must be 4-byte aligned");
+    if (!d_in_off && in_len >= 0x80000000u) return fail_param("in_len too large");
+    int rc = check_device();
+    if (rc != HDLZ_OK) return rc;
+    hdlz::CompressArgs a{d_in, d_in_off, in_pitch, in_len, nblocks, cwindow, maxmatch, d_out, out_pitch, d_out_len, d_status};
+    hipError_t e = hdlz::launch_compress(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "launch k_compress");
+    return HDLZ_OK;
+}
+
+int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
+                       uint64_t nstreams, uint32_t flags, uint32_t obsize, uint8_t* d_out, uint64_t out_pitch,
+                       uint32_t* d_out_len, uint32_t* d_status, void* stream) {
+    if (nstreams > 0x7FFFFFFFull * 32) return fail_param("nstreams too large for one launch");
+    if (nstreams && (!d_in || !d_out || !d_out_len || !d_status)) return fail_param("null device pointer");
+    if (flags & ~HDLZ_INFLATE_ASSUME_FIXED) return fail_param("unknown flag");
+    if ((out_pitch & 3u) || (reinterpret_cast<uintptr_t>(d_out) & 3u)) return fail_param("d_out / out_pitch must be 4-byte aligned");
+    int rc = check_device();
+    if (rc != HDLZ_OK) return rc;
+    hdlz::InflateArgs a{d_in, d_in_off, in_pitch, in_len, nstreams, flags, obsize, d_out, out_pitch, d_out_len, d_status};
+    hipError_t e = hdlz::launch_inflate(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "launch k_inflate");
+    return HDLZ_OK;
+}
+
+}  // extern "C"

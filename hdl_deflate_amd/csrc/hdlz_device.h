@@ -1,0 +1,55 @@
+// hdlz_device.h -- shared declarations of the HIP side of libhdlz.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include <utility>
+#include "../../include/hdlz.h"
+
+namespace hdlz {
+
+struct CompressArgs {
+    const uint8_t* in;
+    const uint64_t* in_off;   // nullable: then fixed pitch / length
+    uint64_t in_pitch;
+    uint32_t in_len;
+    uint64_t nblocks;
+    int cwindow;
+    int maxmatch;
+    uint8_t* out;
+    uint64_t out_pitch;
+    uint32_t* out_len;
+    uint32_t* status;
+};
+
+struct InflateArgs {
+    const uint8_t* in;
+    const uint64_t* in_off;
+    uint64_t in_pitch;
+    uint32_t in_len;
+    uint64_t nstreams;
+    uint32_t flags;
+    uint32_t obsize;
+    uint8_t* out;
+    uint64_t out_pitch;
+    uint32_t* out_len;
+    uint32_t* status;
+};
+
+__host__ __device__ inline uint32_t out_bound(uint32_t n) {
+    return 6u + (uint32_t)((9ull * n + 10ull + 7ull) >> 3);
+}
+
+// compile-time counted loop: body(std::integral_constant<int, I>{}) for I in [B, E)
+template <int B, int E, class F>
+__host__ __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+hipError_t launch_compress(const CompressArgs& a, hipStream_t stream);
+hipError_t launch_inflate(const InflateArgs& a, hipStream_t stream);
+
+}  // namespace hdlz

@@ -1,0 +1,92 @@
+"""Synthetic inputs shaped like the reference's test data families (test_deflate.py:38-66).
+
+family 1  "   Hello World! <i>     " joined by " "      (text + running counter)
+family 2  "Hi: <rand 0..4095> " joined by " "
+family 3  uniform random bytes
+family 4  random '0'/'1' characters
+`family_bytes` is the exact small-scale Python form (seeded); `make_blocks` builds millions of
+distinct blocks directly on the GPU with the same textual shape (SURVEY 8(d) cfg 2: block b is
+family 1 + (b mod 4); family 1's counter starts at b*16 so blocks differ; the working set must be
+far larger than the 256 MB Infinity Cache -- no tiling of a small pool)."""
+import random
+
+
+def family_bytes(f, n, seed=1, counter0=0):
+    r = random.Random(seed)
+    if f == 1:
+        s = " ".join("   Hello World! " + str(counter0 + i) + "     " for i in range(n // 10 + 2)).encode()
+    elif f == 2:
+        s = " ".join("Hi: " + str(r.randrange(0, 0x1000)) + " " for _ in range(n // 4 + 2)).encode()
+    elif f == 3:
+        s = bytes(r.randrange(256) for _ in range(n))
+    elif f == 4:
+        s = "".join(str(r.randrange(2)) for _ in range(n)).encode()
+    else:
+        raise ValueError("family %r" % (f,))
+    return s[:n]
+
+
+def _ndigits(torch, v):
+    return 1 + (v >= 10).long() + (v >= 100).long() + (v >= 1000).long() + (v >= 10000).long() + \
+        (v >= 100000).long() + (v >= 1000000).long() + (v >= 10000000).long() + (v >= 100000000).long()
+
+
+def _item_text(torch, numbers, prefix, suffix_len, n, device):
+    """rows of `prefix + str(number) + ' '*suffix_len` items, cut to n bytes per row -> uint8 [B, n]"""
+    B, K = numbers.shape
+    L = _ndigits(torch, numbers)
+    plen = len(prefix)
+    ilen = plen + L + suffix_len
+    ends = torch.cumsum(ilen, dim=1)                                   # [B, K]
+    pos = torch.arange(n, device=device).unsqueeze(0).expand(B, n).contiguous()
+    idx = torch.searchsorted(ends, pos, right=True).clamp_(max=K - 1)  # item containing each position
+    start = torch.gather(ends - ilen, 1, idx)
+    o = pos - start                                                    # offset inside the item
+    num = torch.gather(numbers, 1, idx)
+    Ln = torch.gather(L, 1, idx)
+    pfx = torch.tensor(list(prefix.encode()), dtype=torch.uint8, device=device)
+    ch = torch.full((B, n), 32, dtype=torch.uint8, device=device)      # spaces
+    in_p = o < plen
+    ch[in_p] = pfx[o[in_p]]
+    in_d = (o >= plen) & (o < plen + Ln)
+    k = (plen + Ln - 1 - o).clamp_(min=0)                               # power of ten of this digit
+    p10 = torch.tensor([10 ** e for e in range(10)], dtype=torch.int64, device=device)
+    dig = (num // p10[k.clamp(max=9)]) % 10
+    ch[in_d] = (dig[in_d] + 48).to(torch.uint8)
+    return ch
+
+
+def make_blocks(nblocks, n, device, seed=0, families=(1, 2, 3, 4), first_block=0, chunk=16384):
+    """uint8 [nblocks, n] on `device`; block b (global index first_block + b) is family
+    families[b % len(families)], every block distinct."""
+    import torch
+    g = torch.Generator(device=device)
+    out = torch.empty((nblocks, n), dtype=torch.uint8, device=device)
+    nf = len(families)
+    for c0 in range(0, nblocks, chunk):
+        c1 = min(nblocks, c0 + chunk)
+        for fi, f in enumerate(families):
+            gb = torch.arange(first_block + c0, first_block + c1, device=device)
+            sel = torch.nonzero((gb % nf) == fi).squeeze(1)
+            rows = c0 + sel
+            gsel = gb[sel]
+            B = rows.numel()
+            if B == 0:
+                continue
+            g.manual_seed(seed * 1000003 + (first_block + c0) * 7 + f)
+            if f == 3:
+                blk = torch.randint(0, 256, (B, n), generator=g, device=device, dtype=torch.uint8)
+            elif f == 4:
+                blk = torch.randint(0, 2, (B, n), generator=g, device=device, dtype=torch.uint8) + 48
+            elif f == 2:
+                K = n // 7 + 2
+                nums = torch.randint(0, 0x1000, (B, K), generator=g, device=device, dtype=torch.int64)
+                blk = _item_text(torch, nums, "Hi: ", 2, n, device)
+            elif f == 1:
+                K = n // 23 + 2
+                nums = gsel.unsqueeze(1) * 16 + torch.arange(K, device=device).unsqueeze(0)
+                blk = _item_text(torch, nums, "   Hello World! ", 6, n, device)
+            else:
+                raise ValueError("family %r" % (f,))
+            out[rows] = blk
+    return out

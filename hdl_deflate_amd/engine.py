@@ -1,0 +1,102 @@
+"""Batch engine: thin Python over the C-ABI (include/hdlz.h).  torch is used for device memory and
+streams only.  All tensors live on the GPU; nothing here computes on the CPU."""
+import torch
+
+from . import _lib
+from .constants import OK, pitch_for
+from .errors import Error
+
+
+class Engine(object):
+    """One engine per process/GPU.  Methods enqueue on torch's current stream and return device tensors."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("hdl_deflate_amd.Engine needs a HIP device (gfx950); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.lib.hdlz_device_count() < 1:
+            raise RuntimeError("no gfx950 device visible to libhdlz")
+
+    # -- helpers
+    def _check(self, rc, what):
+        if rc != OK:
+            raise Error("%s failed: %s (%s)" % (what, self.lib.hdlz_status_string(rc).decode(),
+                                                self.lib.hdlz_last_error().decode()))
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def _prep(self, d_in, in_off, in_len, nblocks):
+        assert d_in.is_cuda and d_in.dtype == torch.uint8 and d_in.is_contiguous()
+        if in_off is not None:
+            assert in_off.is_cuda and in_off.dtype == torch.int64 and in_off.is_contiguous()
+            nb = in_off.numel() - 1
+            return in_off.data_ptr(), 0, 0, nb
+        assert d_in.dim() == 2 or nblocks is not None
+        if d_in.dim() == 2:
+            nb, pitch = d_in.shape
+            return None, pitch, (pitch if in_len is None else in_len), nb
+        return None, in_len, in_len, nblocks
+
+    # -- STARTC for a batch
+    def compress_batch(self, d_in, in_off=None, in_len=None, nblocks=None, cwindow=32, maxmatch=10,
+                       out=None, out_pitch=None, max_len=None):
+        """d_in: uint8 [B, pitch] (fixed-size blocks) or flat uint8 with in_off int64[B+1].
+        Returns (out uint8[B, out_pitch], out_len int32[B], status int32[B])."""
+        off_ptr, pitch, ilen, nb = self._prep(d_in, in_off, in_len, nblocks)
+        if out_pitch is None:
+            if max_len is None:
+                max_len = ilen if in_off is None else int((in_off[1:] - in_off[:-1]).max().item()) if nb else 0
+            out_pitch = pitch_for(max_len)
+        if out is None:
+            out = torch.empty((nb, out_pitch), dtype=torch.uint8, device=d_in.device)
+        out_len = torch.empty(nb, dtype=torch.int32, device=d_in.device)
+        status = torch.empty(nb, dtype=torch.int32, device=d_in.device)
+        rc = self.lib.hdlz_compress_batch(d_in.data_ptr(), off_ptr, pitch, ilen, nb, cwindow, maxmatch,
+                                          out.data_ptr(), out_pitch, out_len.data_ptr(), status.data_ptr(),
+                                          self._stream())
+        self._check(rc, "hdlz_compress_batch")
+        return out, out_len, status
+
+    # -- STARTD for a batch
+    def inflate_batch(self, d_in, in_off=None, in_len=None, nblocks=None, out_pitch=None, flags=0, obsize=0,
+                      out=None):
+        off_ptr, pitch, ilen, nb = self._prep(d_in, in_off, in_len, nblocks)
+        assert out_pitch is not None and out_pitch % 4 == 0
+        if out is None:
+            out = torch.empty((nb, out_pitch), dtype=torch.uint8, device=d_in.device)
+        out_len = torch.empty(nb, dtype=torch.int32, device=d_in.device)
+        status = torch.empty(nb, dtype=torch.int32, device=d_in.device)
+        rc = self.lib.hdlz_inflate_batch(d_in.data_ptr(), off_ptr, pitch, ilen, nb, flags, obsize,
+                                         out.data_ptr(), out_pitch, out_len.data_ptr(), status.data_ptr(),
+                                         self._stream())
+        self._check(rc, "hdlz_inflate_batch")
+        return out, out_len, status
+
+    # -- single-stream conveniences used by the port adapter (one START = one block)
+    def compress_bytes(self, data, cwindow=32, maxmatch=10):
+        """-> (status, bytes)"""
+        n = len(data)
+        pad = (n + 15) // 16 * 16 + 16
+        host = torch.zeros(pad, dtype=torch.uint8)
+        if n:
+            host[:n] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        d = host.to(self.device).view(1, pad)
+        out, ol, st = self.compress_batch(d, in_len=n, cwindow=cwindow, maxmatch=maxmatch)
+        st = int(st.item())
+        return st, bytes(out[0, :int(ol.item())].cpu().numpy().tobytes())
+
+    def inflate_bytes(self, z, out_cap=None, flags=0, obsize=0):
+        n = len(z)
+        pad = (n + 15) // 16 * 16 + 16
+        host = torch.zeros(pad, dtype=torch.uint8)
+        if n:
+            host[:n] = torch.frombuffer(bytearray(z), dtype=torch.uint8)
+        d = host.to(self.device).view(1, pad)
+        cap = out_cap if out_cap is not None else max(1 << 16, 260 * n)
+        cap = (cap + 15) // 16 * 16
+        out, ol, st = self.inflate_batch(d, in_len=n, out_pitch=cap, flags=flags, obsize=obsize)
+        st = int(st.item())
+        return st, bytes(out[0, :int(ol.item())].cpu().numpy().tobytes())

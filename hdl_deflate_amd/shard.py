@@ -1,0 +1,43 @@
+"""Multi-GPU block sharding.
+
+Every block is an independent zlib stream (own header, own Adler-32, no cross-block history: the
+reference has exactly one stream per START), so the node's GPUs are used as an embarrassingly
+parallel shard: rank r owns a contiguous range of blocks, inputs are resident per GPU, and the ONLY
+exchange step is an all-gather of the per-block uint32 output lengths (RCCL over xGMI with backend
+"nccl"; gloo on CPU in the tests) followed by an exclusive scan that gives every block its offset in
+the concatenated archive.  No payload crosses xGMI on the timed path."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(nblocks, rank, world):
+    """contiguous range [b0, b1) of rank `rank`; sizes differ by at most one block"""
+    base, rem = divmod(nblocks, world)
+    b0 = rank * base + min(rank, rem)
+    return b0, b0 + base + (1 if rank < rem else 0)
+
+
+def gather_lengths(local_len, nblocks, group=None):
+    """all-gather per-block output lengths of contiguous shards -> int32 [nblocks] on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        assert local_len.numel() == nblocks
+        return local_len.to(torch.int32)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = [shard_range(nblocks, r, world) for r in range(world)]
+    maxn = max(b1 - b0 for b0, b1 in sizes)
+    b0, b1 = sizes[rank]
+    assert local_len.numel() == b1 - b0
+    pad = torch.zeros(maxn, dtype=torch.int32, device=local_len.device)
+    pad[:b1 - b0] = local_len.to(torch.int32)
+    full = torch.empty(world * maxn, dtype=torch.int32, device=local_len.device)
+    dist.all_gather_into_tensor(full, pad, group=group)
+    parts = [full[r * maxn: r * maxn + (s1 - s0)] for r, (s0, s1) in enumerate(sizes)]
+    return torch.cat(parts)
+
+
+def archive_offsets(all_len):
+    """exclusive scan of the gathered lengths -> (int64 offsets [nblocks], total bytes)"""
+    l64 = all_len.to(torch.int64)
+    incl = torch.cumsum(l64, 0)
+    return incl - l64, int(incl[-1].item()) if l64.numel() else 0

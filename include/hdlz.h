@@ -1,0 +1,100 @@
+/*
+ * hdlz.h -- C-ABI of the MI355X-native HDL-deflate engine (libhdlz.so).
+ *
+ * This is the drop-in boundary for the one hot path of tomtor/HDL-deflate: everything that
+ * happens between STARTC/STARTD and o_done inside the reference's `deflate(...)` block
+ * (/root/reference/deflate.py:219-221 port list, :607-1664 engine).  The reference moves one
+ * byte per clock through i_data/o_byte (deflate.py:599-605); here whole batches of independent
+ * blocks are handed over as device buffers.  The Python port-protocol adapter
+ * (hdl_deflate_amd/port.py) re-creates the IDLE/WRITE/READ/STARTC/STARTD surface on top of
+ * these entry points; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HBM); the library never allocates, frees or
+ *     retains caller memory; all work is enqueued asynchronously on `stream` (a hipStream_t
+ *     passed as void*; NULL = the default stream);
+ *   - block b of a batch is d_in[in_off[b] .. in_off[b+1]) when d_in_off != NULL, otherwise
+ *     d_in[b*in_pitch .. b*in_pitch + in_len);
+ *   - output of block b goes to d_out + b*out_pitch; out_pitch % 4 == 0 and d_out 4-byte
+ *     aligned (16 recommended); d_out_len[b] receives the byte count (the reference's final
+ *     o_oprogress, deflate.py:814 / :1554), d_status[b] one of HDLZ_OK / HDLZ_E_*;
+ *   - the return value is HDLZ_OK or HDLZ_E_BAD_PARAM / HDLZ_E_HIP for host-side failures;
+ *     per-block failures are only reported through d_status.
+ * There is no CPU implementation behind this ABI: without a gfx950 device every compute entry
+ * point returns HDLZ_E_HIP.
+ */
+#ifndef HDLZ_H
+#define HDLZ_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HDLZ_VERSION 0x000100
+
+/* command codes of the reference port surface (deflate.py:18) -- used by the adapter */
+enum { HDLZ_IDLE = 0, HDLZ_WRITE = 1, HDLZ_READ = 2, HDLZ_STARTC = 3, HDLZ_STARTD = 4 };
+
+/* per-block status.  The reference has no error port: where it raises a Python `Error`
+ * (deflate.py, 22 sites) or stalls forever, this engine reports a status instead. */
+enum {
+    HDLZ_OK = 0,
+    HDLZ_E_SHORT_INPUT = 1,         /* N < 5: reference never starts (deflate.py:429-431, :740-741; README:194) */
+    HDLZ_E_OUT_CAPACITY = 2,        /* compress: out_pitch < hdlz_out_bound(n); inflate: output exceeds out_pitch */
+    HDLZ_E_BAD_BTYPE = 3,           /* "Bad method" (deflate.py:719-721) */
+    HDLZ_E_BAD_DISTANCE = 4,        /* distance code 30/31, distance > bytes produced or > obsize (deflate.py:1506-1508, :1581) */
+    HDLZ_E_NO_EOF = 5,              /* "NO EOF!" (deflate.py:1535-1539) or input exhausted (:1600-1602 would stall) */
+    HDLZ_E_DYNAMIC_UNSUPPORTED = 6, /* BTYPE=2 block met (dynamic trees: SURVEY 8(f) rank 1, not built yet) */
+    HDLZ_E_BAD_SYMBOL = 7,          /* literal/length symbol 286/287 ("< 1 bits", deflate.py:1437-1439) */
+    HDLZ_E_BAD_PARAM = 8,
+    HDLZ_E_HIP = 9                  /* HIP runtime error / no device; see hdlz_last_error() */
+};
+
+/* inflate flags */
+#define HDLZ_INFLATE_ASSUME_FIXED 1u /* DYNAMIC=False build: every block is decoded as BTYPE=1 (deflate.py:724-732) */
+
+int hdlz_version(void);
+const char* hdlz_status_string(int status);
+const char* hdlz_last_error(void);
+
+/* number of visible HIP devices with a gfx950 agent; 0 if none (then nothing below can run) */
+int hdlz_device_count(void);
+
+/* Worst-case compressed size of an n-byte block: 2 header bytes + 3 block-header bits + 9 bits
+ * per literal + 7 EOB bits, padded, + 4 Adler bytes = 6 + ceil((9n+10)/8)  (SURVEY 8(a)). */
+size_t hdlz_out_bound(size_t n);
+
+/*
+ * STARTC for a batch: zlib stream 78 9C, ONE final fixed-Huffman block, LZ77 with a `cwindow`
+ * byte look-back, nearest 3-byte match extended to at most `maxmatch` bytes, greedy parse,
+ * Adler-32 trailer.  Replaces deflate.py:616-633 (IDLE/STARTC), :1064-1082 (STATIC),
+ * :734-834 (CSTATIC), :966-1016 (SEARCH), :899-964 (SEARCHF), :1018-1062 (SEARCH10),
+ * :836-882 (DISTANCE), :884-897 (CHECKSUM), :535-567 (put/do_flush), :407-421 (matcher3),
+ * :423-515 (fill_buf).  Output is bit-identical to the reference for the same
+ * (bytes, CWINDOW, MATCH10): cwindow in [1,256] (reference builds: 32 FAST/LOWLUT, 256
+ * otherwise, deflate.py:56-59), maxmatch 10 (MATCH10=True) or 5 (deflate.py:34-35).
+ */
+int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
+                        uint64_t nblocks, int cwindow, int maxmatch, uint8_t* d_out, uint64_t out_pitch,
+                        uint32_t* d_out_len, uint32_t* d_status, void* stream);
+
+/*
+ * STARTD for a batch of independent zlib streams: 2 header bytes skipped unvalidated, blocks
+ * until BFINAL, stored (BTYPE 0) and fixed-Huffman (BTYPE 1) blocks, 4 trailer bytes required
+ * but Adler-32 not verified -- exactly the reference's acceptance (deflate.py:635-651 IDLE/STARTD,
+ * :656-732 HEADER, :1402-1445 NEXT, :1519-1591 INFLATE, :1593-1659 COPY, :517-533 get4/adv).
+ * `obsize` != 0 selects the reference-exact behaviour of an OBSIZE build (deflate.py:61-62):
+ * back-references may reach at most obsize bytes and a stored block's LEN is taken modulo
+ * 2^floor(log2(obsize)) because the reference's `length` register is LOBSIZE bits wide
+ * (deflate.py:329, :714).  obsize == 0 = RFC1951 behaviour (32 KiB history, 16-bit LEN).
+ */
+int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
+                       uint64_t nstreams, uint32_t flags, uint32_t obsize, uint8_t* d_out, uint64_t out_pitch,
+                       uint32_t* d_out_len, uint32_t* d_status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDLZ_H */

@@ -1,0 +1,36 @@
+import json
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """the CPU oracle (checker only; see oracle/hdlz_oracle.c header)"""
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """the HIP engine through the C-ABI; fails loudly when the extension or the GPU is missing"""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import hdl_deflate_amd
+    return hdl_deflate_amd.Engine()

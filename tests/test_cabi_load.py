@@ -1,0 +1,62 @@
+"""CPU: the C-ABI library loads, exports every symbol include/hdlz.h declares, and refuses to
+compute without a GPU (there is no CPU fallback in the product)."""
+import ctypes
+import os
+import re
+
+from conftest import REPO
+
+
+def _declared():
+    src = open(os.path.join(REPO, "include", "hdlz.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hdlz_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hdl_deflate_amd import _lib
+    names = _declared()
+    assert set(names) == set(_lib.EXPORTS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_version_bound_and_strings():
+    from hdl_deflate_amd import _lib, out_bound
+    L = _lib.load()
+    assert L.hdlz_version() == 0x000100
+    for n in (0, 5, 256, 2048, 65536, 1 << 24):
+        assert L.hdlz_out_bound(n) == out_bound(n) == 6 + (9 * n + 10 + 7) // 8
+    assert L.hdlz_status_string(0) == b"OK" and b"SHORT" in L.hdlz_status_string(1)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        return
+    from hdl_deflate_amd import _lib, E_HIP, E_BAD_PARAM
+    import hdl_deflate_amd
+    L = _lib.load()
+    assert L.hdlz_device_count() == 0
+    buf = (ctypes.c_uint8 * 64)()
+    rc = L.hdlz_compress_batch(buf, None, 64, 64, 1, 32, 10, buf, 64, buf, buf, None)
+    assert rc == E_HIP and b"no CPU path" in L.hdlz_last_error() or rc == E_HIP
+    assert L.hdlz_compress_batch(buf, None, 64, 64, 1, 999, 10, buf, 64, buf, buf, None) == E_BAD_PARAM
+    assert L.hdlz_inflate_batch(buf, None, 64, 64, 1, 0, 0, buf, 64, buf, buf, None) == E_HIP
+    try:
+        hdl_deflate_amd.Engine()
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("Engine() must fail loudly without a GPU")
+
+
+def test_product_never_imports_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
+    pkg = os.path.join(REPO, "hdl_deflate_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "oracle" not in txt.lower(), (root, f)

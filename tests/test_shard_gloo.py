@@ -1,0 +1,69 @@
+"""CPU, world_size 2 over gloo: the N>1 path of SURVEY 8(e) -- contiguous block shards, all-gather of
+per-block output lengths, exclusive scan for archive offsets.  No payload collective exists."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hdl_deflate_amd.shard import shard_range, gather_lengths, archive_offsets
+
+
+def test_shard_range_covers_everything():
+    for nb in (0, 1, 7, 8, 9, 131072, 1000003):
+        for w in (1, 2, 3, 4, 8):
+            rs = [shard_range(nb, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == nb
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, nblocks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from hdl_deflate_amd.data import family_bytes
+        b0, b1 = shard_range(nblocks, rank, world)
+        blocks = [family_bytes(1 + b % 4, 300 + (b % 5), seed=b, counter0=16 * b) for b in range(b0, b1)]
+        lens = torch.tensor([len(O.compress(x)[1]) for x in blocks], dtype=torch.int32)
+        all_len = gather_lengths(lens, nblocks)
+        offs, total = archive_offsets(all_len)
+        q.put((rank, all_len.tolist(), offs.tolist(), total))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_length_allgather_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    nblocks, world = 11, 2           # uneven shards: 6 + 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, nblocks, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    from oracle import oracle as O
+    from hdl_deflate_amd.data import family_bytes
+    want = [len(O.compress(family_bytes(1 + b % 4, 300 + (b % 5), seed=b, counter0=16 * b))[1]) for b in range(nblocks)]
+    for rank, all_len, offs, total in res:
+        assert all_len == want
+        assert offs == list(np.cumsum([0] + want[:-1]))
+        assert total == sum(want)
+
+
+def test_single_process_passthrough():
+    l = torch.tensor([3, 4, 5], dtype=torch.int32)
+    assert gather_lengths(l, 3).tolist() == [3, 4, 5]
+    offs, tot = archive_offsets(l)
+    assert offs.tolist() == [0, 3, 7] and tot == 12
