@@ -34,6 +34,24 @@ constexpr int LOOKAHEAD = 16;       // bytes staged behind the tile (need p+9 an
 constexpr int IN_BYTES = HALO + TILE + LOOKAHEAD;   // 2320
 constexpr int OUT_WORDS = 592;      // 9 bits * 2048 = 576 words + carry word + slack
 constexpr uint32_t ADLER_MOD = 65521u;
+#ifndef WAVES_PER_EU
+#define WAVES_PER_EU 1
+#endif
+// fence for the instruction scheduler: keeps independent phases from being overlapped (which blew the
+// VGPR budget to 239 and spilled ~200 SGPR lane masks in the first version)
+#define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// value fence: an empty asm that "redefines" each element pins producers before / consumers after this
+// point in program order (no instruction is emitted)
+template <int N>
+__device__ __forceinline__ void pin(uint32_t (&a)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) asm volatile("" : "+v"(a[i]));
+}
+template <int B, int E, int N>
+__device__ __forceinline__ void pin_range(uint32_t (&a)[N]) {
+#pragma unroll
+    for (int i = B; i < E; i++) asm volatile("" : "+v"(a[i]));
+}
 
 struct __attribute__((aligned(16))) WaveLds {
     uint32_t in[IN_BYTES / 4];      // byte index = position - tile_start + HALO
@@ -90,7 +108,7 @@ __device__ __forceinline__ void match_bits(uint32_t m, uint32_t d, uint32_t& cod
 }
 
 template <int NCH>   // NCH = ceil(cwindow / 32): 1, 2 or 8 chunks of 32 candidate distances
-__global__ __launch_bounds__(64) void k_compress(CompressArgs a) {
+__global__ __launch_bounds__(64, WAVES_PER_EU) void k_compress(CompressArgs a) {
     __shared__ WaveLds lds;
     const uint32_t lane = threadIdx.x;
     const uint64_t blk = blockIdx.x;
@@ -186,6 +204,8 @@ __global__ __launch_bounds__(64) void k_compress(CompressArgs a) {
         uint32_t ko[RUN];
         static_for<0, RUN>([&](auto I) { constexpr int i = decltype(I)::value; ko[i] = key3<i>(ow, (uint32_t)(i + 32)); });
 
+        pin(ko); pin(ow);
+        PHASE_FENCE();
         uint32_t best[RUN];                                       // nearest distance, >= 0x10000 = none
 #pragma unroll
         for (int i = 0; i < RUN; i++) best[i] = 0xFFFFFFFFu;
@@ -228,6 +248,7 @@ __global__ __launch_bounds__(64) void k_compress(CompressArgs a) {
                         else if constexpr (use0) m[i] = min(m[i], ko[i] - kc0);
                         else if constexpr (use1) m[i] = min(m[i], ko[i] - kc1);
                     });
+                    if constexpr ((j & 7) == 6) { pin(m); PHASE_FENCE(); }
                 }
             });
 #pragma unroll
@@ -235,6 +256,8 @@ __global__ __launch_bounds__(64) void k_compress(CompressArgs a) {
                 if (m[i] < 64u) best[i] = m[i] + 32u * (uint32_t)k;
         }
 
+        pin(best); pin(ow);
+        PHASE_FENCE();
         // ------------------------------------------------------------------ 3. eligibility + extension
         // afterwards tok[i] = (len << 16) | dist  with len = 1 (literal) or 3..10
         const uint32_t p_run = t0 + lane * RUN;                   // first position of this run
@@ -262,8 +285,11 @@ __global__ __launch_bounds__(64) void k_compress(CompressArgs a) {
             mlen = min(mlen, kmax);
             mlen = min(mlen, n - 2u - p);                         // never covers the last two bytes
             tok[i] = ok ? ((mlen << 16) | d) : (1u << 16);
+            if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(tok); pin(ow); PHASE_FENCE(); }
         });
 
+        pin(tok); pin(ow);
+        PHASE_FENCE();
         // ------------------------------------------------------------------ 4. greedy parse
         // backward pass: E[i] = exit skip if a token starts at local index i; nibbles of P hold E[i+1..i+10]
         uint64_t P = 0x9876543210ull;
@@ -279,20 +305,30 @@ __global__ __launch_bounds__(64) void k_compress(CompressArgs a) {
             const uint32_t plo = (uint32_t)P, phi = (uint32_t)(P >> 32);
             uint32_t s = skip_in;
             uint64_t sv[4] = {0, 0, 0, 0};     // entry skips of all 64 lanes, one nibble each (scalar regs)
+            // 4 segments of 16 lanes; the scheduling barriers keep the compiler from hoisting all 128
+            // readlanes to the top (that needed ~260 SGPR spills = v_writelane/v_readlane traffic)
+            static_for<0, 4>([&](auto G) {
+                constexpr int g = decltype(G)::value;
+                uint64_t acc = 0;
 #pragma unroll
-            for (int l = 0; l < 64; l++) {
-                sv[l >> 4] |= (uint64_t)s << (4 * (l & 15));
-                // NB: readlane returns a signed int -- cast before widening or bit 31 smears into the high half
-                const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, l) << 32) |
-                                   (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)plo, l);
-                s = (uint32_t)(f >> (4u * s)) & 15u;
-            }
+                for (int l = 0; l < 16; l++) {
+                    acc |= (uint64_t)s << (4 * l);
+                    // NB: readlane returns a signed int -- cast before widening or bit 31 smears into the high half
+                    const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, g * 16 + l) << 32) |
+                                       (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)plo, g * 16 + l);
+                    s = (uint32_t)(f >> (4u * s)) & 15u;
+                }
+                sv[g] = acc;
+                __builtin_amdgcn_sched_barrier(0);
+            });
             skip_in = s;
             const uint32_t g = lane >> 4;
             const uint64_t mine = g == 0 ? sv[0] : g == 1 ? sv[1] : g == 2 ? sv[2] : sv[3];
             myskip = (uint32_t)(mine >> (4u * (lane & 15u))) & 15u;
         }
 
+        pin(tok); pin(ow); asm volatile("" : "+v"(myskip));
+        PHASE_FENCE();
         // ------------------------------------------------------------------ 5. token bits
         uint32_t code[RUN];     // (nb << 24) | bits   (bits <= 18)
         uint32_t lane_bits = 0;
@@ -315,8 +351,11 @@ __global__ __launch_bounds__(64) void k_compress(CompressArgs a) {
                 nb = start ? nb : 0u;
                 code[i] = bits | (nb << 24);
                 lane_bits += nb;
+                if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(code); asm volatile("" : "+v"(c), "+v"(lane_bits)); PHASE_FENCE(); }
             });
         }
+        pin(code); pin(ow);
+        PHASE_FENCE();
         // wave exclusive scan of lane_bits
         uint32_t incl = lane_bits;
 #pragma unroll
@@ -346,6 +385,7 @@ __global__ __launch_bounds__(64) void k_compress(CompressArgs a) {
             if (fill) atomicOr(&lds.out[widx], (uint32_t)acc);
         }
 
+        PHASE_FENCE();
         // ------------------------------------------------------------------ 6. Adler partials
         {
             uint32_t sa = 0, sc = 0;    // sum x_i, sum i*x_i over the run
