@@ -16,3 +16,5 @@ rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$out/pmc_fetch
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$out/pmc_write" -o t -- $BENCH > "$out/bench_pmc_write.log" 2>&1
 python tools/summarize_prof.py "$out" > "$out/summary.txt" 2>&1
 cat "$out/summary.txt"
+# keep gpurun_out small (<64 MiB is merged back): drop the raw per-dispatch CSVs, keep stats + summary
+find "$out" -name "*kernel_trace.csv" -delete; find "$out" -name "*counter_collection.csv" -delete; find "$out" -name "*agent_info.csv" -delete
