@@ -39,7 +39,11 @@ def main():
     ap.add_argument("--maxmatch", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--verify", type=int, default=256, help="blocks checked against zlib outside the timed region")
+    ap.add_argument("--mode", default="compress", choices=["compress", "inflate"],
+                    help="compress = BASELINE metric (default); inflate = configs[3] side metric (1 GPU)")
     a = ap.parse_args()
+    if a.mode == "inflate":
+        return bench_inflate(a)
 
     import torch
     import torch.distributed as dist
@@ -157,6 +161,97 @@ def main():
     print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _zfixed_chunk(args):
+    import zlib
+    buf, n = args
+    out = []
+    for k in range(0, len(buf), n):
+        co = zlib.compressobj(strategy=zlib.Z_FIXED, wbits=15)
+        out.append(co.compress(buf[k:k + n]) + co.flush())
+    return out
+
+
+def bench_inflate(a):
+    """BASELINE configs[3]: B stock-zlib Z_FIXED streams (wbits=15) over 2 KiB blocks of families 1/2/4
+    (family 3 would make zlib emit stored blocks, which the DYNAMIC=False reference mis-decodes), made on
+    the host cores with stock zlib outside the timed region; DYNAMIC=False semantics
+    (HDLZ_INFLATE_ASSUME_FIXED); every stream checked against the original block."""
+    import multiprocessing as mp
+    import numpy as np
+    import torch
+    import hdl_deflate_amd
+    from hdl_deflate_amd.data import make_blocks
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    eng = hdl_deflate_amd.Engine(dev)
+    B, n = a.blocks, a.block_size
+    d_plain = make_blocks(B, n, dev, seed=4, families=(1, 2, 4))
+    host = d_plain.cpu().numpy()
+    nproc = min(os.cpu_count() or 1, 64)
+    per = (B + nproc - 1) // nproc
+    with mp.get_context("fork").Pool(nproc) as pool:
+        parts = pool.map(_zfixed_chunk, [(host[k:k + per].tobytes(), n) for k in range(0, B, per)])
+    streams = [z for p in parts for z in p]
+    lens = np.fromiter((len(z) for z in streams), dtype=np.int64, count=B)
+    off = np.zeros(B + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    flat = np.frombuffer(b"".join(streams) + bytes(64), dtype=np.uint8)
+    d_in = torch.from_numpy(flat.copy()).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    d_out = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    flags = hdl_deflate_amd.INFLATE_ASSUME_FIXED
+
+    def step():
+        return eng.inflate_batch(d_in, in_off=d_off, out_pitch=n, flags=flags, out=d_out)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out, ol, st = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    evs = []
+    for _ in range(max(3, a.steps)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step()
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    k_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    k_avg = sum(k_ms) / len(k_ms)
+    assert int((st != 0).sum().item()) == 0 and int((ol != n).sum().item()) == 0
+    assert torch.equal(d_out, d_plain), "inflate output differs from the original blocks"
+    z_bytes, u_bytes = int(off[-1]), B * n
+    algo = z_bytes + u_bytes + 4 * B
+    achieved = algo / (k_avg * 1e-3) / 1e9
+    res = {"metric": "inflate_output_throughput (zlib Z_FIXED streams, DYNAMIC=False)",
+           "value": round(u_bytes / (dt / a.steps) / 1e6, 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[3]: %d zlib Z_FIXED streams over %d B blocks, families 1/2/4, "
+                                  "HBM-resident" % (B, n), "streams": B, "block_bytes": n},
+           "input_MBps": round(z_bytes / (dt / a.steps) / 1e6, 1),
+           "compression_ratio_out_over_in": round(z_bytes / u_bytes, 4),
+           "roofline": {"bound": "hbm", "kernel": "k_inflate", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": algo, "kernel_ms_avg": round(k_avg, 4),
+                        "kernel_ms_min": round(k_ms[0], 4)}}
+    if a.cpu_seconds > 0:
+        from oracle import oracle as O
+        cores = os.cpu_count() or 1
+        S = min(B, 1 << 17)
+        t1 = time.perf_counter()
+        _, l2, s2 = O.inflate_batch(flat, off[:S + 1].astype(np.uint64), n, flags=1, nthreads=cores)
+        dtc = time.perf_counter() - t1
+        assert (s2 == 0).all()
+        res["cpu_baseline"] = {"value": round(S * n / dtc / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
+                               "sample": "first %d streams, oracle/hdlz_oracle.c inflate, %d threads, %.2f s" % (S, cores, dtc)}
+    print(json.dumps(res), flush=True)
 
 
 def cpu_baseline(d_in, n, a):

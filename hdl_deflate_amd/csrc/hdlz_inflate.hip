@@ -4,54 +4,67 @@
 // (/root/reference/deflate.py:635-732 IDLE/HEADER, :1402-1445 NEXT, :1519-1591 INFLATE,
 // :1593-1659 COPY, :517-533 get4/adv).  Rule names D0..D8 are SURVEY.md 8(a)'s.
 //
-// Inflate is serial per stream, so the parallelism is ACROSS streams: one lane per stream,
-// 64 streams per wave.  The 512-entry fixed-tree leaf table (the reference's stat_leaves,
-// deflate.py:151-216: leaf = (sym << 4) | nbits, indexed by the next 9 bits) lives in LDS and is
-// generated arithmetically from RFC1951 3.2.6 at kernel start.
+// Inflate is serial per stream, so the parallelism is ACROSS streams: one lane per stream, 64
+// streams per wave, run in LOCKSTEP: every iteration each active lane produces exactly ONE output
+// byte (a literal, a stored byte, or the next byte of a pending LZ copy -- the reference's COPY state
+// also moves one byte per clock, deflate.py:1627-1659).  Consequences:
+//   * the output offset `o` is wave-uniform, so output is staged in a lane-interleaved LDS ring
+//     (dword w of lane l at dword index w*64 + l: every access of the wave hits 64 different banks
+//     whatever the per-lane history offset is) and flushed as 64 full 64-byte lines per 64 iterations
+//   * LZ copies with distance <= 256 read the ring (ds_read_u8); longer distances (up to OBSIZE)
+//     read the stream's own, already flushed, output in HBM/L2
+//   * the decode path and the copy path are both short, so divergence between "lane decodes a
+//     symbol" and "lane continues a copy" costs the sum of two short paths, not a loop of one.
+// The 512-entry fixed-tree leaf table (the reference's stat_leaves, deflate.py:151-216:
+// leaf = (sym << 4) | nbits, indexed by the next 9 bits) lives in LDS, generated from RFC1951 3.2.6.
+// Input is pulled per lane through a 64-bit bit buffer refilled 4 bytes at a time.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
 
 namespace hdlz {
 
-__device__ __forceinline__ uint32_t alignbyte_i(uint32_t hi, uint32_t lo, uint32_t sh) {
-    return __builtin_amdgcn_alignbyte(hi, lo, sh);
-}
+constexpr uint32_t RING_BYTES = 256;          // history kept in LDS per stream
+constexpr uint32_t RING_DW = RING_BYTES / 4;  // dwords per lane
+constexpr uint32_t CHUNK = 64;                // bytes per stream per flush
 
-// 8 bytes of the stream starting at byte `idx` (little endian), zeros past `zn`
-// (the reference's b41 window, deflate.py:348, widened to 64 bits)
-__device__ __forceinline__ uint64_t window64(const uint8_t* __restrict__ z, uint32_t idx, uint32_t zn) {
-    if (idx >= zn) return 0;
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(z) + idx;
-    const uint32_t sh = (uint32_t)(addr & 3u);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(addr - sh);
-    const uint32_t valid = zn - idx;                 // >= 1
-    const uint32_t nd = (valid + sh + 3u) >> 2;      // dwords holding valid bytes
-    const uint32_t a0 = q[0];
-    const uint32_t a1 = nd > 1 ? q[1] : 0u;
-    const uint32_t a2 = nd > 2 ? q[2] : 0u;
-    uint64_t w = ((uint64_t)alignbyte_i(a2, a1, sh) << 32) | alignbyte_i(a1, a0, sh);
-    if (valid < 8u) w &= (1ull << (8u * valid)) - 1ull;
-    return w;
-}
+struct __attribute__((aligned(16))) InflateLds {
+    uint32_t ring[RING_DW * 64];   // 16 KiB: [dword][lane]
+    uint16_t leaves[512];
+};
+
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
 __device__ __forceinline__ uint32_t rev(uint32_t v, uint32_t nbits) { return __builtin_bitreverse32(v) >> (32u - nbits); }
 
+// 4 stream bytes at byte `ip` (little endian); bytes at or beyond zn read as zero (the reference's
+// input memory holds nothing there; the oracle restates it as zeros)
+__device__ __forceinline__ uint32_t load32(const uint8_t* __restrict__ z, uint32_t ip, uint32_t zn) {
+    if (ip + 4u <= zn) return *reinterpret_cast<const u32_unaligned*>(z + ip);
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 4u; k++)
+        if (ip + k < zn) v |= (uint32_t)z[ip + k] << (8u * k);
+    return v;
+}
+
 // RFC1951 tables in closed form (deflate.py:100-110)
 __device__ __forceinline__ void length_info(uint32_t token, uint32_t& base, uint32_t& eb) {
-    // token = sym - 257 in [0, 28]
     if (token < 8u) { base = 3u + token; eb = 0; }
     else if (token == 28u) { base = 258u; eb = 0; }
     else { eb = (token >> 2) - 1u; base = 3u + ((4u + (token & 3u)) << eb); }
 }
 __device__ __forceinline__ void dist_info(uint32_t dc, uint32_t& base, uint32_t& eb) {
-    // dc in [0, 29]
     if (dc < 4u) { base = 1u + dc; eb = 0; }
     else { eb = (dc >> 1) - 1u; base = 1u + ((2u + (dc & 1u)) << eb); }
 }
 
+__device__ __forceinline__ uint32_t ring_addr(uint32_t pos, uint32_t lane) {
+    const uint32_t b = pos & (RING_BYTES - 1u);
+    return ((b >> 2) << 8) | (lane << 2) | (b & 3u);     // byte address inside InflateLds::ring
+}
+
 __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
-    __shared__ uint16_t leaves[512];
+    __shared__ InflateLds lds;
     const uint32_t lane = threadIdx.x;
     // ---- fixed-tree leaf table: index = next 9 stream bits (LSB first)
     for (uint32_t c = lane; c < 512u; c += 64u) {
@@ -59,108 +72,199 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
         const uint32_t r7 = rev(c & 127u, 7);
         const uint32_t r8 = rev(c & 255u, 8);
         const uint32_t r9 = rev(c, 9);
-        if (r7 < 24u) { sym = 256u + r7; nb = 7; }                     // 0000000..0010111
-        else if (r8 >= 0x30u && r8 < 0xC0u) { sym = r8 - 0x30u; nb = 8; } // 00110000..10111111
+        if (r7 < 24u) { sym = 256u + r7; nb = 7; }                        // 0000000..0010111
+        else if (r8 >= 0x30u && r8 < 0xC0u) { sym = r8 - 0x30u; nb = 8; }  // 00110000..10111111
         else if (r8 >= 0xC0u && r8 < 0xC8u) { sym = 280u + (r8 - 0xC0u); nb = 8; }
-        else { sym = r9 - 256u; nb = 9; }                              // 110010000..111111111 -> 144..255
+        else { sym = r9 - 256u; nb = 9; }                                 // 110010000..111111111 -> 144..255
         uint32_t leaf = (sym << 4) | nb;
         if (sym == 287u) leaf = 0;      // the reference's table holds 0 there (deflate.py:212) -> "< 1 bits"
-        leaves[c] = (uint16_t)leaf;
+        lds.leaves[c] = (uint16_t)leaf;
     }
     __syncthreads();
 
-    const uint64_t sid = (uint64_t)blockIdx.x * 64u + lane;
-    if (sid >= a.nstreams) return;
-    uint64_t off;
-    uint32_t zn;
-    if (a.in_off) {
-        off = a.in_off[sid];
-        zn = (uint32_t)(a.in_off[sid + 1] - off);
-    } else {
-        off = sid * a.in_pitch;
-        zn = a.in_len;
+    const uint64_t sid0 = (uint64_t)blockIdx.x * 64u;
+    const uint64_t sid = sid0 + lane;
+    const bool exists = sid < a.nstreams;
+    uint64_t off = 0;
+    uint32_t zn = 0;
+    if (exists) {
+        if (a.in_off) {
+            off = a.in_off[sid];
+            zn = (uint32_t)(a.in_off[sid + 1] - off);
+        } else {
+            off = sid * a.in_pitch;
+            zn = a.in_len;
+        }
     }
     const uint8_t* __restrict__ z = a.in + off;
     uint8_t* __restrict__ out = a.out + sid * a.out_pitch;
-    const uint64_t cap = a.out_pitch;
+    uint8_t* ring8 = reinterpret_cast<uint8_t*>(lds.ring);
+    const uint32_t cap = a.out_pitch > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a.out_pitch;
     // obsize != 0: reference-exact OBSIZE build -- the stored LEN register is LOBSIZE bits wide
     // (deflate.py:329,:714), so LEN is taken mod 2^floor(log2(obsize)); obsize == 0: RFC behaviour.
     const uint32_t obsize = a.obsize ? a.obsize : 32768u;
     const uint32_t len_mask = a.obsize ? ((1u << (31u - (uint32_t)__builtin_clz(a.obsize))) - 1u) : 0xFFFFu;
     const bool assume_fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) != 0;
+    const bool out16 = ((reinterpret_cast<uintptr_t>(a.out) | a.out_pitch) & 15u) == 0;
+    const int32_t isize = (int32_t)zn - 1;            // deflate.py:605
 
     uint32_t status = HDLZ_OK;
-    uint32_t dout = 0;
-    if (zn < 5u) {
-        status = HDLZ_E_SHORT_INPUT;
-    } else {
-        const int32_t isize = (int32_t)zn - 1;            // deflate.py:605
-        uint32_t bitpos = 16;                             // D0: zlib header skipped unvalidated
-        for (;;) {
-            // HEADER (deflate.py:677-732)
-            uint64_t w = window64(z, bitpos >> 3, zn) >> (bitpos & 7u);
-            const uint32_t final = (uint32_t)w & 1u;
-            const uint32_t hm = assume_fixed ? 1u : ((uint32_t)(w >> 1) & 3u);
-            if (hm == 3u) { status = HDLZ_E_BAD_BTYPE; break; }
-            if (hm == 2u) { status = HDLZ_E_DYNAMIC_UNSUPPORTED; break; }
-            if (hm == 0u) {
-                // stored (deflate.py:709-717, COPY :1603-1626)
-                const uint32_t dio = bitpos & 7u;
-                uint32_t skip = 8u - dio;
-                if (skip <= 2u) skip = 16u - dio;
-                const uint32_t length = (uint32_t)(w >> skip) & 0xFFFFu & len_mask;
-                bitpos += skip + 16u;                     // at NLEN (unchecked, D2); data at di+2
-                int32_t di = (int32_t)(bitpos >> 3);
-                for (uint32_t i = 0; i < length; i++) {
-                    if (di >= isize - 2) { status = HDLZ_E_NO_EOF; break; }
-                    if (dout >= cap) { status = HDLZ_E_OUT_CAPACITY; break; }
-                    out[dout++] = z[di + 2];
-                    di++;
+    uint32_t out_len = 0;
+    bool active = exists;
+    if (exists && zn < 5u) { status = HDLZ_E_SHORT_INPUT; active = false; }
+
+    uint64_t bb = 0;            // bit buffer (LSB first)
+    uint32_t bc = 0;            // valid bits in bb
+    uint32_t ip = 2;            // D0: next byte to load; the 2 zlib header bytes are skipped unvalidated
+    uint32_t rem = 0, dist = 0; // pending LZ copy
+    uint32_t srem = 0;          // pending stored bytes
+    uint32_t lit = 0;
+    uint32_t final_ = 0;
+    bool need_header = true;
+
+#define HDLZ_FAIL(code) do { status = (code); out_len = 0; active = false; } while (0)
+#define HDLZ_BITPOS() (8u * ip - bc)
+
+    for (uint32_t o = 0;; ++o) {
+        // ------------------------------------------------------------ 1. fetch the next token where needed
+        bool have = false;
+        while (active && rem == 0u && srem == 0u && !have) {
+            if (bc <= 32u) { bb |= (uint64_t)load32(z, ip, zn) << bc; bc += 32u; ip += 4u; }
+            if (need_header) {
+                // HEADER (deflate.py:677-732)
+                final_ = (uint32_t)bb & 1u;
+                const uint32_t hm = assume_fixed ? 1u : ((uint32_t)(bb >> 1) & 3u);
+                if (hm == 3u) { HDLZ_FAIL(HDLZ_E_BAD_BTYPE); break; }
+                if (hm == 2u) { HDLZ_FAIL(HDLZ_E_DYNAMIC_UNSUPPORTED); break; }
+                need_header = false;
+                if (hm == 0u) {
+                    // stored (deflate.py:709-717): LEN sits `skip` bits after the header start
+                    const uint32_t dio = HDLZ_BITPOS() & 7u;
+                    uint32_t skip = 8u - dio;
+                    if (skip <= 2u) skip = 16u - dio;
+                    const uint32_t length = (uint32_t)(bb >> skip) & 0xFFFFu & len_mask;
+                    bb >>= (skip + 16u); bc -= (skip + 16u);          // now at NLEN = the reference's di
+                    if (bc <= 32u) { bb |= (uint64_t)load32(z, ip, zn) << bc; bc += 32u; ip += 4u; }
+                    bb >>= 16; bc -= 16u;                             // NLEN unchecked (D2); data follows
+                    srem = length;
+                    if (length == 0u) {
+                        // COPY with nothing to copy (deflate.py:1617-1626)
+                        if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize) { HDLZ_FAIL(HDLZ_E_NO_EOF); break; }
+                        if (final_) { out_len = o; active = false; break; }
+                        need_header = true;
+                    }
+                } else {
+                    bb >>= 3; bc -= 3u;
                 }
-                if (status != HDLZ_OK) break;
-                if (di >= isize - 2) { status = HDLZ_E_NO_EOF; break; }
-                if (final) break;
-                bitpos = (uint32_t)(di + 2) * 8u;
                 continue;
             }
-            bitpos += 3u;
-            // NEXT / INFLATE
-            for (;;) {
-                w = window64(z, bitpos >> 3, zn) >> (bitpos & 7u);
-                const uint32_t leaf = leaves[(uint32_t)w & 511u];
-                const uint32_t nb = leaf & 15u, code = leaf >> 4;
-                if (nb < 1u) { status = HDLZ_E_BAD_SYMBOL; break; }
-                bitpos += nb;
-                w >>= nb;
-                if ((int32_t)(bitpos >> 3) > isize - 3) { status = HDLZ_E_NO_EOF; break; }   // deflate.py:1535
-                if (code == 256u) break;
-                if (code < 256u) {
-                    if (dout >= cap) { status = HDLZ_E_OUT_CAPACITY; break; }
-                    out[dout++] = (uint8_t)code;
-                    continue;
-                }
-                const uint32_t token = code - 257u;
-                if (token >= 29u) { status = HDLZ_E_BAD_SYMBOL; break; }
-                uint32_t lbase, leb, dbase, deb;
-                length_info(token, lbase, leb);
-                const uint32_t tlength = lbase + ((uint32_t)w & ((1u << leb) - 1u));
-                w >>= leb;
-                const uint32_t dc = rev((uint32_t)w & 31u, 5);
-                w >>= 5;
-                if (dc >= 30u) { status = HDLZ_E_BAD_DISTANCE; break; }
-                dist_info(dc, dbase, deb);
-                const uint32_t distance = dbase + ((uint32_t)w & ((1u << deb) - 1u));
-                bitpos += leb + 5u + deb;
-                if (distance > dout || distance > obsize) { status = HDLZ_E_BAD_DISTANCE; break; }
-                if ((int32_t)(bitpos >> 3) >= isize - 2) { status = HDLZ_E_NO_EOF; break; }
-                if ((uint64_t)dout + tlength > cap) { status = HDLZ_E_OUT_CAPACITY; break; }
-                for (uint32_t i = 0; i < tlength; i++, dout++) out[dout] = out[dout - distance];
+            // NEXT (deflate.py:1409-1445)
+            const uint32_t leaf = lds.leaves[(uint32_t)bb & 511u];
+            const uint32_t nb = leaf & 15u, code = leaf >> 4;
+            if (nb < 1u) { HDLZ_FAIL(HDLZ_E_BAD_SYMBOL); break; }
+            bb >>= nb; bc -= nb;
+            // INFLATE (deflate.py:1519-1591)
+            if ((int32_t)(HDLZ_BITPOS() >> 3) > isize - 3) { HDLZ_FAIL(HDLZ_E_NO_EOF); break; }   // :1535-1539
+            if (code == 256u) {
+                if (final_) { out_len = o; active = false; break; }   // D6
+                need_header = true;
+                continue;
             }
-            if (status != HDLZ_OK || final) break;
+            if (code < 256u) {
+                if (o >= cap) { HDLZ_FAIL(HDLZ_E_OUT_CAPACITY); break; }
+                lit = code;
+                have = true;
+                break;
+            }
+            const uint32_t token = code - 257u;
+            if (token >= 29u) { HDLZ_FAIL(HDLZ_E_BAD_SYMBOL); break; }
+            uint32_t lbase, leb, dbase, deb;
+            length_info(token, lbase, leb);
+            const uint32_t tlength = lbase + ((uint32_t)bb & ((1u << leb) - 1u));
+            bb >>= leb;
+            const uint32_t dc = rev((uint32_t)bb & 31u, 5);
+            bb >>= 5;
+            if (dc >= 30u) { HDLZ_FAIL(HDLZ_E_BAD_DISTANCE); break; }
+            dist_info(dc, dbase, deb);
+            const uint32_t distance = dbase + ((uint32_t)bb & ((1u << deb) - 1u));
+            bb >>= deb;
+            bc -= leb + 5u + deb;
+            if (distance > o || distance > obsize) { HDLZ_FAIL(HDLZ_E_BAD_DISTANCE); break; }        // D8
+            if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize - 2) { HDLZ_FAIL(HDLZ_E_NO_EOF); break; }      // COPY hold, :1600
+            if ((uint64_t)o + tlength > cap) { HDLZ_FAIL(HDLZ_E_OUT_CAPACITY); break; }
+            rem = tlength;
+            dist = distance;
+        }
+        const uint64_t actmask = __ballot(active);
+        if (actmask == 0ull) break;
+
+        // ------------------------------------------------------------ 2. one output byte per active lane
+        bool wrote = false;        // this lane put a byte into the ring in this iteration
+        if (active) {
+            uint32_t byte;
+            bool stored_done = false;
+            if (rem != 0u) {                                       // COPY (deflate.py:1627-1659)
+                if (dist <= RING_BYTES) byte = ring8[ring_addr(o - dist, lane)];
+                else byte = out[o - dist];
+                rem--;
+            } else if (srem != 0u) {                               // stored COPY (deflate.py:1603-1616)
+                if (bc <= 32u) { bb |= (uint64_t)load32(z, ip, zn) << bc; bc += 32u; ip += 4u; }
+                if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize) { HDLZ_FAIL(HDLZ_E_NO_EOF); }
+                else if (o >= cap) { HDLZ_FAIL(HDLZ_E_OUT_CAPACITY); }
+                byte = (uint32_t)bb & 0xFFu;
+                bb >>= 8; bc -= 8u;
+                srem--;
+                stored_done = (srem == 0u);
+            } else {
+                byte = lit;
+            }
+            if (active) { ring8[ring_addr(o, lane)] = (uint8_t)byte; wrote = true; }
+            if (active && stored_done) {                           // a stored block just ended (deflate.py:1617-1626)
+                if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize) { HDLZ_FAIL(HDLZ_E_NO_EOF); }
+                else if (final_) { out_len = o + 1u; active = false; }
+                else need_header = true;
+            }
+        }
+
+        // ------------------------------------------------------------ 3. flush 64 bytes per stream every 64 iterations
+        if ((o & (CHUNK - 1u)) == CHUNK - 1u) {
+            const uint64_t live = __ballot(wrote);      // lanes that filled this whole chunk (incl. one finishing on it)
+            const uint32_t c0 = o - (CHUNK - 1u);                       // first byte of the chunk
+            const uint32_t w0 = (c0 & (RING_BYTES - 1u)) >> 2;          // its ring dword
+            const uint32_t q = lane & 3u;
+#pragma unroll
+            for (uint32_t r = 0; r < 4u; r++) {
+                const uint32_t s = (lane >> 2) + 16u * r;               // stream (lane index) this lane copies for
+                if ((live >> s) & 1ull) {
+                    const uint32_t* src = &lds.ring[(w0 + 4u * q) * 64u + s];
+                    uint4 v;
+                    v.x = src[0]; v.y = src[64]; v.z = src[128]; v.w = src[192];
+                    uint8_t* dst = a.out + (sid0 + s) * a.out_pitch + c0 + 16u * q;
+                    if (out16) {
+                        *reinterpret_cast<uint4*>(dst) = v;
+                    } else {
+                        uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+                        d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
+                    }
+                }
+            }
+            // later far copies (distance > 256) read these bytes back through L1/L2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
     }
-    a.out_len[sid] = status == HDLZ_OK ? dout : 0u;
-    a.status[sid] = status;
+#undef HDLZ_FAIL
+#undef HDLZ_BITPOS
+
+    // ---- tail: the bytes of the last, partial chunk are still only in the ring
+    if (exists && status == HDLZ_OK) {
+        const uint32_t c0 = out_len & ~(CHUNK - 1u);
+        for (uint32_t p = c0; p < out_len; p++) out[p] = ring8[ring_addr(p, lane)];
+    }
+    if (exists) {
+        a.out_len[sid] = out_len;
+        a.status[sid] = status;
+    }
 }
 
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t stream) {
