@@ -11,7 +11,7 @@
 //   * the output offset `o` is wave-uniform, so output is staged in a lane-interleaved LDS ring
 //     (dword w of lane l at dword index w*64 + l: every access of the wave hits 64 different banks
 //     whatever the per-lane history offset is) and flushed as 64 full 64-byte lines per 64 iterations
-//   * LZ copies with distance <= 256 read the ring (ds_read_u8); longer distances (up to OBSIZE)
+//   * LZ copies with distance <= 128 read the ring (ds_read_u8); longer distances (up to OBSIZE)
 //     read the stream's own, already flushed, output in HBM/L2
 //   * the decode path and the copy path are both short, so divergence between "lane decodes a
 //     symbol" and "lane continues a copy" costs the sum of two short paths, not a loop of one.
@@ -24,16 +24,18 @@
 
 namespace hdlz {
 
-constexpr uint32_t RING_BYTES = 256;          // history kept in LDS per stream
+constexpr uint32_t RING_BYTES = 128;          // history kept in LDS per stream (8 KiB per wave -> ~15 waves per CU)
 constexpr uint32_t RING_DW = RING_BYTES / 4;  // dwords per lane
 constexpr uint32_t CHUNK = 64;                // bytes per stream per flush
 
 struct __attribute__((aligned(16))) InflateLds {
-    uint32_t ring[RING_DW * 64];   // 16 KiB: [dword][lane]
-    uint16_t leaves[512];
+    uint32_t ring[RING_DW * 64];   // [dword][lane]
+    uint32_t lit[512];             // literal/length table, see lit_entry()
+    uint32_t dst[32];              // distance table indexed by the RAW 5 stream bits
 };
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 
 __device__ __forceinline__ uint32_t rev(uint32_t v, uint32_t nbits) { return __builtin_bitreverse32(v) >> (32u - nbits); }
 
@@ -58,6 +60,33 @@ __device__ __forceinline__ void dist_info(uint32_t dc, uint32_t& base, uint32_t&
     else { eb = (dc >> 1) - 1u; base = 1u + ((2u + (dc & 1u)) << eb); }
 }
 
+// literal/length table entry for the next 9 stream bits (the reference's stat_leaves, deflate.py:151-216,
+// widened): nbits[3:0] | sym[12:4] | type[14:13] | lbase[24:16] | leb[27:25]
+//   type 0 literal, 1 length symbol 257..285, 2 end of block, 3 invalid (286: nbits 8; 287: nbits 0 =
+//   the reference's zero leaf at index 483 -> "< 1 bits")
+enum { T_LIT = 0, T_LEN = 1, T_EOB = 2, T_BAD = 3 };
+__device__ __forceinline__ uint32_t lit_entry(uint32_t c) {
+    uint32_t sym, nb;
+    const uint32_t r7 = rev(c & 127u, 7), r8 = rev(c & 255u, 8), r9 = rev(c, 9);
+    if (r7 < 24u) { sym = 256u + r7; nb = 7; }                        // 0000000..0010111
+    else if (r8 >= 0x30u && r8 < 0xC0u) { sym = r8 - 0x30u; nb = 8; }  // 00110000..10111111
+    else if (r8 >= 0xC0u && r8 < 0xC8u) { sym = 280u + (r8 - 0xC0u); nb = 8; }
+    else { sym = r9 - 256u; nb = 9; }                                 // 110010000..111111111 -> 144..255
+    uint32_t type = sym < 256u ? T_LIT : sym == 256u ? T_EOB : sym <= 285u ? T_LEN : T_BAD;
+    uint32_t lbase = 0, leb = 0;
+    if (type == T_LEN) length_info(sym - 257u, lbase, leb);
+    if (sym == 287u) nb = 0;
+    return nb | (sym << 4) | (type << 13) | (lbase << 16) | (leb << 25);
+}
+// distance table entry for the raw 5 bits: dbase[15:0] | deb[19:16], 0xFFFFFFFF for codes 30/31
+__device__ __forceinline__ uint32_t dst_entry(uint32_t raw5) {
+    const uint32_t dc = rev(raw5, 5);
+    if (dc >= 30u) return 0xFFFFFFFFu;
+    uint32_t dbase, deb;
+    dist_info(dc, dbase, deb);
+    return dbase | (deb << 16);
+}
+
 __device__ __forceinline__ uint32_t ring_addr(uint32_t pos, uint32_t lane) {
     const uint32_t b = pos & (RING_BYTES - 1u);
     return ((b >> 2) << 8) | (lane << 2) | (b & 3u);     // byte address inside InflateLds::ring
@@ -66,20 +95,8 @@ __device__ __forceinline__ uint32_t ring_addr(uint32_t pos, uint32_t lane) {
 __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
     __shared__ InflateLds lds;
     const uint32_t lane = threadIdx.x;
-    // ---- fixed-tree leaf table: index = next 9 stream bits (LSB first)
-    for (uint32_t c = lane; c < 512u; c += 64u) {
-        uint32_t sym, nb;
-        const uint32_t r7 = rev(c & 127u, 7);
-        const uint32_t r8 = rev(c & 255u, 8);
-        const uint32_t r9 = rev(c, 9);
-        if (r7 < 24u) { sym = 256u + r7; nb = 7; }                        // 0000000..0010111
-        else if (r8 >= 0x30u && r8 < 0xC0u) { sym = r8 - 0x30u; nb = 8; }  // 00110000..10111111
-        else if (r8 >= 0xC0u && r8 < 0xC8u) { sym = 280u + (r8 - 0xC0u); nb = 8; }
-        else { sym = r9 - 256u; nb = 9; }                                 // 110010000..111111111 -> 144..255
-        uint32_t leaf = (sym << 4) | nb;
-        if (sym == 287u) leaf = 0;      // the reference's table holds 0 there (deflate.py:212) -> "< 1 bits"
-        lds.leaves[c] = (uint16_t)leaf;
-    }
+    for (uint32_t c = lane; c < 512u; c += 64u) lds.lit[c] = lit_entry(c);
+    if (lane < 32u) lds.dst[lane] = dst_entry(lane);
     __syncthreads();
 
     const uint64_t sid0 = (uint64_t)blockIdx.x * 64u;
@@ -121,102 +138,152 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
     uint32_t lit = 0;
     uint32_t final_ = 0;
     bool need_header = true;
+    uint64_t fb = 0;            // far-copy buffer: up to 8 source bytes fetched from the flushed output
+    uint32_t fbn = 0;
+    uint64_t fpre = 0;          // ... and the NEXT 8, requested one refill period ahead (latency hiding)
+    // input prefetch: `pre` always holds the 4 stream bytes at `ip`, loaded one refill period before use,
+    // so the global-load latency is never on the per-iteration critical path
+    uint32_t pre = active ? load32(z, ip, zn) : 0u;
+#define HDLZ_REFILL() do { if (bc <= 32u) { bb |= (uint64_t)pre << bc; bc += 32u; ip += 4u; pre = load32(z, ip, zn); } } while (0)
 
 #define HDLZ_FAIL(code) do { status = (code); out_len = 0; active = false; } while (0)
 #define HDLZ_BITPOS() (8u * ip - bc)
 
     for (uint32_t o = 0;; ++o) {
-        // ------------------------------------------------------------ 1. fetch the next token where needed
+        // ------------------------------------------------------------ 1a. fast path: literal / match inside a fixed block
         bool have = false;
-        while (active && rem == 0u && srem == 0u && !have) {
-            if (bc <= 32u) { bb |= (uint64_t)load32(z, ip, zn) << bc; bc += 32u; ip += 4u; }
-            if (need_header) {
-                // HEADER (deflate.py:677-732)
-                final_ = (uint32_t)bb & 1u;
-                const uint32_t hm = assume_fixed ? 1u : ((uint32_t)(bb >> 1) & 3u);
-                if (hm == 3u) { HDLZ_FAIL(HDLZ_E_BAD_BTYPE); break; }
-                if (hm == 2u) { HDLZ_FAIL(HDLZ_E_DYNAMIC_UNSUPPORTED); break; }
-                need_header = false;
-                if (hm == 0u) {
-                    // stored (deflate.py:709-717): LEN sits `skip` bits after the header start
-                    const uint32_t dio = HDLZ_BITPOS() & 7u;
-                    uint32_t skip = 8u - dio;
-                    if (skip <= 2u) skip = 16u - dio;
-                    const uint32_t length = (uint32_t)(bb >> skip) & 0xFFFFu & len_mask;
-                    bb >>= (skip + 16u); bc -= (skip + 16u);          // now at NLEN = the reference's di
-                    if (bc <= 32u) { bb |= (uint64_t)load32(z, ip, zn) << bc; bc += 32u; ip += 4u; }
-                    bb >>= 16; bc -= 16u;                             // NLEN unchecked (D2); data follows
-                    srem = length;
-                    if (length == 0u) {
-                        // COPY with nothing to copy (deflate.py:1617-1626)
-                        if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize) { HDLZ_FAIL(HDLZ_E_NO_EOF); break; }
-                        if (final_) { out_len = o; active = false; break; }
-                        need_header = true;
-                    }
-                } else {
-                    bb >>= 3; bc -= 3u;
+        bool slow = false;
+        if (active && rem == 0u && srem == 0u) {
+            slow = need_header;
+            HDLZ_REFILL();
+            const uint32_t e = lds.lit[(uint32_t)bb & 511u];
+            const uint32_t nb = e & 15u, type = (e >> 13) & 3u;
+            const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;
+            uint64_t x = bb >> nb;
+            const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));
+            x >>= leb;
+            const uint32_t de = lds.dst[(uint32_t)x & 31u];
+            const uint32_t deb = (de >> 16) & 15u;
+            const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> 5) & ((1u << deb) - 1u));
+            const uint32_t mbits = nb + leb + 5u + deb;
+            const uint32_t bp0 = HDLZ_BITPOS();
+            const bool sym_ok = (int32_t)((bp0 + nb) >> 3) <= isize - 3;                 // deflate.py:1535-1539
+            const bool lit_ok = (type == (uint32_t)T_LIT) & sym_ok & (o < cap);
+            const bool len_ok = (type == (uint32_t)T_LEN) & sym_ok & (de != 0xFFFFFFFFu) & (distance <= o) &
+                                (distance <= obsize) & ((int32_t)((bp0 + mbits) >> 3) < isize - 2) &
+                                ((uint64_t)o + tlength <= (uint64_t)cap);
+            if (!slow && (lit_ok | len_ok)) {
+                const uint32_t used = lit_ok ? nb : mbits;
+                bb >>= used; bc -= used;
+                if (lit_ok) { lit = (e >> 4) & 0xFFu; have = true; }
+                else {
+                    rem = tlength; dist = distance; fbn = 0;
+                    if (distance > RING_BYTES) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
                 }
-                continue;
+            } else {
+                slow = true;                                        // EOB, header, invalid data, any failing check
             }
-            // NEXT (deflate.py:1409-1445)
-            const uint32_t leaf = lds.leaves[(uint32_t)bb & 511u];
-            const uint32_t nb = leaf & 15u, code = leaf >> 4;
-            if (nb < 1u) { HDLZ_FAIL(HDLZ_E_BAD_SYMBOL); break; }
-            bb >>= nb; bc -= nb;
-            // INFLATE (deflate.py:1519-1591)
-            if ((int32_t)(HDLZ_BITPOS() >> 3) > isize - 3) { HDLZ_FAIL(HDLZ_E_NO_EOF); break; }   // :1535-1539
-            if (code == 256u) {
-                if (final_) { out_len = o; active = false; break; }   // D6
-                need_header = true;
-                continue;
-            }
-            if (code < 256u) {
-                if (o >= cap) { HDLZ_FAIL(HDLZ_E_OUT_CAPACITY); break; }
-                lit = code;
-                have = true;
-                break;
-            }
-            const uint32_t token = code - 257u;
-            if (token >= 29u) { HDLZ_FAIL(HDLZ_E_BAD_SYMBOL); break; }
-            uint32_t lbase, leb, dbase, deb;
-            length_info(token, lbase, leb);
-            const uint32_t tlength = lbase + ((uint32_t)bb & ((1u << leb) - 1u));
-            bb >>= leb;
-            const uint32_t dc = rev((uint32_t)bb & 31u, 5);
-            bb >>= 5;
-            if (dc >= 30u) { HDLZ_FAIL(HDLZ_E_BAD_DISTANCE); break; }
-            dist_info(dc, dbase, deb);
-            const uint32_t distance = dbase + ((uint32_t)bb & ((1u << deb) - 1u));
-            bb >>= deb;
-            bc -= leb + 5u + deb;
-            if (distance > o || distance > obsize) { HDLZ_FAIL(HDLZ_E_BAD_DISTANCE); break; }        // D8
-            if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize - 2) { HDLZ_FAIL(HDLZ_E_NO_EOF); break; }      // COPY hold, :1600
-            if ((uint64_t)o + tlength > cap) { HDLZ_FAIL(HDLZ_E_OUT_CAPACITY); break; }
-            rem = tlength;
-            dist = distance;
         }
-        const uint64_t actmask = __ballot(active);
-        if (actmask == 0ull) break;
+        // ------------------------------------------------------------ 1b. slow path (wave-uniform branch, rare)
+        if (__ballot(slow) != 0ull) {
+            while (slow && active && rem == 0u && srem == 0u && !have) {
+                HDLZ_REFILL();
+                if (need_header) {
+                    // HEADER (deflate.py:677-732)
+                    final_ = (uint32_t)bb & 1u;
+                    const uint32_t hm = assume_fixed ? 1u : ((uint32_t)(bb >> 1) & 3u);
+                    if (hm == 3u) { HDLZ_FAIL(HDLZ_E_BAD_BTYPE); break; }
+                    if (hm == 2u) { HDLZ_FAIL(HDLZ_E_DYNAMIC_UNSUPPORTED); break; }
+                    need_header = false;
+                    if (hm == 0u) {
+                        // stored (deflate.py:709-717): LEN sits `skip` bits after the header start
+                        const uint32_t dio = HDLZ_BITPOS() & 7u;
+                        uint32_t skip = 8u - dio;
+                        if (skip <= 2u) skip = 16u - dio;
+                        const uint32_t length = (uint32_t)(bb >> skip) & 0xFFFFu & len_mask;
+                        bb >>= (skip + 16u); bc -= (skip + 16u);          // now at NLEN = the reference's di
+                        HDLZ_REFILL();
+                        bb >>= 16; bc -= 16u;                             // NLEN unchecked (D2); data follows
+                        srem = length;
+                        if (length == 0u) {
+                            // COPY with nothing to copy (deflate.py:1617-1626)
+                            if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize) { HDLZ_FAIL(HDLZ_E_NO_EOF); break; }
+                            if (final_) { out_len = o; active = false; break; }
+                            need_header = true;
+                        }
+                    } else {
+                        bb >>= 3; bc -= 3u;
+                    }
+                    continue;
+                }
+                // NEXT (deflate.py:1409-1445)
+                const uint32_t e = lds.lit[(uint32_t)bb & 511u];
+                const uint32_t nb = e & 15u, code = (e >> 4) & 0x1FFu;
+                if (nb < 1u) { HDLZ_FAIL(HDLZ_E_BAD_SYMBOL); break; }
+                bb >>= nb; bc -= nb;
+                // INFLATE (deflate.py:1519-1591)
+                if ((int32_t)(HDLZ_BITPOS() >> 3) > isize - 3) { HDLZ_FAIL(HDLZ_E_NO_EOF); break; }   // :1535-1539
+                if (code == 256u) {
+                    if (final_) { out_len = o; active = false; break; }   // D6
+                    need_header = true;
+                    continue;
+                }
+                if (code < 256u) {
+                    if (o >= cap) { HDLZ_FAIL(HDLZ_E_OUT_CAPACITY); break; }
+                    lit = code;
+                    have = true;
+                    break;
+                }
+                const uint32_t token = code - 257u;
+                if (token >= 29u) { HDLZ_FAIL(HDLZ_E_BAD_SYMBOL); break; }
+                uint32_t lbase, leb, dbase, deb;
+                length_info(token, lbase, leb);
+                const uint32_t tlength = lbase + ((uint32_t)bb & ((1u << leb) - 1u));
+                bb >>= leb;
+                const uint32_t dc = rev((uint32_t)bb & 31u, 5);
+                bb >>= 5;
+                if (dc >= 30u) { HDLZ_FAIL(HDLZ_E_BAD_DISTANCE); break; }
+                dist_info(dc, dbase, deb);
+                const uint32_t distance = dbase + ((uint32_t)bb & ((1u << deb) - 1u));
+                bb >>= deb;
+                bc -= leb + 5u + deb;
+                if (distance > o || distance > obsize) { HDLZ_FAIL(HDLZ_E_BAD_DISTANCE); break; }        // D8
+                if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize - 2) { HDLZ_FAIL(HDLZ_E_NO_EOF); break; }      // COPY hold, :1600
+                if ((uint64_t)o + tlength > cap) { HDLZ_FAIL(HDLZ_E_OUT_CAPACITY); break; }
+                rem = tlength;
+                dist = distance;
+                fbn = 0;
+                if (distance > RING_BYTES) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
+            }
+        }
+        if (__ballot(active) == 0ull) break;
 
         // ------------------------------------------------------------ 2. one output byte per active lane
         bool wrote = false;        // this lane put a byte into the ring in this iteration
         if (active) {
-            uint32_t byte;
+            uint32_t byte = lit;
             bool stored_done = false;
             if (rem != 0u) {                                       // COPY (deflate.py:1627-1659)
-                if (dist <= RING_BYTES) byte = ring8[ring_addr(o - dist, lane)];
-                else byte = out[o - dist];
+                const uint32_t rb = ring8[ring_addr(o - dist, lane)];     // LDS history (valid for dist <= 256)
+                if (dist > RING_BYTES) {                           // far history: the stream's own flushed output
+                    if (fbn == 0u) {          // take the prefetched 8 bytes, request the following 8 (all already flushed: dist > 78)
+                        fb = fpre; fbn = 8u;
+                        if (rem > 8u) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - dist) + 8u);
+                    }
+                    byte = (uint32_t)fb & 0xFFu;
+                    fb >>= 8; fbn--;
+                } else {
+                    byte = rb;
+                }
                 rem--;
             } else if (srem != 0u) {                               // stored COPY (deflate.py:1603-1616)
-                if (bc <= 32u) { bb |= (uint64_t)load32(z, ip, zn) << bc; bc += 32u; ip += 4u; }
+                HDLZ_REFILL();
                 if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize) { HDLZ_FAIL(HDLZ_E_NO_EOF); }
                 else if (o >= cap) { HDLZ_FAIL(HDLZ_E_OUT_CAPACITY); }
                 byte = (uint32_t)bb & 0xFFu;
                 bb >>= 8; bc -= 8u;
                 srem--;
                 stored_done = (srem == 0u);
-            } else {
-                byte = lit;
             }
             if (active) { ring8[ring_addr(o, lane)] = (uint8_t)byte; wrote = true; }
             if (active && stored_done) {                           // a stored block just ended (deflate.py:1617-1626)
@@ -255,6 +322,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
     }
 #undef HDLZ_FAIL
 #undef HDLZ_BITPOS
+#undef HDLZ_REFILL
 
     // ---- tail: the bytes of the last, partial chunk are still only in the ring
     if (exists && status == HDLZ_OK) {
