@@ -56,12 +56,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, "launch with torchrun --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("HDLZ_BENCH_BACKEND", "nccl")   # "gloo": functional check of the N>1 flow on fewer GPUs
+    if backend == "nccl":
+        assert local < ndev, "one GPU per rank is required with RCCL"
+    local = min(local, ndev - 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     eng = hdl_deflate_amd.Engine(dev)
     B, n = a.blocks, a.block_size
@@ -92,8 +100,9 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    cdev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -114,7 +123,7 @@ def main():
     bad = int((st != 0).sum().item())
     out_bytes_local = int(ol.to(torch.int64).sum().item())
     in_bytes_local = B * n
-    tot = torch.tensor([out_bytes_local, in_bytes_local, bad], dtype=torch.int64, device=dev)
+    tot = torch.tensor([out_bytes_local, in_bytes_local, bad], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(tot)
         assert int(all_len.to(torch.int64).sum().item()) == int(tot[0].item())

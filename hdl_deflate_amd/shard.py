@@ -28,10 +28,15 @@ def gather_lengths(local_len, nblocks, group=None):
     maxn = max(b1 - b0 for b0, b1 in sizes)
     b0, b1 = sizes[rank]
     assert local_len.numel() == b1 - b0
-    pad = torch.zeros(maxn, dtype=torch.int32, device=local_len.device)
-    pad[:b1 - b0] = local_len.to(torch.int32)
-    full = torch.empty(world * maxn, dtype=torch.int32, device=local_len.device)
+    # RCCL ("nccl") gathers device tensors directly; gloo (CPU tests, or two ranks sharing one GPU) needs
+    # host tensors -- 4 bytes per block, so the hop is negligible
+    dev = local_len.device
+    cdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
+    pad = torch.zeros(maxn, dtype=torch.int32, device=cdev)
+    pad[:b1 - b0] = local_len.to(torch.int32).to(cdev)
+    full = torch.empty(world * maxn, dtype=torch.int32, device=cdev)
     dist.all_gather_into_tensor(full, pad, group=group)
+    full = full.to(dev)
     parts = [full[r * maxn: r * maxn + (s1 - s0)] for r, (s0, s1) in enumerate(sizes)]
     return torch.cat(parts)
 
