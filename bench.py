@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--maxmatch", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--verify", type=int, default=256, help="blocks checked against zlib outside the timed region")
+    ap.add_argument("--data", default="families", choices=["families", "text"],
+                    help="families = test_deflate.py families 1-4 (BASELINE configs[1]); text = Zipf pseudo-English "
+                         "(enwik8 stand-in for configs[2]: enwik8 cannot be fetched, no network)")
     ap.add_argument("--mode", default="compress", choices=["compress", "inflate"],
                     help="compress = BASELINE metric (default); inflate = configs[3] side metric (1 GPU)")
     a = ap.parse_args()
@@ -48,7 +51,7 @@ def main():
     import torch
     import torch.distributed as dist
     import hdl_deflate_amd
-    from hdl_deflate_amd.data import make_blocks
+    from hdl_deflate_amd.data import make_blocks, make_text_blocks
     from hdl_deflate_amd.shard import gather_lengths
     from hdl_deflate_amd.constants import pitch_for
 
@@ -75,7 +78,10 @@ def main():
     B, n = a.blocks, a.block_size
     nblocks_total = B * world
     # rank r owns the contiguous block range [r*B, (r+1)*B) of the job (weak scaling)
-    d_in = make_blocks(B, n, dev, seed=0, first_block=rank * B)
+    if a.data == "text":
+        d_in = make_text_blocks(B, n, dev, seed=rank)
+    else:
+        d_in = make_blocks(B, n, dev, seed=0, first_block=rank * B)
     pitch = pitch_for(n)
     d_out = torch.empty((B, pitch), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
@@ -152,13 +158,14 @@ def main():
         "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: %d x %d B blocks per GPU, families 1-4 (test_deflate.py:38-66), "
-                               "distinct blocks, HBM-resident" % (B, n),
+        "config": {"workload": ("BASELINE configs[1]: %d x %d B blocks per GPU, families 1-4 (test_deflate.py:38-66), "
+                                "distinct blocks, HBM-resident" % (B, n)) if a.data == "families" else
+                               ("%d x %d B blocks per GPU of Zipf pseudo-English (enwik8 stand-in), HBM-resident" % (B, n)),
                    "cwindow": a.cwindow, "maxmatch": a.maxmatch, "blocks_per_gpu": B, "block_bytes": n,
                    "parallelism": "block-shard x%d (length all-gather only)" % world},
         "per_gpu_MBps": round(value / world, 1),
         "compression_ratio_out_over_in": round(out_bytes / in_bytes, 4),
-        "roofline": {"bound": "hbm", "kernel": "k_compress<1>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_compress<%d>" % (1 if a.cwindow <= 32 else 2 if a.cwindow <= 64 else 8), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg, 4),
                      "kernel_ms_min": round(k_ms[0], 4),
@@ -252,8 +259,8 @@ def bench_inflate(a):
                         "kernel_ms_min": round(k_ms[0], 4)}}
     if a.cpu_seconds > 0:
         from oracle import oracle as O
-        cores = os.cpu_count() or 1
-        S = min(B, 1 << 17)
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        S = min(B, 1 << 19)
         t1 = time.perf_counter()
         _, l2, s2 = O.inflate_batch(flat, off[:S + 1].astype(np.uint64), n, flags=1, nthreads=cores)
         dtc = time.perf_counter() - t1
@@ -268,27 +275,31 @@ def cpu_baseline(d_in, n, a):
     import numpy as np
     from oracle import oracle as O          # cpu_baseline leg: the oracle is the thing timed here, as allowed
     O.lib()
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     B = d_in.shape[0]
-    probe = d_in[:min(B, 2048)].cpu().numpy()
-    off = (np.arange(probe.shape[0] + 1, dtype=np.uint64) * n)
-    t0 = time.perf_counter()
-    O.compress_batch(probe.reshape(-1), off, a.cwindow, a.maxmatch, nthreads=cores)
-    rate = probe.size / max(time.perf_counter() - t0, 1e-6)
-    S = int(min(B, max(2048, rate * a.cpu_seconds / n)))
+    pitch = O.out_bound(n)
+
+    def run(sample, threads):
+        S = sample.shape[0]
+        off = (np.arange(S + 1, dtype=np.uint64) * n)
+        out = np.ones((S, pitch), np.uint8)               # pre-touched: no first-touch faults in the timed call
+        t0 = time.perf_counter()
+        _, ol, st = O.compress_batch(sample.reshape(-1), off, a.cwindow, a.maxmatch, nthreads=threads, out=out)
+        dt = time.perf_counter() - t0
+        assert (st == 0).all()
+        return dt
+
+    probe = d_in[:min(B, 4096)].cpu().numpy()
+    run(probe, cores)                                      # warm: library load, thread start-up
+    rate1 = probe.size / run(probe[:512], 1)               # single-thread bytes/s
+    # bounded sample: about cpu_seconds of single-core-equivalent work per core, capped by the data we have
+    S = int(min(B, max(4096, rate1 * cores * a.cpu_seconds * 0.5 / n)))
     sample = d_in[:S].cpu().numpy()
-    off = (np.arange(S + 1, dtype=np.uint64) * n)
-    t0 = time.perf_counter()
-    _, ol, st = O.compress_batch(sample.reshape(-1), off, a.cwindow, a.maxmatch, nthreads=cores)
-    dt = time.perf_counter() - t0
-    assert (st == 0).all()
-    t1 = time.perf_counter()
-    O.compress_batch(sample[:max(1, S // cores)].reshape(-1), off[:max(1, S // cores) + 1], a.cwindow, a.maxmatch, nthreads=1)
-    dt1 = time.perf_counter() - t1
+    dt = run(sample, cores)
     return {"value": round(sample.size / dt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
-            "sample": "first %d blocks of the same workload (%.1f MiB), oracle/hdlz_oracle.c, %d threads, %.1f s"
+            "sample": "first %d blocks of the same workload (%.1f MiB), oracle/hdlz_oracle.c, %d threads, %.2f s"
                       % (S, sample.size / 2 ** 20, cores, dt),
-            "single_thread_MBps": round(sample[:max(1, S // cores)].size / dt1 / 1e6, 1),
+            "single_thread_MBps": round(rate1 / 1e6, 1),
             "reference_constants": {"fpga_100MHz_3cyc_per_byte_MBps": 33, "standin_sim_KBps": "0.5-1 (BASELINE.md)"}}
 
 

@@ -90,3 +90,56 @@ def make_blocks(nblocks, n, device, seed=0, families=(1, 2, 3, 4), first_block=0
                 raise ValueError("family %r" % (f,))
             out[rows] = blk
     return out
+
+
+# ---- BASELINE configs[2]: enwik8 is not obtainable (no network), so an English-like substitute is generated:
+# a fixed vocabulary with Zipf-distributed word frequencies, words separated by spaces, sentences by ". "
+_SYLL = ("th", "e", "an", "in", "er", "on", "re", "at", "st", "en", "al", "or", "ti", "ar", "ng", "ou", "is", "it",
+         "le", "ed", "ro", "ve", "co", "me", "de", "ha", "se", "li", "ra", "ne", "ic", "io", "ma", "ur", "wi", "ta")
+
+
+def _vocab(size=4096, seed=12345):
+    r = random.Random(seed)
+    words, seen = [], set()
+    while len(words) < size:
+        w = "".join(r.choice(_SYLL) for _ in range(r.choice((1, 1, 2, 2, 2, 3, 3, 4))))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    return words
+
+
+def make_text_blocks(nblocks, n, device, seed=0, vocab_size=4096):
+    """uint8 [nblocks, n] of Zipf-distributed pseudo-English (enwik8 stand-in for BASELINE configs[2])."""
+    import torch
+    words = _vocab(vocab_size)
+    maxw = max(len(w) for w in words) + 1
+    tab = torch.zeros((vocab_size, maxw), dtype=torch.uint8)
+    wl = torch.zeros(vocab_size, dtype=torch.int64)
+    for k, w in enumerate(words):
+        b = (w + " ").encode()
+        tab[k, :len(b)] = torch.tensor(list(b), dtype=torch.uint8)
+        wl[k] = len(b)
+    tab, wl = tab.to(device), wl.to(device)
+    ranks = torch.arange(1, vocab_size + 1, dtype=torch.float64, device=device)
+    cdf = torch.cumsum(1.0 / ranks, 0)
+    cdf = (cdf / cdf[-1]).to(torch.float32)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed * 7919 + 17)
+    out = torch.empty((nblocks, n), dtype=torch.uint8, device=device)
+    K = n // 3 + 8                                       # words per block (average word+space > 3 bytes)
+    chunk = max(1, (1 << 24) // n)
+    pos = torch.arange(n, device=device).unsqueeze(0)
+    for c0 in range(0, nblocks, chunk):
+        c1 = min(nblocks, c0 + chunk)
+        Bc = c1 - c0
+        u = torch.rand((Bc, K), generator=g, device=device)
+        wid = torch.searchsorted(cdf, u).clamp_(max=vocab_size - 1)
+        ln = wl[wid]
+        ends = torch.cumsum(ln, 1)
+        p = pos.expand(Bc, n).contiguous()
+        idx = torch.searchsorted(ends, p, right=True).clamp_(max=K - 1)
+        o = p - torch.gather(ends - ln, 1, idx)
+        w = torch.gather(wid, 1, idx)
+        out[c0:c1] = tab[w, o.clamp_(max=maxw - 1)]
+    return out

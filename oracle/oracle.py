@@ -94,14 +94,17 @@ def tokens(data, cwindow=32, maxmatch=10):
     return list(zip(pos[:k].tolist(), ln[:k].tolist(), ds[:k].tolist()))
 
 
-def compress_batch(in_u8, in_off, cwindow=32, maxmatch=10, out_pitch=None, nthreads=1):
-    """numpy batch driver: in_u8 uint8[total], in_off uint64[B+1] -> (out uint8[B,pitch], out_len, status)"""
+def compress_batch(in_u8, in_off, cwindow=32, maxmatch=10, out_pitch=None, nthreads=1, out=None):
+    """numpy batch driver: in_u8 uint8[total], in_off uint64[B+1] -> (out uint8[B,pitch], out_len, status).
+    Pass a pre-touched `out` to keep first-touch page faults out of a timed region."""
     in_u8 = np.ascontiguousarray(in_u8, np.uint8)
     in_off = np.ascontiguousarray(in_off, np.uint64)
     B = len(in_off) - 1
     if out_pitch is None:
-        out_pitch = out_bound(int((in_off[1:] - in_off[:-1]).max()) if B else 0)
-    out = np.zeros((B, out_pitch), np.uint8)
+        out_pitch = out.shape[1] if out is not None else out_bound(int((in_off[1:] - in_off[:-1]).max()) if B else 0)
+    if out is None:
+        out = np.zeros((B, out_pitch), np.uint8)
+    assert out.shape == (B, out_pitch) and out.dtype == np.uint8 and out.flags.c_contiguous
     out_len = np.zeros(B, np.uint32)
     status = np.zeros(B, np.uint32)
     lib().hdlz_oracle_compress_batch(in_u8.ctypes.data, in_off.ctypes.data, B, cwindow, maxmatch,
