@@ -3,11 +3,12 @@ IDLE, WRITE, READ, STARTC, STARTD = range(5)
 
 (OK, E_SHORT_INPUT, E_OUT_CAPACITY, E_BAD_BTYPE, E_BAD_DISTANCE, E_NO_EOF, E_DYNAMIC_UNSUPPORTED,
  E_BAD_SYMBOL, E_BAD_PARAM, E_HIP) = range(10)
+E_BAD_TREE = 10
 INFLATE_ASSUME_FIXED = 1
 
 STATUS_NAMES = {OK: "OK", E_SHORT_INPUT: "SHORT_INPUT", E_OUT_CAPACITY: "OUT_CAPACITY", E_BAD_BTYPE: "BAD_BTYPE",
                 E_BAD_DISTANCE: "BAD_DISTANCE", E_NO_EOF: "NO_EOF", E_DYNAMIC_UNSUPPORTED: "DYNAMIC_UNSUPPORTED",
-                E_BAD_SYMBOL: "BAD_SYMBOL", E_BAD_PARAM: "BAD_PARAM", E_HIP: "HIP_ERROR"}
+                E_BAD_SYMBOL: "BAD_SYMBOL", E_BAD_PARAM: "BAD_PARAM", E_HIP: "HIP_ERROR", E_BAD_TREE: "BAD_TREE"}
 
 # reference defaults (deflate.py:34-76)
 CWINDOW = 32

@@ -47,6 +47,7 @@ const char* hdlz_status_string(int s) {
         case HDLZ_E_BAD_SYMBOL: return "BAD_SYMBOL";
         case HDLZ_E_BAD_PARAM: return "BAD_PARAM";
         case HDLZ_E_HIP: return "HIP_ERROR";
+        case HDLZ_E_BAD_TREE: return "BAD_TREE";
         default: return "?";
     }
 }
@@ -93,6 +94,10 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     hdlz::InflateArgs a{d_in, d_in_off, in_pitch, in_len, nstreams, flags, obsize, d_out, out_pitch, d_out_len, d_status};
     hipError_t e = hdlz::launch_inflate(a, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "launch k_inflate");
+    // second pass, same stream: streams in which pass 1 met a dynamic-tree block (status 6) are redone
+    // by one wave each; everything else is left untouched
+    e = hdlz::launch_inflate_dyn(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "launch k_inflate_dyn");
     return HDLZ_OK;
 }
 

@@ -51,5 +51,6 @@ __host__ __device__ __forceinline__ void static_for(F&& f) {
 
 hipError_t launch_compress(const CompressArgs& a, hipStream_t stream);
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t stream);
+hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream);
 
 }  // namespace hdlz

@@ -40,7 +40,7 @@ typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 __device__ __forceinline__ uint32_t rev(uint32_t v, uint32_t nbits) { return __builtin_bitreverse32(v) >> (32u - nbits); }
 
 // 4 stream bytes at byte `ip` (little endian); bytes at or beyond zn read as zero (the reference's
-// input memory holds nothing there; the oracle restates it as zeros)
+// input memory holds nothing there)
 __device__ __forceinline__ uint32_t load32(const uint8_t* __restrict__ z, uint32_t ip, uint32_t zn) {
     if (ip + 4u <= zn) return *reinterpret_cast<const u32_unaligned*>(z + ip);
     uint32_t v = 0;

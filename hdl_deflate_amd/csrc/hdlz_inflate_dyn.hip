@@ -1,0 +1,338 @@
+// hdlz_inflate_dyn.hip -- second inflate pass for streams that contain dynamic-tree (BTYPE=2) blocks.
+//
+// SURVEY.md 8(f) rank 1.  Replaces the reference's dynamic-tree machinery: BL/READBL/REPEAT/INIT3/
+// DISTTREE (/root/reference/deflate.py:1084-1202), canonical code construction HF1..HF4/SPREAD
+// (:1204-1400) and the distance decode D_NEXT/D_NEXT_2 (:1447-1517); stored and fixed blocks met in
+// the same stream are handled here too (the stream is restarted from its first block).
+//
+// Per-stream Huffman tables cannot live per LANE in LDS, so the mapping differs from k_inflate:
+// ONE WAVE PER STREAM.  The symbol decode is wave-uniform ("scalar-style": every lane runs the same
+// canonical-code walk, code counts live in registers, symbols in LDS), and the lanes split what is
+// parallel: an LZ copy of length L, distance D is done in ceil(L/64) steps with
+//     out[o+i] = out[o - D + (i mod D)]
+// which has no dependency on bytes produced by the same copy, whatever the overlap.  Output goes through
+// a 4 KiB LDS history ring and is flushed to HBM as full 64-byte lines.
+// The reference's table layout (10-bit instant table + incremental-mask retry) is FPGA-specific; a
+// canonical count/offset decoder returns the same symbols for every valid code.  Invalid code
+// descriptions are HDLZ_E_BAD_TREE (zlib's acceptance rules: over-subscribed sets rejected, incomplete
+// sets only with a single code).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hdlz_device.h"
+
+namespace hdlz {
+
+constexpr uint32_t DRING = 4096;     // history ring bytes (power of two)
+constexpr uint32_t DCHUNK = 64;
+
+struct __attribute__((aligned(16))) DynLds {
+    uint8_t ring[DRING];
+    uint8_t lengths[320];
+    uint16_t lsym[288];
+    uint16_t dsym[32];
+    uint16_t csym[20];
+    uint16_t cnt[3][16];             // code counts per length: [0] code-length code, [1] lit/len, [2] distance
+    int32_t left[3];
+};
+
+typedef uint32_t __attribute__((aligned(1))) u32u;
+
+__device__ __forceinline__ uint32_t dload32(const uint8_t* __restrict__ z, uint32_t ip, uint32_t zn) {
+    if (ip + 4u <= zn) return *reinterpret_cast<const u32u*>(z + ip);
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 4u; k++)
+        if (ip + k < zn) v |= (uint32_t)z[ip + k] << (8u * k);
+    return v;
+}
+
+__device__ __forceinline__ void d_length_info(uint32_t token, uint32_t& base, uint32_t& eb) {
+    if (token < 8u) { base = 3u + token; eb = 0; }
+    else if (token == 28u) { base = 258u; eb = 0; }
+    else { eb = (token >> 2) - 1u; base = 3u + ((4u + (token & 3u)) << eb); }
+}
+__device__ __forceinline__ void d_dist_info(uint32_t dc, uint32_t& base, uint32_t& eb) {
+    if (dc < 4u) { base = 1u + dc; eb = 0; }
+    else { eb = (dc >> 1) - 1u; base = 1u + ((2u + (dc & 1u)) << eb); }
+}
+
+// canonical code construction by lane 0 (serial, n <= 288): counts, then symbols ordered by (length, value)
+__device__ void canon_build(DynLds& L, int which, const uint8_t* len, uint16_t* symbol, int n) {
+    uint16_t* count = L.cnt[which];
+    uint16_t offs[16];
+    for (int l = 0; l < 16; l++) count[l] = 0;
+    for (int s = 0; s < n; s++) count[len[s]]++;
+    int left = 1;
+    for (int l = 1; l < 16; l++) {
+        left <<= 1;
+        left -= count[l];
+        if (left < 0) break;
+    }
+    L.left[which] = left;
+    if (left < 0) return;
+    offs[1] = 0;
+    for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+    for (int s = 0; s < n; s++)
+        if (len[s]) symbol[offs[len[s]]++] = (uint16_t)s;
+}
+
+struct CodeRegs { uint32_t c[16]; };   // counts of one code in registers (wave-uniform)
+
+__device__ __forceinline__ void load_counts(CodeRegs& r, const uint16_t* count) {
+#pragma unroll
+    for (int l = 0; l < 16; l++) r.c[l] = count[l];
+}
+
+// decode one symbol from the next (up to 15) stream bits `peek` (LSB first); returns symbol or -1
+__device__ __forceinline__ int canon_decode(const CodeRegs& r, const uint16_t* symbol, uint32_t peek, uint32_t& used) {
+    const uint32_t rb = __builtin_bitreverse32(peek) >> 17;   // first stream bit = MSB of a 15-bit value
+    uint32_t first = 0, index = 0;
+#pragma unroll
+    for (int l = 1; l < 16; l++) {
+        const uint32_t code = rb >> (15 - l);
+        const uint32_t count = r.c[l];
+        if (code - first < count) {            // (unsigned) also false when code < first
+            used = (uint32_t)l;
+            return (int)symbol[index + (code - first)];
+        }
+        index += count;
+        first = (first + count) << 1;
+    }
+    used = 15;
+    return -1;
+}
+
+__global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
+    __shared__ DynLds L;
+    const uint32_t lane = threadIdx.x;
+    for (uint64_t sid = blockIdx.x; sid < a.nstreams; sid += gridDim.x) {
+        if (a.status[sid] != HDLZ_E_DYNAMIC_UNSUPPORTED) continue;   // pass 1 finished this stream
+        uint64_t off;
+        uint32_t zn;
+        if (a.in_off) {
+            off = a.in_off[sid];
+            zn = (uint32_t)(a.in_off[sid + 1] - off);
+        } else {
+            off = sid * a.in_pitch;
+            zn = a.in_len;
+        }
+        const uint8_t* __restrict__ z = a.in + off;
+        uint8_t* __restrict__ out = a.out + sid * a.out_pitch;
+        const uint32_t cap = a.out_pitch > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a.out_pitch;
+        const uint32_t obsize = a.obsize ? a.obsize : 32768u;
+        const uint32_t len_mask = a.obsize ? ((1u << (31u - (uint32_t)__builtin_clz(a.obsize))) - 1u) : 0xFFFFu;
+        const int32_t isize = (int32_t)zn - 1;
+
+        uint32_t status = HDLZ_OK;
+        uint32_t o = 0;                     // bytes produced
+        uint64_t bb = 0;
+        uint32_t bc = 0, ip = 2;            // D0: zlib header skipped unvalidated
+#define REFILL() do { if (bc <= 32u) { bb |= (uint64_t)dload32(z, ip, zn) << bc; bc += 32u; ip += 4u; } } while (0)
+#define BITPOS() (8u * ip - bc)
+#define TAKE(n) do { bb >>= (n); bc -= (n); } while (0)
+#define FAIL(code) do { status = (code); goto done; } while (0)
+        // flush every completed 64-byte line in [from, to)
+        auto flush_lines = [&](uint32_t from, uint32_t to) {
+            for (uint32_t c0 = from & ~(DCHUNK - 1u); c0 + DCHUNK <= to; c0 += DCHUNK)
+                out[c0 + lane] = L.ring[(c0 + lane) & (DRING - 1u)];
+            // far copies read flushed bytes back through L1/L2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+
+        for (;;) {
+            REFILL();
+            // HEADER (deflate.py:677-732)
+            const uint32_t final_ = (uint32_t)bb & 1u;
+            const uint32_t hm = (uint32_t)(bb >> 1) & 3u;
+            if (hm == 3u) FAIL(HDLZ_E_BAD_BTYPE);
+            if (hm == 0u) {
+                // stored (deflate.py:709-717, COPY :1603-1626)
+                const uint32_t dio = BITPOS() & 7u;
+                uint32_t skip = 8u - dio;
+                if (skip <= 2u) skip = 16u - dio;
+                const uint32_t length = (uint32_t)(bb >> skip) & 0xFFFFu & len_mask;
+                TAKE(skip + 16u);
+                REFILL();
+                TAKE(16u);                                   // NLEN unchecked (D2)
+                const uint32_t p0 = BITPOS() >> 3;            // first data byte (bit reader is byte aligned here)
+                // the reference checks, byte by byte and in this order: input left (deflate.py:1600), then room
+                const uint32_t i_noeof = (int32_t)p0 >= isize ? 0u : (uint32_t)isize - p0;
+                const uint32_t i_cap = cap - o;
+                if (length > (i_noeof < i_cap ? i_noeof : i_cap)) FAIL(i_noeof <= i_cap ? HDLZ_E_NO_EOF : HDLZ_E_OUT_CAPACITY);
+                {
+                    // bytes of the current, still unflushed line live only in the ring: push them out first
+                    const uint32_t c0 = o & ~(DCHUNK - 1u);
+                    if (c0 + lane < o) out[c0 + lane] = L.ring[(c0 + lane) & (DRING - 1u)];
+                    // the block itself goes straight to the output; the ring keeps its last DRING bytes
+                    for (uint32_t i = lane; i < length; i += 64u) out[o + i] = z[p0 + i];
+                    const uint32_t t0 = length > DRING ? length - DRING : 0u;
+                    for (uint32_t i = t0 + lane; i < length; i += 64u) L.ring[(o + i) & (DRING - 1u)] = z[p0 + i];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                o += length;
+                if ((int32_t)(p0 + length) >= isize) FAIL(HDLZ_E_NO_EOF);      // deflate.py:1617-1626 with the COPY hold
+                ip = p0 + length; bb = 0; bc = 0;                              // resynchronise the bit reader
+                if (final_) break;
+                continue;
+            }
+            TAKE(3u);
+            if (hm == 1u) {
+                // fixed code lengths (deflate.py:1066-1073)
+                for (uint32_t s = lane; s < 288u; s += 64u) L.lengths[s] = (uint8_t)(s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8);
+                if (lane < 32u) L.lengths[288u + lane] = 5;
+                __syncthreads();
+                if (lane == 0) {
+                    canon_build(L, 1, L.lengths, L.lsym, 288);
+                    canon_build(L, 2, L.lengths + 288, L.dsym, 32);
+                }
+                __syncthreads();
+            } else {
+                // BL (deflate.py:1090-1114)
+                REFILL();
+                const uint32_t nlen = ((uint32_t)bb & 31u) + 257u;
+                const uint32_t ndist = ((uint32_t)(bb >> 5) & 31u) + 1u;
+                const uint32_t ncode = ((uint32_t)(bb >> 10) & 15u) + 4u;
+                TAKE(14u);
+                if (nlen > 286u || ndist > 30u) FAIL(HDLZ_E_BAD_TREE);
+                for (uint32_t s = lane; s < 320u; s += 64u) L.lengths[s] = 0;
+                __syncthreads();
+                static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                for (uint32_t i = 0; i < ncode; i++) {
+                    REFILL();
+                    if (lane == 0) L.lengths[order[i]] = (uint8_t)((uint32_t)bb & 7u);
+                    TAKE(3u);
+                }
+                __syncthreads();
+                if (lane == 0) canon_build(L, 0, L.lengths, L.csym, 19);
+                __syncthreads();
+                if (L.left[0] != 0) FAIL(HDLZ_E_BAD_TREE);
+                CodeRegs cl;
+                load_counts(cl, L.cnt[0]);
+                __syncthreads();
+                for (uint32_t s = lane; s < 320u; s += 64u) L.lengths[s] = 0;     // reuse as the real length list
+                __syncthreads();
+                // READBL / REPEAT (deflate.py:1116-1164, :1190-1202)
+                uint32_t idx = 0, prev = 0;
+                while (idx < nlen + ndist) {
+                    REFILL();
+                    uint32_t used;
+                    const int sym = canon_decode(cl, L.csym, (uint32_t)bb & 0x7FFFu, used);
+                    if (sym < 0) FAIL(HDLZ_E_BAD_TREE);
+                    TAKE(used);
+                    if (sym < 16) {
+                        if (lane == 0) L.lengths[idx] = (uint8_t)sym;
+                        prev = (uint32_t)sym;
+                        idx++;
+                    } else {
+                        uint32_t rep, val = 0;
+                        if (sym == 16) {
+                            if (idx == 0u) FAIL(HDLZ_E_BAD_TREE);
+                            val = prev;
+                            rep = 3u + ((uint32_t)bb & 3u);
+                            TAKE(2u);
+                        } else if (sym == 17) {
+                            rep = 3u + ((uint32_t)bb & 7u);
+                            TAKE(3u);
+                        } else {
+                            rep = 11u + ((uint32_t)bb & 127u);
+                            TAKE(7u);
+                        }
+                        if (idx + rep > nlen + ndist) FAIL(HDLZ_E_BAD_TREE);
+                        for (uint32_t k = lane; k < rep; k += 64u) L.lengths[idx + k] = (uint8_t)val;
+                        prev = val;
+                        idx += rep;
+                    }
+                }
+                __syncthreads();
+                if (L.lengths[256] == 0) FAIL(HDLZ_E_BAD_TREE);          // no end-of-block code
+                if (lane == 0) {
+                    canon_build(L, 1, L.lengths, L.lsym, (int)nlen);
+                    canon_build(L, 2, L.lengths + nlen, L.dsym, (int)ndist);
+                }
+                __syncthreads();
+                {
+                    const int l1 = L.left[1], l2 = L.left[2];
+                    if (l1 < 0 || (l1 > 0 && (int)nlen - (int)L.cnt[1][0] != 1)) FAIL(HDLZ_E_BAD_TREE);
+                    if (l2 < 0 || (l2 > 0 && (int)ndist - (int)L.cnt[2][0] != 1)) FAIL(HDLZ_E_BAD_TREE);
+                }
+                if ((int32_t)(BITPOS() >> 3) > isize - 3) FAIL(HDLZ_E_NO_EOF);
+            }
+            {
+                CodeRegs lc, dc_;
+                load_counts(lc, L.cnt[1]);
+                load_counts(dc_, L.cnt[2]);
+                // NEXT / INFLATE / D_NEXT / COPY
+                for (;;) {
+                    REFILL();
+                    uint32_t used;
+                    const int sym = canon_decode(lc, L.lsym, (uint32_t)bb & 0x7FFFu, used);
+                    if (sym < 0) FAIL(HDLZ_E_BAD_SYMBOL);
+                    if (hm == 1u && sym == 287) FAIL(HDLZ_E_BAD_SYMBOL);               // zero leaf, deflate.py:212,:1437-1439
+                    TAKE(used);
+                    if ((int32_t)(BITPOS() >> 3) > isize - 3) FAIL(HDLZ_E_NO_EOF);     // deflate.py:1535-1539
+                    if (sym == 256) break;
+                    if (sym < 256) {
+                        if (o >= cap) FAIL(HDLZ_E_OUT_CAPACITY);
+                        if (lane == 0) L.ring[o & (DRING - 1u)] = (uint8_t)sym;
+                        o++;
+                        if ((o & (DCHUNK - 1u)) == 0u) out[o - DCHUNK + lane] = L.ring[(o - DCHUNK + lane) & (DRING - 1u)];
+                        continue;
+                    }
+                    const uint32_t token = (uint32_t)sym - 257u;
+                    if (token >= 29u) FAIL(HDLZ_E_BAD_SYMBOL);
+                    uint32_t lbase, leb, dbase, deb;
+                    d_length_info(token, lbase, leb);
+                    const uint32_t tlength = lbase + ((uint32_t)bb & ((1u << leb) - 1u));
+                    TAKE(leb);
+                    REFILL();
+                    const int ds = canon_decode(dc_, L.dsym, (uint32_t)bb & 0x7FFFu, used);
+                    if (ds < 0) FAIL(HDLZ_E_BAD_SYMBOL);
+                    TAKE(used);
+                    if (ds >= 30) FAIL(HDLZ_E_BAD_DISTANCE);
+                    d_dist_info((uint32_t)ds, dbase, deb);
+                    const uint32_t distance = dbase + ((uint32_t)bb & ((1u << deb) - 1u));
+                    TAKE(deb);
+                    if (distance > o || distance > obsize) FAIL(HDLZ_E_BAD_DISTANCE);     // deflate.py:1506-1508, D8
+                    if ((int32_t)(BITPOS() >> 3) >= isize - 2) FAIL(HDLZ_E_NO_EOF);        // COPY hold, :1600
+                    if ((uint64_t)o + tlength > cap) FAIL(HDLZ_E_OUT_CAPACITY);
+                    // COPY (deflate.py:1627-1659), lane-parallel: out[o+i] = out[o - D + (i mod D)]
+                    for (uint32_t i = lane; i < tlength; i += 64u) {
+                        const uint32_t src = o - distance + (distance >= tlength ? i : i % distance);
+                        uint32_t byte;
+                        if ((o + i) - src <= DRING - 512u) byte = L.ring[src & (DRING - 1u)];   // still in the ring for sure
+                        else byte = out[src];                                   // far history: flushed long ago
+                        L.ring[(o + i) & (DRING - 1u)] = (uint8_t)byte;
+                    }
+                    flush_lines(o, o + tlength);
+                    o += tlength;
+                }
+            }
+            if (final_) break;                                                   // D6
+        }
+    done:
+        __syncthreads();
+        if (status == HDLZ_OK) {
+            const uint32_t c0 = o & ~(DCHUNK - 1u);
+            if (c0 + lane < o) out[c0 + lane] = L.ring[(c0 + lane) & (DRING - 1u)];
+        }
+        if (lane == 0) {
+            a.out_len[sid] = status == HDLZ_OK ? o : 0u;
+            a.status[sid] = status;
+        }
+        __syncthreads();
+#undef REFILL
+#undef BITPOS
+#undef TAKE
+#undef FAIL
+    }
+}
+
+hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream) {
+    if (a.nstreams == 0 || (a.flags & HDLZ_INFLATE_ASSUME_FIXED)) return hipSuccess;
+    uint64_t g = a.nstreams < 65536u ? a.nstreams : 65536u;
+    hipLaunchKernelGGL(k_inflate_dyn, dim3((unsigned)g), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace hdlz

@@ -46,10 +46,12 @@ enum {
     HDLZ_E_BAD_BTYPE = 3,           /* "Bad method" (deflate.py:719-721) */
     HDLZ_E_BAD_DISTANCE = 4,        /* distance code 30/31, distance > bytes produced or > obsize (deflate.py:1506-1508, :1581) */
     HDLZ_E_NO_EOF = 5,              /* "NO EOF!" (deflate.py:1535-1539) or input exhausted (:1600-1602 would stall) */
-    HDLZ_E_DYNAMIC_UNSUPPORTED = 6, /* BTYPE=2 block met (dynamic trees: SURVEY 8(f) rank 1, not built yet) */
+    HDLZ_E_DYNAMIC_UNSUPPORTED = 6, /* internal hand-over mark between the two inflate passes; never returned */
     HDLZ_E_BAD_SYMBOL = 7,          /* literal/length symbol 286/287 ("< 1 bits", deflate.py:1437-1439) */
     HDLZ_E_BAD_PARAM = 8,
-    HDLZ_E_HIP = 9                  /* HIP runtime error / no device; see hdlz_last_error() */
+    HDLZ_E_HIP = 9,                 /* HIP runtime error / no device; see hdlz_last_error() */
+    HDLZ_E_BAD_TREE = 10            /* dynamic block header does not describe a valid prefix code (the reference
+                                       builds garbage tables there, deflate.py:1204-1400; zlib's rules are used) */
 };
 
 /* inflate flags */
@@ -82,7 +84,8 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
 
 /*
  * STARTD for a batch of independent zlib streams: 2 header bytes skipped unvalidated, blocks
- * until BFINAL, stored (BTYPE 0) and fixed-Huffman (BTYPE 1) blocks, 4 trailer bytes required
+ * until BFINAL, stored (BTYPE 0), fixed-Huffman (BTYPE 1) and dynamic-tree (BTYPE 2, deflate.py:1084-1517;
+ * handled by a second, wave-per-stream pass) blocks, 4 trailer bytes required
  * but Adler-32 not verified -- exactly the reference's acceptance (deflate.py:635-651 IDLE/STARTD,
  * :656-732 HEADER, :1402-1445 NEXT, :1519-1591 INFLATE, :1593-1659 COPY, :517-533 get4/adv).
  * `obsize` != 0 selects the reference-exact behaviour of an OBSIZE build (deflate.py:61-62):

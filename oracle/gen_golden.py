@@ -396,6 +396,28 @@ def gen_inflate(quick, only):
         assert err is None and res == data
         out["vectors"].append({"build": "DYNAMIC=True,OBSIZE=512", "name": name, "z_hex": z.hex(),
                                "out_hex": res.hex(), "out_len": len(res), "error": None, "cycles": cyc})
+    # (e) dynamic-tree streams (stock zlib default strategy), default build: SURVEY 8(f) rank 1
+    dyn = []
+    for f in (1, 2, 4):
+        for n in (300, 2048):
+            d = family(f, n, seed=11 + f)
+            co = zlib.compressobj(6, zlib.DEFLATED, 9)
+            dyn.append(("zdyn_fam%d_%d" % (f, n), co.compress(d) + co.flush(), d))
+    r2 = random.Random(5)
+    d = bytes(r2.choice(b"eeeeeeeeetttttttaaaaaooooiiinnn  shrdlucmfwypvbgkqjxz") for _ in range(3000))
+    co = zlib.compressobj(9, zlib.DEFLATED, 9)
+    dyn.append(("zdyn_skewed_3000", co.compress(d) + co.flush(), d))
+    co = zlib.compressobj(6, zlib.DEFLATED, 9)
+    z = co.compress(d[:1500]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(family(1, 600)) + co.flush()
+    dyn.append(("zdyn_multiblock_mixed", z, d[:1500] + family(1, 600)))
+    for name, z, d in dyn:
+        name += "_btype%d" % ((z[2] >> 1) & 3)      # zlib may still choose a fixed block for short inputs
+        t0 = time.time()
+        res, err, cyc = ref_inflate(z, dynamic=True, obsize=512)
+        assert err is None and res == d, (name, err)
+        out["vectors"].append({"build": "DYNAMIC=True,OBSIZE=512", "name": name, "z_hex": z.hex(),
+                               "out_hex": res.hex(), "out_len": len(res), "error": None, "cycles": cyc})
+        print("inflate %-34s %5d -> %5d  %7d cyc  %.1fs" % (name, len(z), len(res), cyc, time.time() - t0), flush=True)
     # (d) error behaviour: trailer truncated -> "NO EOF!" (deflate.py:1535-1539), or a stall
     #     that never ends (deflate.py:1600-1602), or -- one byte short -- still accepted
     for fam in (1, 4):
@@ -475,15 +497,17 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     sets = a.sets.split(",")
     t0 = time.time()
+    def dump(name, obj):          # generate first, then replace the fixture atomically
+        tmp = os.path.join(GOLD, name + ".tmp")
+        with open(tmp, "w") as f:
+            json.dump(obj, f, indent=0)
+        os.replace(tmp, os.path.join(GOLD, name))
     if "compress" in sets:
-        with open(os.path.join(GOLD, "compress_vectors.json"), "w") as f:
-            json.dump(gen_compress(a.quick, a.only), f, indent=0)
+        dump("compress_vectors.json", gen_compress(a.quick, a.only))
     if "inflate" in sets:
-        with open(os.path.join(GOLD, "inflate_vectors.json"), "w") as f:
-            json.dump(gen_inflate(a.quick, a.only), f, indent=0)
+        dump("inflate_vectors.json", gen_inflate(a.quick, a.only))
     if "port" in sets:
-        with open(os.path.join(GOLD, "port_modes.json"), "w") as f:
-            json.dump(gen_port_modes(a.quick, a.only), f, indent=0)
+        dump("port_modes.json", gen_port_modes(a.quick, a.only))
     print("done in %.0fs" % (time.time() - t0))
 
 

@@ -31,6 +31,8 @@
 #define HDLZ_E_DYNAMIC_UNSUPPORTED 6
 #define HDLZ_E_BAD_SYMBOL 7    /* literal/length symbols 286,287 (deflate.py:1437-1439 "< 1 bits") */
 #define HDLZ_E_BAD_PARAM 8
+#define HDLZ_E_HIP 9
+#define HDLZ_E_BAD_TREE 10     /* dynamic block header describes an impossible Huffman code */
 
 #define HDLZ_INFLATE_ASSUME_FIXED 1u /* DYNAMIC=False build: BTYPE ignored (deflate.py:724-732) */
 
@@ -267,6 +269,55 @@ static void adv(bitr* r, unsigned width) { /* deflate.py:521-533 */
     r->dio = t & 7;
 }
 
+/* ---- dynamic trees (BTYPE=2): deflate.py:1084-1202 (BL/READBL/REPEAT/INIT3/DISTTREE),
+ * :1204-1400 (HF1..HF4/SPREAD: canonical code construction), :1447-1517 (D_NEXT/D_NEXT_2).
+ * The reference builds instant tables with an incremental-mask retry for long codes; a canonical
+ * count/offset decoder yields the same symbols for every VALID code.  For code descriptions that are
+ * not valid prefix codes the reference's behaviour is undefined table garbage; here they are errors
+ * (HDLZ_E_BAD_TREE), using zlib's acceptance rules: over-subscribed sets are rejected, incomplete sets
+ * only allowed when they hold a single code. */
+static const uint8_t code_length_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15}; /* :97-98 */
+
+typedef struct {
+    uint16_t count[16];   /* number of codes of each length */
+    uint16_t symbol[320]; /* symbols ordered by (length, value) */
+} canon;
+
+/* returns 0 for a complete code, >0 incomplete (unused code space), <0 over-subscribed */
+static int canon_build(canon* h, const uint8_t* len, int n) {
+    uint16_t offs[16];
+    for (int l = 0; l < 16; l++) h->count[l] = 0;
+    for (int s = 0; s < n; s++) h->count[len[s]]++;
+    int left = 1;
+    for (int l = 1; l < 16; l++) {
+        left <<= 1;
+        left -= h->count[l];
+        if (left < 0) return left;
+    }
+    offs[1] = 0;
+    for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + h->count[l]);
+    for (int s = 0; s < n; s++)
+        if (len[s]) h->symbol[offs[len[s]]++] = (uint16_t)s;
+    return left;
+}
+
+/* decode one symbol (codes are packed MSB first, deflate.py:1295-1316 reverses them into the tables);
+ * returns the symbol or -1 when no code of length <= 15 matches */
+static int canon_decode(bitr* r, const canon* h) {
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l < 16; l++) {
+        code |= (int)get4(r, 0, 1);
+        adv(r, 1);
+        int count = h->count[l];
+        if (code - count < first) return h->symbol[index + (code - first)];
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
 int hdlz_oracle_inflate(const uint8_t* z, size_t zn, unsigned flags, uint32_t obsize, uint8_t* out,
                         size_t out_cap, size_t* out_len) {
     build_tables();
@@ -292,7 +343,6 @@ int hdlz_oracle_inflate(const uint8_t* z, size_t zn, unsigned flags, uint32_t ob
         final = (int)get4(&r, 0, 1);
         unsigned hm = (flags & HDLZ_INFLATE_ASSUME_FIXED) ? 1u : get4(&r, 1, 2);
         if (hm == 3) return HDLZ_E_BAD_BTYPE;
-        if (hm == 2) return HDLZ_E_DYNAMIC_UNSUPPORTED;
         if (hm == 0) {
             /* stored: deflate.py:709-717 then COPY :1603-1626 */
             unsigned skip = 8 - r.dio;
@@ -313,14 +363,69 @@ int hdlz_oracle_inflate(const uint8_t* z, size_t zn, unsigned flags, uint32_t ob
             break;
         }
         adv(&r, 3);
+        canon lencode, distcode;
+        if (hm == 2) {
+            /* BL (deflate.py:1090-1114): HLIT, HDIST, HCLEN, then the code-length code lengths */
+            int nlen = (int)get4(&r, 0, 5) + 257;
+            int ndist = (int)get4(&r, 5, 5) + 1;
+            int ncode = (int)get4(&r, 10, 4) + 4;
+            adv(&r, 14);
+            if (nlen > 286 || ndist > 30) return HDLZ_E_BAD_TREE;
+            uint8_t lengths[320];
+            memset(lengths, 0, sizeof(lengths));
+            for (int i = 0; i < ncode; i++) {
+                lengths[code_length_order[i]] = (uint8_t)get4(&r, 0, 3);
+                adv(&r, 3);
+            }
+            if (canon_build(&lencode, lengths, 19) != 0) return HDLZ_E_BAD_TREE;
+            /* READBL / REPEAT (deflate.py:1116-1164, :1190-1202) */
+            int idx = 0;
+            while (idx < nlen + ndist) {
+                int sym = canon_decode(&r, &lencode);
+                if (sym < 0) return HDLZ_E_BAD_TREE;
+                if (sym < 16) {
+                    lengths[idx++] = (uint8_t)sym;
+                } else {
+                    int prev = 0, rep;
+                    if (sym == 16) {
+                        if (idx == 0) return HDLZ_E_BAD_TREE;
+                        prev = lengths[idx - 1];
+                        rep = 3 + (int)get4(&r, 0, 2);
+                        adv(&r, 2);
+                    } else if (sym == 17) {
+                        rep = 3 + (int)get4(&r, 0, 3);
+                        adv(&r, 3);
+                    } else {
+                        rep = 11 + (int)get4(&r, 0, 7);
+                        adv(&r, 7);
+                    }
+                    if (idx + rep > nlen + ndist) return HDLZ_E_BAD_TREE;
+                    while (rep--) lengths[idx++] = (uint8_t)prev;
+                }
+            }
+            if (lengths[256] == 0) return HDLZ_E_BAD_TREE; /* no end-of-block code */
+            int err = canon_build(&lencode, lengths, nlen);
+            if (err < 0 || (err > 0 && nlen - lencode.count[0] != 1)) return HDLZ_E_BAD_TREE;
+            err = canon_build(&distcode, lengths + nlen, ndist);
+            if (err < 0 || (err > 0 && ndist - distcode.count[0] != 1)) return HDLZ_E_BAD_TREE;
+            if (r.di > isize - 3) return HDLZ_E_NO_EOF; /* header ran into the trailer / past the end */
+        }
         /* NEXT / INFLATE loop */
         int eob = 0;
         while (!eob) {
-            unsigned cto = get4(&r, 0, 9);            /* deflate.py:1411 */
-            unsigned leaf = stat_leaves[cto & 511];  /* :1417 */
-            unsigned nbits = leaf & 15, code = leaf >> 4;
-            if (nbits < 1) return HDLZ_E_BAD_SYMBOL; /* :1437-1439 */
-            adv(&r, nbits);
+            unsigned code;
+            if (hm == 2) {
+                int sym = canon_decode(&r, &lencode); /* NEXT with the dynamic leaves (deflate.py:1409-1445) */
+                if (sym < 0) return HDLZ_E_BAD_SYMBOL;
+                code = (unsigned)sym;
+            } else {
+                unsigned cto = get4(&r, 0, 9);            /* deflate.py:1411 */
+                unsigned leaf = stat_leaves[cto & 511];  /* :1417 */
+                unsigned nbits = leaf & 15;
+                code = leaf >> 4;
+                if (nbits < 1) return HDLZ_E_BAD_SYMBOL; /* :1437-1439 */
+                adv(&r, nbits);
+            }
             /* INFLATE (deflate.py:1519-1591) */
             if (r.di > isize - 3) return HDLZ_E_NO_EOF; /* :1535-1539 */
             if (code == 256) {
@@ -333,13 +438,26 @@ int hdlz_oracle_inflate(const uint8_t* z, size_t zn, unsigned flags, uint32_t ob
                 if (token >= 29) return HDLZ_E_BAD_SYMBOL; /* CopyLength has 29 entries */
                 unsigned el = extra_length_bits[token];
                 unsigned tlength = copy_length[token] + get4(&r, 0, el);
-                unsigned t = get4(&r, el, 5);
-                unsigned dc = rev_bits(t, 5);
-                if (dc >= 30) return HDLZ_E_BAD_DISTANCE; /* CopyDistance has 30 entries */
-                unsigned more = extra_distance_bits[dc >> 1];
-                unsigned distance = copy_distance[dc] + get4(&r, el + 5, more);
-                adv(&r, el + 5 + more);
-                if (distance > dout || distance > obsize) return HDLZ_E_BAD_DISTANCE; /* D8 */
+                unsigned dc, more, distance;
+                if (hm == 2) {
+                    /* D_NEXT / D_NEXT_2 (deflate.py:1447-1517): extra length bits, distance symbol, extra bits */
+                    adv(&r, el);
+                    int ds = canon_decode(&r, &distcode);
+                    if (ds < 0) return HDLZ_E_BAD_SYMBOL;
+                    dc = (unsigned)ds;
+                    if (dc >= 30) return HDLZ_E_BAD_DISTANCE;
+                    more = extra_distance_bits[dc >> 1];
+                    distance = copy_distance[dc] + get4(&r, 0, more);
+                    adv(&r, more);
+                } else {
+                    unsigned t = get4(&r, el, 5);
+                    dc = rev_bits(t, 5);
+                    if (dc >= 30) return HDLZ_E_BAD_DISTANCE; /* CopyDistance has 30 entries */
+                    more = extra_distance_bits[dc >> 1];
+                    distance = copy_distance[dc] + get4(&r, el + 5, more);
+                    adv(&r, el + 5 + more);
+                }
+                if (distance > dout || distance > obsize) return HDLZ_E_BAD_DISTANCE; /* :1506-1508, D8 */
                 if (r.di >= isize - 2) return HDLZ_E_NO_EOF; /* COPY would hold forever (:1600) */
                 if (dout + tlength > out_cap) return HDLZ_E_OUT_CAPACITY;
                 for (unsigned i = 0; i < tlength; i++, dout++) out[dout] = out[dout - distance]; /* COPY :1627-1659 */

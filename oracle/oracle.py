@@ -11,6 +11,7 @@ _SO = os.path.join(_HERE, "_build", "libhdlz_oracle.so")
 
 OK, E_SHORT_INPUT, E_OUT_CAPACITY, E_BAD_BTYPE, E_BAD_DISTANCE, E_NO_EOF, E_DYNAMIC_UNSUPPORTED, \
     E_BAD_SYMBOL, E_BAD_PARAM = range(9)
+E_HIP, E_BAD_TREE = 9, 10
 INFLATE_ASSUME_FIXED = 1
 
 

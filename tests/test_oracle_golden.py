@@ -151,10 +151,13 @@ def test_inflate_errors(oracle):
     # BTYPE=3
     z = b"\x78\x9c" + bytes([0x07]) + bytes(8)
     assert oracle.inflate(z)[0] == oracle.E_BAD_BTYPE
-    # dynamic block -> unsupported
+    # dynamic block: decoded; a damaged code description is BAD_TREE
     z = zlib.compress(DYN_TEXT, 9)
     assert (z[2] >> 1) & 3 == 2
-    assert oracle.inflate(z)[0] == oracle.E_DYNAMIC_UNSUPPORTED
+    assert oracle.inflate(z) == (0, DYN_TEXT)
+    bad = bytearray(z)
+    bad[3] |= 0xFF; bad[4] |= 0xFF          # HLIT/HDIST/HCLEN and the first code-length codes forced to ones
+    assert oracle.inflate(bytes(bad))[0] in (oracle.E_BAD_TREE, oracle.E_BAD_SYMBOL, oracle.E_BAD_DISTANCE, oracle.E_NO_EOF)
     # distance reaching before the start of the output
     bad = bytearray(zlib.compressobj(strategy=zlib.Z_FIXED).compress(b"") )
     # fixed block: literal 'a' then match len 3 dist 4 (only 1 byte produced)
@@ -173,6 +176,23 @@ def test_inflate_errors(oracle):
     z = b"\x78\x9c" + body + bytes(4)
     assert oracle.inflate(z)[0] == oracle.E_BAD_DISTANCE
     assert oracle.inflate(b"\x78\x9c\x03")[0] == oracle.E_SHORT_INPUT
+
+
+def test_inflate_dynamic_streams_vs_zlib(oracle):
+    r = random.Random(21)
+    for it in range(150):
+        n = r.choice([1, 10, 100, 1000, 5000, 40000])
+        alpha = r.choice([b"ab", b"abcdefgh", bytes(range(256)), b"0123456789 ", DYN_TEXT[:64]])
+        data = bytes(r.choice(alpha) for _ in range(n))
+        co = zlib.compressobj(r.choice([1, 6, 9]), zlib.DEFLATED, r.choice([9, 12, 15]))
+        z = co.compress(data[: n // 2]) + (co.flush(zlib.Z_FULL_FLUSH) if r.random() < 0.3 else b"") + \
+            co.compress(data[n // 2:]) + co.flush()
+        assert oracle.inflate(z) == (0, data)
+        # random damage never crashes and never "succeeds" with a different length silently
+        zb = bytearray(z)
+        zb[r.randrange(2, len(zb))] ^= 1 << r.randrange(8)
+        rc, out = oracle.inflate(bytes(zb))
+        assert rc in range(11)
 
 
 def test_batch_driver_threads(oracle):

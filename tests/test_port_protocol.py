@@ -88,18 +88,10 @@ def run_mode_flow(rec, engine):
     b_data = bytes.fromhex(rec["b_hex"])
     zl = bytes.fromhex(rec["zl_hex"])
     dut, s = make_dut(engine)
-    if (zl[2] >> 1) & 3 == 2:
-        # stock zlib chose a dynamic block: dynamic trees are SURVEY 8(f) rank 1 (not built yet)
-        with pytest.raises(Error):
-            stream_leg(dut, s, zl, STARTD)
-        dut, s = make_dut(engine)
-        # keep the input memory state the reference had before its compress leg
-        for a, b in enumerate(zl):
-            s["i_mode"].next, s["i_waddr"].next, s["i_data"].next = WRITE, a, b
-            dut.cycle()
-    else:
-        inf, _ = stream_leg(dut, s, zl, STARTD)
-        assert inf == b_data and inf.hex() == rec["inflate_hex"]
+    # stock zlib (default strategy) emits dynamic-tree blocks for most modes: handled by the second
+    # inflate pass
+    inf, _ = stream_leg(dut, s, zl, STARTD)
+    assert inf == b_data and inf.hex() == rec["inflate_hex"]
     payload = bytes.fromhex(rec["compress_in_hex"])
     comp, total = stream_leg(dut, s, payload, STARTC, short_input=len(b_data) < 4)
     assert comp.hex() == rec["compress_hex"], rec["mode"]
