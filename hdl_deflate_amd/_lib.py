@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HDLZ_LIB") or os.path.join(_HERE, "lib", "libhdlz.so")   # HDLZ_LIB: A/B builds
 EXPORTS = ("hdlz_version", "hdlz_status_string", "hdlz_last_error", "hdlz_device_count", "hdlz_out_bound",
-           "hdlz_compress_batch", "hdlz_inflate_batch")
+           "hdlz_compress_batch", "hdlz_inflate_batch", "hdlz_compact_batch")
 _lib = None
 
 
@@ -34,5 +34,7 @@ def load():
     L.hdlz_compress_batch.argtypes = [vp, vp, u64, u32, u64, ci, ci, vp, u64, vp, vp, vp]
     L.hdlz_inflate_batch.restype = ci
     L.hdlz_inflate_batch.argtypes = [vp, vp, u64, u32, u64, u32, u32, vp, u64, vp, vp, vp]
+    L.hdlz_compact_batch.restype = ci
+    L.hdlz_compact_batch.argtypes = [vp, u64, vp, vp, u64, vp, vp]
     _lib = L
     return L

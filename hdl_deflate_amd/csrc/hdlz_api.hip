@@ -101,4 +101,14 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     return HDLZ_OK;
 }
 
+int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, const uint64_t* d_off,
+                       uint64_t nblocks, uint8_t* d_archive, void* stream) {
+    if (nblocks && (!d_rows || !d_len || !d_off || !d_archive)) return fail_param("null device pointer");
+    int rc = check_device();
+    if (rc != HDLZ_OK) return rc;
+    hipError_t e = hdlz::launch_compact(d_rows, row_pitch, d_len, d_off, nblocks, d_archive, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "launch k_compact");
+    return HDLZ_OK;
+}
+
 }  // extern "C"

@@ -75,6 +75,26 @@ class Engine(object):
         self._check(rc, "hdlz_inflate_batch")
         return out, out_len, status
 
+    # -- archive compaction
+    def compact(self, rows, lens, offsets=None, archive=None):
+        """rows uint8[B, pitch], lens int32[B] -> (archive uint8[total], offsets int64[B]).
+        `offsets` (exclusive scan, e.g. global offsets after the multi-GPU length all-gather) and `archive`
+        may be supplied; otherwise they are computed / allocated here (one host sync for the size)."""
+        assert rows.is_cuda and rows.dtype == torch.uint8 and rows.dim() == 2 and rows.is_contiguous()
+        B, pitch = rows.shape
+        lens = lens.contiguous()
+        if offsets is None:
+            l64 = lens.to(torch.int64)
+            offsets = torch.cumsum(l64, 0) - l64
+        offsets = offsets.contiguous()
+        if archive is None:
+            total = int((offsets[-1] + lens[-1]).item()) if B else 0
+            archive = torch.empty(total, dtype=torch.uint8, device=rows.device)
+        rc = self.lib.hdlz_compact_batch(rows.data_ptr(), pitch, lens.data_ptr(), offsets.data_ptr(), B,
+                                         archive.data_ptr(), self._stream())
+        self._check(rc, "hdlz_compact_batch")
+        return archive, offsets
+
     # -- single-stream conveniences used by the port adapter (one START = one block)
     def compress_bytes(self, data, cwindow=32, maxmatch=10):
         """-> (status, bytes)"""

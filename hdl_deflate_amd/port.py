@@ -18,6 +18,13 @@ Protocol facts honoured:
     (test_deflate.py:159,250) never dead-locks;
   * o_done rises only when all output is readable; final o_oprogress = output length (deflate.py:814);
   * where the reference raises myhdl.Error (or hangs: N < 5), cycle() raises hdl_deflate_amd.Error.
+
+Streaming mode: with `obsize=N` (a power of two, the reference's OBSIZE,
+deflate.py:61-62) the output memory is the reference's circular buffer of N bytes -- `o_byte` returns
+oram[i_raddr & (N-1)] (deflate.py:601) -- and output is released with the reference's back-pressure:
+the engine's result becomes visible only up to `i_raddr + N` (the reference holds while
+`do >= i_raddr + OBSIZE`, deflate.py:1531-1534, :1597-1599), so a harness that reads too slowly sees
+exactly the stall it would see on the hardware, and `o_done` rises only when the last byte is released.
 """
 from .constants import (IDLE, WRITE, READ, STARTC, STARTD, OK, CWINDOW, MAXMATCH, LMAX, STATUS_NAMES)
 from .errors import Error, HdlzStatusError
@@ -72,7 +79,7 @@ class DeflatePort(object):
 
     def __init__(self, i_mode, o_done, i_data, o_iprogress, o_oprogress, o_byte, i_waddr, i_raddr,
                  clk=None, reset=None, engine=None, cwindow=CWINDOW, maxmatch=MAXMATCH,
-                 inflate_flags=0, obsize=0):
+                 inflate_flags=0, obsize=0, stream_obsize=None):
         self.i_mode, self.o_done, self.i_data = i_mode, o_done, i_data
         self.o_iprogress, self.o_oprogress, self.o_byte = o_iprogress, o_oprogress, o_byte
         self.i_waddr, self.i_raddr, self.clk, self.reset = i_waddr, i_raddr, clk, reset
@@ -82,6 +89,10 @@ class DeflatePort(object):
         self.engine = engine
         self.cwindow, self.maxmatch = cwindow, maxmatch
         self.inflate_flags, self.obsize = inflate_flags, obsize
+        if stream_obsize is not None and (stream_obsize < 64 or stream_obsize & (stream_obsize - 1)):
+            raise ValueError("stream_obsize must be a power of two >= 64")
+        self.stream_obsize = stream_obsize
+        self.pending_done = False
         self.iram = bytearray()
         self.oram = b""
         self.isize = 0
@@ -102,7 +113,22 @@ class DeflatePort(object):
         mode = int(self.i_mode.val)
         # io_logic (deflate.py:599-605)
         ra = int(self.i_raddr.val) & mask
-        self._set(self.o_byte, self.oram[ra] if ra < len(self.oram) else 0)
+        if self.stream_obsize is None:
+            self._set(self.o_byte, self.oram[ra] if ra < len(self.oram) else 0)
+        else:
+            # circular output memory: the newest released byte whose address is congruent to i_raddr
+            N = self.stream_obsize
+            vis = int(self.o_oprogress.val)
+            p = (ra & (N - 1)) + ((vis - 1 - (ra & (N - 1))) // N) * N if vis > (ra & (N - 1)) else -1
+            self._set(self.o_byte, self.oram[p] if 0 <= p < len(self.oram) else 0)
+            if self.pending_done:
+                # release output with the reference's hold `do >= i_raddr + OBSIZE` (deflate.py:1531-1534)
+                vis = min(len(self.oram), ra + N)
+                if vis > int(self.o_oprogress.val):
+                    self._set(self.o_oprogress, vis)
+                if int(self.o_oprogress.val) == len(self.oram):
+                    self.pending_done = False
+                    self._set(self.o_done, True)
         if mode == WRITE:
             wa = int(self.i_waddr.val) & mask
             if wa >= len(self.iram):
@@ -119,6 +145,7 @@ class DeflatePort(object):
                 self._set(self.o_iprogress, 0)
                 self._set(self.o_oprogress, 0)
                 self.oram = b""
+                self.pending_done = False
         elif mode == IDLE:
             self._run()
 
@@ -138,8 +165,14 @@ class DeflatePort(object):
             raise HdlzStatusError(st, what)
         self.oram = res
         self._set(self.o_iprogress, self.isize)
-        self._set(self.o_oprogress, len(res))
-        self._set(self.o_done, True)
+        if self.stream_obsize is None:
+            self._set(self.o_oprogress, len(res))
+            self._set(self.o_done, True)
+        else:
+            self._set(self.o_oprogress, min(len(res), (int(self.i_raddr.val) & ((1 << LMAX) - 1)) + self.stream_obsize))
+            self.pending_done = int(self.o_oprogress.val) < len(res)
+            if not self.pending_done:
+                self._set(self.o_done, True)
 
     @staticmethod
     def _set(sig, v):

@@ -46,3 +46,22 @@ def archive_offsets(all_len):
     l64 = all_len.to(torch.int64)
     incl = torch.cumsum(l64, 0)
     return incl - l64, int(incl[-1].item()) if l64.numel() else 0
+
+
+def gather_archive(local_archive, nbytes_local, group=None):
+    """concatenate the per-rank archives on every rank (payload gather; NOT on the timed path):
+    all-gather of sizes, pad to the largest, all-gather, trim.  Returns uint8 [sum of sizes]."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_archive[:nbytes_local]
+    world = dist.get_world_size(group)
+    dev = local_archive.device
+    cdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
+    sizes = torch.zeros(world, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([nbytes_local], dtype=torch.int64, device=cdev), group=group)
+    sizes = sizes.tolist()
+    mx = max(sizes) if sizes else 0
+    pad = torch.zeros(mx, dtype=torch.uint8, device=cdev)
+    pad[:nbytes_local] = local_archive[:nbytes_local].to(cdev)
+    full = torch.empty(world * mx, dtype=torch.uint8, device=cdev)
+    dist.all_gather_into_tensor(full, pad, group=group)
+    return torch.cat([full[r * mx: r * mx + sizes[r]] for r in range(world)]).to(dev)

@@ -97,6 +97,15 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
                        uint64_t nstreams, uint32_t flags, uint32_t obsize, uint8_t* d_out, uint64_t out_pitch,
                        uint32_t* d_out_len, uint32_t* d_status, void* stream);
 
+/*
+ * Archive compaction (no reference counterpart -- the reference drains its output
+ * one byte per READ, deflate.py:601): copies d_len[b] bytes of row b (d_rows + b*row_pitch) to
+ * d_archive + d_off[b].  d_off is the exclusive scan of the lengths, computed by the caller (across GPUs:
+ * after the all-gather of the lengths).  Works for compress and inflate outputs alike.
+ */
+int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, const uint64_t* d_off,
+                       uint64_t nblocks, uint8_t* d_archive, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

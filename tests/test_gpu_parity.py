@@ -249,6 +249,26 @@ def test_inflate_error_statuses(engine, oracle):
     assert st == 2
 
 
+def test_compact_archive(engine, oracle):
+    """variable-length rows -> one contiguous archive; every stream must still inflate"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    B, n = 1000, 1500
+    d = make_blocks(B, n, "cuda", seed=77)
+    out, ol, st = engine.compress_batch(d)
+    arch, offs = engine.compact(out, ol)
+    torch.cuda.synchronize()
+    ha, ho, hl, hoff = arch.cpu().numpy(), out.cpu().numpy(), ol.cpu().numpy(), offs.cpu().numpy()
+    assert len(ha) == int(hl.sum()) and (hoff == np.cumsum(hl) - hl).all()
+    for b in range(B):
+        assert ha[hoff[b]:hoff[b] + hl[b]].tobytes() == ho[b, :hl[b]].tobytes()
+    # the archive + offsets are a valid ragged inflate input
+    in_off = torch.cat([offs, (offs[-1:] + ol[-1:].to(torch.int64))])
+    back, bl, bs = engine.inflate_batch(torch.cat([arch, torch.zeros(64, dtype=torch.uint8, device="cuda")]),
+                                        in_off=in_off, out_pitch=1504)
+    assert int((bs != 0).sum()) == 0 and torch.equal(back[:, :n], d)
+
+
 def test_port_adapter_on_gpu_modes(engine):
     """the reference's own test flow (test_deflate.py:105-286) through the port adapter on the HIP engine"""
     from test_port_protocol import run_mode_flow

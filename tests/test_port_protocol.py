@@ -161,3 +161,45 @@ def test_errors_surface_as_exceptions():
     z = zlib.compress(b"hello hello hello hello")[:-2]
     with pytest.raises(Error):          # "NO EOF!" (deflate.py:1535-1539)
         stream_leg(dut, s, z, STARTD)
+
+
+def test_streaming_obsize_backpressure():
+    """bounded circular output memory with the reference's hold (deflate.py:1531-1534):
+    output is released only up to i_raddr + OBSIZE, reads go through oram[i_raddr & (OBSIZE-1)]"""
+    from hdl_deflate_amd.data import family_bytes
+    data = family_bytes(2, 3000, seed=9)
+    z = zlib.compressobj(strategy=zlib.Z_FIXED, wbits=9)
+    zs = z.compress(data) + z.flush()
+    s = dict(i_mode=Sig(0), o_done=Sig(False), i_data=Sig(0), o_iprogress=Sig(0), o_oprogress=Sig(0),
+             o_byte=Sig(0), i_waddr=Sig(0), i_raddr=Sig(0), clk=Sig(False), reset=Sig(False))
+    dut = deflate(s["i_mode"], s["o_done"], s["i_data"], s["o_iprogress"], s["o_oprogress"], s["o_byte"],
+                  s["i_waddr"], s["i_raddr"], s["clk"], s["reset"], engine=OracleEngine(), stream_obsize=512)
+    # preload, START, then read slowly: the released amount must never run more than OBSIZE ahead
+    for a, b in enumerate(zs):
+        s["i_mode"].next, s["i_waddr"].next, s["i_data"].next = WRITE, a, b
+        dut.cycle()
+    s["i_mode"].next = STARTD
+    dut.cycle()
+    s["i_mode"].next = IDLE
+    dut.cycle()
+    assert not s["o_done"] and int(s["o_oprogress"]) == 512          # held at i_raddr(0) + OBSIZE
+    got = bytearray()
+    ri = 0
+    for _ in range(20000):
+        assert int(s["o_oprogress"]) <= ri + 512
+        if ri < s["o_oprogress"]:
+            s["i_mode"].next, s["i_raddr"].next = READ, ri
+            dut.cycle()
+            got.append(int(s["o_byte"]))
+            ri += 1
+        else:
+            s["i_mode"].next = IDLE
+            dut.cycle()
+        if s["o_done"] and ri == int(s["o_oprogress"]):
+            break
+    assert bytes(got) == data and int(s["o_oprogress"]) == len(data)
+    # the same flow through the reference's streaming harness
+    dut2, s2 = make_dut(OracleEngine())
+    dut2.stream_obsize = 512
+    inf, total = stream_leg(dut2, s2, zs, STARTD)
+    assert inf == data and total == len(data)

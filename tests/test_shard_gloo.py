@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from hdl_deflate_amd.shard import shard_range, gather_lengths, archive_offsets
+from hdl_deflate_amd.shard import shard_range, gather_lengths, archive_offsets, gather_archive
 
 
 def test_shard_range_covers_everything():
@@ -33,7 +33,10 @@ def _worker(rank, world, port, nblocks, q):
         lens = torch.tensor([len(O.compress(x)[1]) for x in blocks], dtype=torch.int32)
         all_len = gather_lengths(lens, nblocks)
         offs, total = archive_offsets(all_len)
-        q.put((rank, all_len.tolist(), offs.tolist(), total))
+        # payload gather of the per-rank archives (8(f) rank 2): concatenation = the global archive
+        mine = torch.frombuffer(bytearray(b"".join(O.compress(x)[1] for x in blocks)), dtype=torch.uint8)
+        whole = gather_archive(mine, mine.numel())
+        q.put((rank, all_len.tolist(), offs.tolist(), total, bytes(whole.numpy().tobytes())))
     finally:
         dist.destroy_process_group()
 
@@ -56,10 +59,12 @@ def test_length_allgather_world2():
     from oracle import oracle as O
     from hdl_deflate_amd.data import family_bytes
     want = [len(O.compress(family_bytes(1 + b % 4, 300 + (b % 5), seed=b, counter0=16 * b))[1]) for b in range(nblocks)]
-    for rank, all_len, offs, total in res:
+    blobs = [O.compress(family_bytes(1 + b % 4, 300 + (b % 5), seed=b, counter0=16 * b))[1] for b in range(nblocks)]
+    for rank, all_len, offs, total, whole in res:
         assert all_len == want
         assert offs == list(np.cumsum([0] + want[:-1]))
         assert total == sum(want)
+        assert whole == b"".join(blobs)
 
 
 def test_single_process_passthrough():
