@@ -298,7 +298,8 @@ __global__ __launch_bounds__(64) void k_compress(CompressArgs a) {
                 const uint32_t d4 = best[i];
                 // R3: 1 <= p <= N-5;  R4: d <= min(CWINDOW, p)
                 const bool ok = (d4 <= cw4) & (d4 <= p4_run + (uint32_t)(4 * i)) & (nrem >= (uint32_t)(i + 5));   // '&': no short-circuit branches
-                const uint32_t d = ok ? (d4 >> 2) : 1u;
+                // distance for the gather; for "no match" any in-range value will do (the result is discarded)
+                const uint32_t d = (NCH == 1) ? ((d4 & 0xFCu) >> 2) : (ok ? (d4 >> 2) : 1u);
                 // R5: common prefix of x[p+3..p+10] and x[p-d+3..p-d+10]
                 const uint32_t q = lds_run + (uint32_t)(i + 3) - d;   // byte offset of the candidate's 4th byte
                 const uint32_t qd = q >> 2, qs = q & 3u;
@@ -319,7 +320,13 @@ __global__ __launch_bounds__(64) void k_compress(CompressArgs a) {
                 if constexpr (bsh == 0) lit = (ow[i >> 2] << 2) & 0x3FCu;
                 else lit = (ow[i >> 2] >> (bsh - 2)) & 0x3FCu;
                 uint32_t mt;
-                if (NCH == 1) mt = mlen * 65664u + d4 + (LUT_MATCH_BYTE - 65924u);          // (len-1)<<16 | base + ((len-3)*32 + d-1)*4
+                if (NCH == 1) {
+                    // (len-1)<<16 | base + ((len-3)*32 + d-1)*4 = mlen*65664 + d4 + const, as two shift-adds:
+                    // hipcc folds the C form into a quarter-rate v_mul_lo_u32
+                    uint32_t t1;
+                    asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(t1) : "v"(mlen), "v"(d4 + (LUT_MATCH_BYTE - 65924u)));
+                    asm("v_lshl_add_u32 %0, %1, 16, %2" : "=v"(mt) : "v"(mlen), "v"(t1));
+                }
                 else mt = (mlen << 16) + d4 + (LUT_MATCH_BYTE - 65540u);                     // (len-1)<<16 | base + (d-1)*4
                 tok[i] = ok ? mt : lit;
                 if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(tok); pin(ow); PHASE_FENCE(); }
