@@ -28,6 +28,16 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def measured_traffic(key):
+    """HBM bytes per launch measured with rocprofv3 PMC passes for exactly this kernel/config (profiles/traffic.json)"""
+    try:
+        with open(os.path.join(REPO, "profiles", "traffic.json")) as f:
+            e = json.load(f).get(key)
+        return (e["traffic_bytes"], e["source"]) if e else (None, None)
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +163,8 @@ def main():
     value = in_bytes / (dt / a.steps) / 1e6                      # MB/s, whole job
     algo_bytes = in_bytes_local + out_bytes_local + 4 * B        # per launch (one GPU)
     achieved = algo_bytes / (k_avg * 1e-3) / 1e9
+    kname = "k_compress<%d>" % (1 if a.cwindow <= 32 else 2 if a.cwindow <= 64 else 8)
+    traffic, tsrc = measured_traffic("%s|blocks=%d|block=%d|data=%s" % (kname, B, n, a.data))
     res = {
         "metric": "compress_input_throughput (CWINDOW=%d, MATCH10=%s, static tree)" % (a.cwindow, a.maxmatch == 10),
         "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -165,9 +177,9 @@ def main():
                    "parallelism": "block-shard x%d (length all-gather only)" % world},
         "per_gpu_MBps": round(value / world, 1),
         "compression_ratio_out_over_in": round(out_bytes / in_bytes, 4),
-        "roofline": {"bound": "hbm", "kernel": "k_compress<%d>" % (1 if a.cwindow <= 32 else 2 if a.cwindow <= 64 else 8), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg, 4),
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": tsrc, "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg, 4),
                      "kernel_ms_min": round(k_ms[0], 4),
                      "note": "bytes = N_in + N_out + 4 per block; this path is VALU-issue bound, not HBM bound "
                              "(DESIGN.md)"},
@@ -245,6 +257,7 @@ def bench_inflate(a):
     z_bytes, u_bytes = int(off[-1]), B * n
     algo = z_bytes + u_bytes + 4 * B
     achieved = algo / (k_avg * 1e-3) / 1e9
+    traffic, tsrc = measured_traffic("k_inflate|streams=%d|block=%d" % (B, n))
     res = {"metric": "inflate_output_throughput (zlib Z_FIXED streams, DYNAMIC=False)",
            "value": round(u_bytes / (dt / a.steps) / 1e6, 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
@@ -254,8 +267,8 @@ def bench_inflate(a):
            "input_MBps": round(z_bytes / (dt / a.steps) / 1e6, 1),
            "compression_ratio_out_over_in": round(z_bytes / u_bytes, 4),
            "roofline": {"bound": "hbm", "kernel": "k_inflate", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                        "algorithmic_bytes_per_launch": algo, "kernel_ms_avg": round(k_avg, 4),
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "traffic_source": tsrc, "algorithmic_bytes_per_launch": algo, "kernel_ms_avg": round(k_avg, 4),
                         "kernel_ms_min": round(k_ms[0], 4)}}
     if a.cpu_seconds > 0:
         from oracle import oracle as O
