@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--data", default="families", choices=["families", "text"],
                     help="families = test_deflate.py families 1-4 (BASELINE configs[1]); text = Zipf pseudo-English "
                          "(enwik8 stand-in for configs[2]: enwik8 cannot be fetched, no network)")
+    ap.add_argument("--zlib-strategy", default="fixed", choices=["fixed", "default"],
+                    help="inflate mode: fixed = Z_FIXED streams (configs[3]); default = stock zlib streams with "
+                         "dynamic trees (exercises the second pass k_inflate_dyn, SURVEY 8(f) rank 1)")
     ap.add_argument("--mode", default="compress", choices=["compress", "inflate"],
                     help="compress = BASELINE metric (default); inflate = configs[3] side metric (1 GPU)")
     a = ap.parse_args()
@@ -193,10 +196,10 @@ def main():
 
 def _zfixed_chunk(args):
     import zlib
-    buf, n = args
+    buf, n, strat = args
     out = []
     for k in range(0, len(buf), n):
-        co = zlib.compressobj(strategy=zlib.Z_FIXED, wbits=15)
+        co = zlib.compressobj(strategy=zlib.Z_FIXED if strat == "fixed" else zlib.Z_DEFAULT_STRATEGY, wbits=15)
         out.append(co.compress(buf[k:k + n]) + co.flush())
     return out
 
@@ -220,7 +223,7 @@ def bench_inflate(a):
     nproc = min(os.cpu_count() or 1, 64)
     per = (B + nproc - 1) // nproc
     with mp.get_context("fork").Pool(nproc) as pool:
-        parts = pool.map(_zfixed_chunk, [(host[k:k + per].tobytes(), n) for k in range(0, B, per)])
+        parts = pool.map(_zfixed_chunk, [(host[k:k + per].tobytes(), n, a.zlib_strategy) for k in range(0, B, per)])
     streams = [z for p in parts for z in p]
     lens = np.fromiter((len(z) for z in streams), dtype=np.int64, count=B)
     off = np.zeros(B + 1, np.int64)
@@ -229,7 +232,7 @@ def bench_inflate(a):
     d_in = torch.from_numpy(flat.copy()).to(dev)
     d_off = torch.from_numpy(off).to(dev)
     d_out = torch.empty((B, n), dtype=torch.uint8, device=dev)
-    flags = hdl_deflate_amd.INFLATE_ASSUME_FIXED
+    flags = hdl_deflate_amd.INFLATE_ASSUME_FIXED if a.zlib_strategy == "fixed" else 0
 
     def step():
         return eng.inflate_batch(d_in, in_off=d_off, out_pitch=n, flags=flags, out=d_out)
@@ -258,12 +261,14 @@ def bench_inflate(a):
     algo = z_bytes + u_bytes + 4 * B
     achieved = algo / (k_avg * 1e-3) / 1e9
     traffic, tsrc = measured_traffic("k_inflate|streams=%d|block=%d" % (B, n))
-    res = {"metric": "inflate_output_throughput (zlib Z_FIXED streams, DYNAMIC=False)",
+    res = {"metric": "inflate_output_throughput (zlib Z_FIXED streams, DYNAMIC=False)" if a.zlib_strategy == "fixed"
+           else "inflate_output_throughput (stock zlib streams, dynamic trees, two passes)",
            "value": round(u_bytes / (dt / a.steps) / 1e6, 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": "BASELINE configs[3]: %d zlib Z_FIXED streams over %d B blocks, families 1/2/4, "
-                                  "HBM-resident" % (B, n), "streams": B, "block_bytes": n},
+           "config": {"workload": "BASELINE configs[3]: %d zlib %s streams over %d B blocks, families 1/2/4, "
+                                  "HBM-resident" % (B, "Z_FIXED" if a.zlib_strategy == "fixed" else "default-strategy (dynamic trees)", n),
+                      "streams": B, "block_bytes": n},
            "input_MBps": round(z_bytes / (dt / a.steps) / 1e6, 1),
            "compression_ratio_out_over_in": round(z_bytes / u_bytes, 4),
            "roofline": {"bound": "hbm", "kernel": "k_inflate", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -275,7 +280,7 @@ def bench_inflate(a):
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         S = min(B, 1 << 19)
         t1 = time.perf_counter()
-        _, l2, s2 = O.inflate_batch(flat, off[:S + 1].astype(np.uint64), n, flags=1, nthreads=cores)
+        _, l2, s2 = O.inflate_batch(flat, off[:S + 1].astype(np.uint64), n, flags=flags, nthreads=cores)
         dtc = time.perf_counter() - t1
         assert (s2 == 0).all()
         res["cpu_baseline"] = {"value": round(S * n / dtc / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",

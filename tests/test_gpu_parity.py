@@ -109,6 +109,27 @@ def test_compress_every_block_vs_oracle_dense_matches(engine, oracle):
         assert ((ho == ro) | ~mask).all(), (nsym, cw, mm)
 
 
+def test_compress_wide_windows_large_blocks_every_block(engine, oracle):
+    """CWINDOW=64 and 256 (k_compress<2>, <8>) on 64 KiB multi-tile blocks of pseudo-English and of the
+    families, MATCH10 on/off: every block against the threaded oracle"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks, make_text_blocks
+    B, n = 192, 65536
+    for mk, cw, mm in [(make_text_blocks, 64, 10), (make_text_blocks, 256, 10), (make_blocks, 64, 5), (make_blocks, 256, 5),
+                       (make_text_blocks, 33, 10), (make_blocks, 200, 10)]:
+        d = mk(B, n, "cuda", seed=cw + mm)
+        out, ol, st = engine.compress_batch(d, cwindow=cw, maxmatch=mm)
+        torch.cuda.synchronize()
+        h, ho, hl = d.cpu().numpy(), out.cpu().numpy(), ol.cpu().numpy()
+        off = np.arange(B + 1, dtype=np.uint64) * n
+        ro, rl, rs = oracle.compress_batch(h.reshape(-1), off, cw, mm, out_pitch=ho.shape[1], nthreads=8)
+        assert (st.cpu().numpy() == 0).all() and (rs == 0).all()
+        assert (hl == rl).all(), (cw, mm)
+        mask = np.arange(ho.shape[1])[None, :] < hl[:, None]
+        assert ((ho == ro) | ~mask).all(), (cw, mm)
+        assert zlib.decompress(ho[0, :hl[0]].tobytes()) == h[0].tobytes()
+
+
 def test_compress_misaligned_inputs(engine, oracle):
     import torch
     from hdl_deflate_amd.data import family_bytes
