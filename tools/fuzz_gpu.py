@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""GPU soak test (not part of pytest: runs for --seconds): random ragged batches, random CWINDOW /
+MATCH10 / alphabets / alignments; every block of every batch is compared with the CPU oracle
+(threaded), compress and inflate.  Exit code 1 on the first mismatch, with a reproducer line."""
+import argparse
+import sys
+import time
+import zlib
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import torch                                   # noqa: E402
+import hdl_deflate_amd                         # noqa: E402
+from oracle import oracle as O                 # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    eng = hdl_deflate_amd.Engine()
+    rng = np.random.default_rng(a.seed)
+    t_end = time.time() + a.seconds
+    it = blocks = nbytes = 0
+    while time.time() < t_end:
+        it += 1
+        B = int(rng.integers(1, 3000))
+        kind = int(rng.integers(0, 6))
+        maxlen = int(rng.choice([16, 64, 300, 2048, 2100, 5000, 70000]))
+        lens = rng.integers(0, maxlen + 1, size=B)
+        if maxlen >= 5000:
+            lens = lens[: max(1, B // 40)]
+        B = len(lens)
+        total = int(lens.sum())
+        nsym = int(rng.choice([1, 2, 3, 4, 8, 26, 256]))
+        if kind == 0:
+            data = rng.integers(0, nsym, size=total, dtype=np.uint8) + (0 if nsym == 256 else int(rng.integers(0, 200)))
+        elif kind == 1:   # periodic with noise
+            per = int(rng.integers(1, 40))
+            base = rng.integers(0, 256, size=per, dtype=np.uint8)
+            data = np.tile(base, total // per + 1)[:total].copy()
+            noise = rng.random(total) < 0.02
+            data[noise] = rng.integers(0, 256, size=int(noise.sum()), dtype=np.uint8)
+        elif kind == 2:   # runs
+            data = np.repeat(rng.integers(0, 4, size=total // 3 + 1, dtype=np.uint8) + 65, 3)[:total].copy()
+        else:             # markov-ish text
+            words = [bytes(rng.integers(97, 123, size=int(rng.integers(1, 9)), dtype=np.uint8)) for _ in range(50)]
+            buf = b" ".join(words[int(i)] for i in rng.integers(0, 50, size=total // 3 + 2))
+            data = np.frombuffer(buf[:total].ljust(total, b"x"), dtype=np.uint8).copy()
+        mis = int(rng.integers(0, 16))
+        flat = np.concatenate([np.zeros(mis, np.uint8), data.astype(np.uint8), np.zeros(64, np.uint8)])
+        off = (np.concatenate([[0], np.cumsum(lens)]) + mis).astype(np.int64)
+        cw = int(rng.choice([1, 2, 5, 16, 31, 32, 33, 48, 64, 65, 128, 255, 256]))
+        mm = int(rng.choice([5, 10]))
+        d_in = torch.from_numpy(flat).cuda()
+        d_off = torch.from_numpy(off).cuda()
+        out, ol, st = eng.compress_batch(d_in, in_off=d_off, cwindow=cw, maxmatch=mm)
+        torch.cuda.synchronize()
+        ho, hl, hs = out.cpu().numpy(), ol.cpu().numpy(), st.cpu().numpy()
+        ro, rl, rs = O.compress_batch(flat, off.astype(np.uint64), cw, mm, out_pitch=ho.shape[1], nthreads=16)
+        mask = np.arange(ho.shape[1])[None, :] < rl[:, None]
+        if not ((hs == rs).all() and (hl == rl).all() and ((ho == ro) | ~mask).all()):
+            bad = int(np.nonzero((hs != rs) | (hl != rl) | (((ho != ro) & mask).any(1)))[0][0])
+            print("COMPRESS MISMATCH it=%d seed=%d block=%d n=%d cw=%d mm=%d kind=%d mis=%d status gpu/ref %d/%d len %d/%d"
+                  % (it, a.seed, bad, lens[bad], cw, mm, kind, mis, hs[bad], rs[bad], hl[bad], rl[bad]))
+            return 1
+        # inflate the compressed rows back on the GPU (padded rows, fixed pitch) for blocks that compressed
+        okb = hs == 0
+        if okb.any():
+            cap = (int(lens.max()) + 15) // 16 * 16 + 16
+            back, bl, bs = eng.inflate_batch(out, out_pitch=cap)
+            torch.cuda.synchronize()
+            hb, hbl, hbs = back.cpu().numpy(), bl.cpu().numpy(), bs.cpu().numpy()
+            for b in np.nonzero(okb)[0][: 4000]:
+                if hbs[b] != 0 or hbl[b] != lens[b] or hb[b, :lens[b]].tobytes() != flat[off[b]:off[b + 1]].tobytes():
+                    print("INFLATE MISMATCH it=%d seed=%d block=%d n=%d cw=%d mm=%d status %d len %d" %
+                          (it, a.seed, b, lens[b], cw, mm, hbs[b], hbl[b]))
+                    return 1
+            b0 = int(np.nonzero(okb)[0][0])
+            assert zlib.decompress(ho[b0, :hl[b0]].tobytes()) == flat[off[b0]:off[b0 + 1]].tobytes()
+        blocks += B
+        nbytes += total
+    print("fuzz OK: %d batches, %d blocks, %.1f MiB, seed %d" % (it, blocks, nbytes / 2 ** 20, a.seed))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
