@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
     const uint8_t* __restrict__ z = a.in + off;
     uint8_t* __restrict__ out = a.out + sid * a.out_pitch;
     uint8_t* ring8 = reinterpret_cast<uint8_t*>(lds.ring);
-    const uint32_t cap = a.out_pitch > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a.out_pitch;
+    const uint32_t cap = a.out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00u : (uint32_t)a.out_pitch;   // o + 258 never wraps
     // obsize != 0: reference-exact OBSIZE build -- the stored LEN register is LOBSIZE bits wide
     // (deflate.py:329,:714), so LEN is taken mod 2^floor(log2(obsize)); obsize == 0: RFC behaviour.
     const uint32_t obsize = a.obsize ? a.obsize : 32768u;
@@ -166,12 +166,13 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
             const uint32_t deb = (de >> 16) & 15u;
             const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> 5) & ((1u << deb) - 1u));
             const uint32_t mbits = nb + leb + 5u + deb;
-            const uint32_t bp0 = HDLZ_BITPOS();
-            const bool sym_ok = (int32_t)((bp0 + nb) >> 3) <= isize - 3;                 // deflate.py:1535-1539
-            const bool lit_ok = (type == (uint32_t)T_LIT) & sym_ok & (o < cap);
-            const bool len_ok = (type == (uint32_t)T_LEN) & sym_ok & (de != 0xFFFFFFFFu) & (distance <= o) &
-                                (distance <= obsize) & ((int32_t)((bp0 + mbits) >> 3) < isize - 2) &
-                                ((uint64_t)o + tlength <= (uint64_t)cap);
+            // input guard: after the refill bc >= 33, so every bit position touched by this token is below
+            // byte ip; with ip + 3 <= zn both reference checks (deflate.py:1535-1539 after the symbol, :1600
+            // before the copy) are guaranteed to pass -- anything closer to the end goes to the slow path
+            const bool in_ok = ip + 3u <= zn;
+            const bool lit_ok = (type == (uint32_t)T_LIT) & in_ok & (o < cap);
+            const bool len_ok = (type == (uint32_t)T_LEN) & in_ok & (de != 0xFFFFFFFFu) & (distance <= o) &
+                                (distance <= obsize) & (o + tlength <= cap);
             if (!slow && (lit_ok | len_ok)) {
                 const uint32_t used = lit_ok ? nb : mbits;
                 bb >>= used; bc -= used;
@@ -260,23 +261,10 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
 
         // ------------------------------------------------------------ 2. one output byte per active lane
         bool wrote = false;        // this lane put a byte into the ring in this iteration
-        if (active) {
-            uint32_t byte = lit;
-            bool stored_done = false;
-            if (rem != 0u) {                                       // COPY (deflate.py:1627-1659)
-                const uint32_t rb = ring8[ring_addr(o - dist, lane)];     // LDS history (valid for dist <= 256)
-                if (dist > RING_BYTES) {                           // far history: the stream's own flushed output
-                    if (fbn == 0u) {          // take the prefetched 8 bytes, request the following 8 (all already flushed: dist > 78)
-                        fb = fpre; fbn = 8u;
-                        if (rem > 8u) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - dist) + 8u);
-                    }
-                    byte = (uint32_t)fb & 0xFFu;
-                    fb >>= 8; fbn--;
-                } else {
-                    byte = rb;
-                }
-                rem--;
-            } else if (srem != 0u) {                               // stored COPY (deflate.py:1603-1616)
+        uint32_t byte = lit;
+        bool stored_done = false;
+        if (__ballot(active && srem != 0u) != 0ull) {              // stored COPY (deflate.py:1603-1616): rare, uniform branch
+            if (active && srem != 0u) {
                 HDLZ_REFILL();
                 if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize) { HDLZ_FAIL(HDLZ_E_NO_EOF); }
                 else if (o >= cap) { HDLZ_FAIL(HDLZ_E_OUT_CAPACITY); }
@@ -285,8 +273,26 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
                 srem--;
                 stored_done = (srem == 0u);
             }
-            if (active) { ring8[ring_addr(o, lane)] = (uint8_t)byte; wrote = true; }
-            if (active && stored_done) {                           // a stored block just ended (deflate.py:1617-1626)
+        }
+        if (active) {
+            if (rem != 0u) {                                       // COPY (deflate.py:1627-1659)
+                const uint32_t rb = ring8[ring_addr(o - dist, lane)];     // LDS history (valid for dist <= RING_BYTES)
+                byte = rb;
+                if (dist > RING_BYTES) {                           // far history: the stream's own flushed output
+                    if (fbn == 0u) {          // take the prefetched 8 bytes, request the following 8 (all already flushed: dist > 78)
+                        fb = fpre; fbn = 8u;
+                        if (rem > 8u) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - dist) + 8u);
+                    }
+                    byte = (uint32_t)fb & 0xFFu;
+                    fb >>= 8; fbn--;
+                }
+                rem--;
+            }
+            ring8[ring_addr(o, lane)] = (uint8_t)byte;
+            wrote = true;
+        }
+        if (__ballot(stored_done) != 0ull) {                       // a stored block just ended (deflate.py:1617-1626)
+            if (active && stored_done) {
                 if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize) { HDLZ_FAIL(HDLZ_E_NO_EOF); }
                 else if (final_) { out_len = o + 1u; active = false; }
                 else need_header = true;
