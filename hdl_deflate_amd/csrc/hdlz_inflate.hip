@@ -11,7 +11,7 @@
 //   * the output offset `o` is wave-uniform, so output is staged in a lane-interleaved LDS ring
 //     (dword w of lane l at dword index w*64 + l: every access of the wave hits 64 different banks
 //     whatever the per-lane history offset is) and flushed as 64 full 64-byte lines per 64 iterations
-//   * LZ copies with distance <= 128 read the ring (ds_read_u8); longer distances (up to OBSIZE)
+//   * LZ copies with distance <= 64 read the ring (ds_read_u8); longer distances (up to OBSIZE)
 //     read the stream's own, already flushed, output in HBM/L2
 //   * the decode path and the copy path are both short, so divergence between "lane decodes a
 //     symbol" and "lane continues a copy" costs the sum of two short paths, not a loop of one.
@@ -24,12 +24,15 @@
 
 namespace hdlz {
 
-constexpr uint32_t RING_BYTES = 128;          // history kept in LDS per stream (8 KiB per wave -> ~15 waves per CU)
+constexpr uint32_t RING_BYTES = 64;           // history kept in LDS per stream = one flush chunk (4 KiB per wave).
+                                              // Occupancy is what matters here: measured 110 / 150 / 202 GB/s for 256 / 128 / 64
 constexpr uint32_t RING_DW = RING_BYTES / 4;  // dwords per lane
 constexpr uint32_t CHUNK = 64;                // bytes per stream per flush
+constexpr uint32_t FAR_BUF_MIN = 79;          // 8-byte far prefetch needs src+15 < flushed end: distance > 78
+constexpr uint32_t WAVES = 4;                 // independent waves per workgroup, sharing the decode tables
 
 struct __attribute__((aligned(16))) InflateLds {
-    uint32_t ring[RING_DW * 64];   // [dword][lane]
+    uint32_t ring[WAVES][RING_DW * 64];   // per wave: [dword][lane]
     uint32_t lit[512];             // literal/length table, see lit_entry()
     uint32_t dst[32];              // distance table indexed by the RAW 5 stream bits
 };
@@ -92,14 +95,15 @@ __device__ __forceinline__ uint32_t ring_addr(uint32_t pos, uint32_t lane) {
     return ((b >> 2) << 8) | (lane << 2) | (b & 3u);     // byte address inside InflateLds::ring
 }
 
-__global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
+__global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
     __shared__ InflateLds lds;
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t c = lane; c < 512u; c += 64u) lds.lit[c] = lit_entry(c);
-    if (lane < 32u) lds.dst[lane] = dst_entry(lane);
-    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t c = threadIdx.x; c < 512u; c += 64u * WAVES) lds.lit[c] = lit_entry(c);
+    if (threadIdx.x < 32u) lds.dst[threadIdx.x] = dst_entry(threadIdx.x);
+    __syncthreads();                 // the only workgroup barrier: the waves are independent from here on
 
-    const uint64_t sid0 = (uint64_t)blockIdx.x * 64u;
+    const uint64_t sid0 = ((uint64_t)blockIdx.x * WAVES + wave) * 64u;
     const uint64_t sid = sid0 + lane;
     const bool exists = sid < a.nstreams;
     uint64_t off = 0;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
     }
     const uint8_t* __restrict__ z = a.in + off;
     uint8_t* __restrict__ out = a.out + sid * a.out_pitch;
-    uint8_t* ring8 = reinterpret_cast<uint8_t*>(lds.ring);
+    uint8_t* ring8 = reinterpret_cast<uint8_t*>(lds.ring[wave]);
     const uint32_t cap = a.out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00u : (uint32_t)a.out_pitch;   // o + 258 never wraps
     // obsize != 0: reference-exact OBSIZE build -- the stored LEN register is LOBSIZE bits wide
     // (deflate.py:329,:714), so LEN is taken mod 2^floor(log2(obsize)); obsize == 0: RFC behaviour.
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
                 if (lit_ok) { lit = (e >> 4) & 0xFFu; have = true; }
                 else {
                     rem = tlength; dist = distance; fbn = 0;
-                    if (distance > RING_BYTES) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
+                    if (distance >= FAR_BUF_MIN) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
                 }
             } else {
                 slow = true;                                        // EOB, header, invalid data, any failing check
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
                 rem = tlength;
                 dist = distance;
                 fbn = 0;
-                if (distance > RING_BYTES) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
+                if (distance >= FAR_BUF_MIN) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
             }
         }
         if (__ballot(active) == 0ull) break;
@@ -278,13 +282,15 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
             if (rem != 0u) {                                       // COPY (deflate.py:1627-1659)
                 const uint32_t rb = ring8[ring_addr(o - dist, lane)];     // LDS history (valid for dist <= RING_BYTES)
                 byte = rb;
-                if (dist > RING_BYTES) {                           // far history: the stream's own flushed output
-                    if (fbn == 0u) {          // take the prefetched 8 bytes, request the following 8 (all already flushed: dist > 78)
+                if (dist >= FAR_BUF_MIN) {                         // far history: the stream's own flushed output
+                    if (fbn == 0u) {          // take the prefetched 8 bytes, request the following 8 (all already flushed)
                         fb = fpre; fbn = 8u;
                         if (rem > 8u) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - dist) + 8u);
                     }
                     byte = (uint32_t)fb & 0xFFu;
                     fb >>= 8; fbn--;
+                } else if (dist > RING_BYTES) {                    // 65..78: flushed, but too close for the 8-byte prefetch
+                    byte = out[o - dist];
                 }
                 rem--;
             }
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
             for (uint32_t r = 0; r < 4u; r++) {
                 const uint32_t s = (lane >> 2) + 16u * r;               // stream (lane index) this lane copies for
                 if ((live >> s) & 1ull) {
-                    const uint32_t* src = &lds.ring[(w0 + 4u * q) * 64u + s];
+                    const uint32_t* src = &lds.ring[wave][(w0 + 4u * q) * 64u + s];
                     uint4 v;
                     v.x = src[0]; v.y = src[64]; v.z = src[128]; v.w = src[192];
                     uint8_t* dst = a.out + (sid0 + s) * a.out_pitch + c0 + 16u * q;
@@ -343,7 +349,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a) {
 
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t stream) {
     if (a.nstreams == 0) return hipSuccess;
-    const dim3 grid((unsigned)((a.nstreams + 63u) / 64u)), block(64);
+    const uint64_t per_wg = 64u * WAVES;
+    const dim3 grid((unsigned)((a.nstreams + per_wg - 1u) / per_wg)), block(64 * WAVES);
     hipLaunchKernelGGL(k_inflate, grid, block, 0, stream, a);
     return hipGetLastError();
 }
