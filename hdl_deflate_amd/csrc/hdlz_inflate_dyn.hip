@@ -24,15 +24,23 @@ namespace hdlz {
 
 constexpr uint32_t DRING = 4096;     // history ring bytes (power of two)
 constexpr uint32_t DCHUNK = 64;
+constexpr uint32_t IWIN = 2048;      // compressed-input window staged in LDS (bytes)
+constexpr uint32_t LBITS = 10;       // instant-table index bits (the reference uses 10 too: InstantMaxBit, deflate.py:256)
+constexpr uint32_t DBITS = 9;
 
 struct __attribute__((aligned(16))) DynLds {
     uint8_t ring[DRING];
+    uint32_t iwin[IWIN / 4];         // input window: stream bytes [iwbase, iwbase + IWIN)
     uint8_t lengths[320];
     uint16_t lsym[288];
     uint16_t dsym[32];
     uint16_t csym[20];
     uint16_t cnt[3][16];             // code counts per length: [0] code-length code, [1] lit/len, [2] distance
     int32_t left[3];
+    uint32_t cnt32[16];              // scratch of canon_build
+    uint32_t next[16];
+    uint16_t llut[1 << LBITS];       // instant tables: (symbol << 4) | code length, 0 = longer code / no code
+    uint16_t dlut[1 << DBITS];
 };
 
 typedef uint32_t __attribute__((aligned(1))) u32u;
@@ -55,24 +63,51 @@ __device__ __forceinline__ void d_dist_info(uint32_t dc, uint32_t& base, uint32_
     else { eb = (dc >> 1) - 1u; base = 1u + ((2u + (dc & 1u)) << eb); }
 }
 
-// canonical code construction by lane 0 (serial, n <= 288): counts, then symbols ordered by (length, value)
-__device__ void canon_build(DynLds& L, int which, const uint8_t* len, uint16_t* symbol, int n) {
-    uint16_t* count = L.cnt[which];
-    uint16_t offs[16];
-    for (int l = 0; l < 16; l++) count[l] = 0;
-    for (int s = 0; s < n; s++) count[len[s]]++;
-    int left = 1;
-    for (int l = 1; l < 16; l++) {
-        left <<= 1;
-        left -= count[l];
-        if (left < 0) break;
+// canonical code construction, wave-parallel (all 64 lanes call it; n <= 320):
+//   counts by LDS atomics, offsets by a 15-step serial prefix, symbol placement ordered by (length, value)
+//   through one ballot per code length and round: rank = bits of the ballot below this lane (v_mbcnt).
+// (A single-lane version is a chain of ~600 dependent LDS round trips per block and dominated the kernel.)
+__device__ void canon_build(DynLds& L, int which, const uint8_t* len, uint16_t* symbol, int n, uint32_t lane) {
+    uint32_t* cnt32 = L.cnt32;
+    uint32_t* nxt = L.next;
+    __syncthreads();
+    if (lane < 16u) cnt32[lane] = 0;
+    __syncthreads();
+    for (int s = (int)lane; s < n; s += 64) atomicAdd(&cnt32[len[s]], 1u);
+    __syncthreads();
+    if (lane == 0) {
+        int left = 1;
+        uint32_t o = 0;
+        for (int l = 1; l < 16; l++) {
+            const uint32_t c = cnt32[l];
+            nxt[l] = o;
+            o += c;
+            left = (left << 1) - (int)c;
+            if (left < 0) break;
+        }
+        nxt[0] = 0;
+        L.left[which] = left;
     }
-    L.left[which] = left;
-    if (left < 0) return;
-    offs[1] = 0;
-    for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
-    for (int s = 0; s < n; s++)
-        if (len[s]) symbol[offs[len[s]]++] = (uint16_t)s;
+    if (lane < 16u) L.cnt[which][lane] = (uint16_t)cnt32[lane];
+    __syncthreads();
+    if (L.left[which] < 0) return;
+    for (int r = 0; r < n; r += 64) {
+        const int s = r + (int)lane;
+        const uint32_t mylen = s < n ? len[s] : 0u;
+        uint32_t rank = 0, addv = 0;
+#pragma unroll
+        for (uint32_t l = 1; l < 16u; l++) {
+            const bool is = mylen == l;
+            const uint64_t m = __ballot(is);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            rank = is ? below : rank;
+            addv = lane == l ? (uint32_t)__popcll(m) : addv;
+        }
+        if (mylen != 0u) symbol[nxt[mylen] + rank] = (uint16_t)s;
+        __syncthreads();
+        if (lane < 16u) nxt[lane] += addv;
+        __syncthreads();
+    }
 }
 
 struct CodeRegs { uint32_t c[16]; };   // counts of one code in registers (wave-uniform)
@@ -101,6 +136,22 @@ __device__ __forceinline__ int canon_decode(const CodeRegs& r, const uint16_t* s
     return -1;
 }
 
+// instant table: every lane canonical-decodes the bit patterns lane, lane+64, ... once per block
+__device__ __forceinline__ void build_lut(const CodeRegs& r, const uint16_t* symbol, uint16_t* lut, uint32_t bits, uint32_t lane) {
+    for (uint32_t e = lane; e < (1u << bits); e += 64u) {
+        uint32_t used;
+        const int sym = canon_decode(r, symbol, e, used);     // bits above `bits` are zero: only codes <= bits long count
+        lut[e] = (sym >= 0 && used <= bits) ? (uint16_t)(((uint32_t)sym << 4) | used) : (uint16_t)0;
+    }
+}
+// table first, canonical walk for the rare longer codes
+__device__ __forceinline__ int fast_decode(const CodeRegs& r, const uint16_t* symbol, const uint16_t* lut, uint32_t bits,
+                                           uint32_t peek, uint32_t& used) {
+    const uint32_t e = lut[peek & ((1u << bits) - 1u)];
+    if (e != 0u) { used = e & 15u; return (int)(e >> 4); }
+    return canon_decode(r, symbol, peek, used);
+}
+
 __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
     __shared__ DynLds L;
     const uint32_t lane = threadIdx.x;
@@ -126,7 +177,20 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
         uint32_t o = 0;                     // bytes produced
         uint64_t bb = 0;
         uint32_t bc = 0, ip = 2;            // D0: zlib header skipped unvalidated
-#define REFILL() do { if (bc <= 32u) { bb |= (uint64_t)dload32(z, ip, zn) << bc; bc += 32u; ip += 4u; } } while (0)
+        // a serial decoder must not pay a global-load latency per 4 input bytes: the compressed stream is
+        // staged through an LDS window, filled cooperatively (coalesced) whenever the reader runs off its end
+        uint32_t iwbase = ip - IWIN;        // forces a fill at the first refill
+#define REFILL() do {                                                                                   \
+        if (bc <= 32u) {                                                                                 \
+            if (ip - iwbase >= IWIN) {                                                                   \
+                __syncthreads();                                                                         \
+                iwbase = ip;                                                                             \
+                for (uint32_t k = lane; k < IWIN / 4u; k += 64u) L.iwin[k] = dload32(z, iwbase + 4u * k, zn); \
+                __syncthreads();                                                                         \
+            }                                                                                            \
+            bb |= (uint64_t)L.iwin[(ip - iwbase) >> 2] << bc; bc += 32u; ip += 4u;                       \
+        }                                                                                                \
+    } while (0)
 #define BITPOS() (8u * ip - bc)
 #define TAKE(n) do { bb >>= (n); bc -= (n); } while (0)
 #define FAIL(code) do { status = (code); goto done; } while (0)
@@ -173,6 +237,7 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                 o += length;
                 if ((int32_t)(p0 + length) >= isize) FAIL(HDLZ_E_NO_EOF);      // deflate.py:1617-1626 with the COPY hold
                 ip = p0 + length; bb = 0; bc = 0;                              // resynchronise the bit reader
+                iwbase = ip - IWIN;                                            // ... and refill the window there
                 if (final_) break;
                 continue;
             }
@@ -182,10 +247,8 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                 for (uint32_t s = lane; s < 288u; s += 64u) L.lengths[s] = (uint8_t)(s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8);
                 if (lane < 32u) L.lengths[288u + lane] = 5;
                 __syncthreads();
-                if (lane == 0) {
-                    canon_build(L, 1, L.lengths, L.lsym, 288);
-                    canon_build(L, 2, L.lengths + 288, L.dsym, 32);
-                }
+                canon_build(L, 1, L.lengths, L.lsym, 288, lane);
+                canon_build(L, 2, L.lengths + 288, L.dsym, 32, lane);
                 __syncthreads();
             } else {
                 // BL (deflate.py:1090-1114)
@@ -204,7 +267,7 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                     TAKE(3u);
                 }
                 __syncthreads();
-                if (lane == 0) canon_build(L, 0, L.lengths, L.csym, 19);
+                canon_build(L, 0, L.lengths, L.csym, 19, lane);
                 __syncthreads();
                 if (L.left[0] != 0) FAIL(HDLZ_E_BAD_TREE);
                 CodeRegs cl;
@@ -246,10 +309,8 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                 }
                 __syncthreads();
                 if (L.lengths[256] == 0) FAIL(HDLZ_E_BAD_TREE);          // no end-of-block code
-                if (lane == 0) {
-                    canon_build(L, 1, L.lengths, L.lsym, (int)nlen);
-                    canon_build(L, 2, L.lengths + nlen, L.dsym, (int)ndist);
-                }
+                canon_build(L, 1, L.lengths, L.lsym, (int)nlen, lane);
+                canon_build(L, 2, L.lengths + nlen, L.dsym, (int)ndist, lane);
                 __syncthreads();
                 {
                     const int l1 = L.left[1], l2 = L.left[2];
@@ -262,11 +323,14 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                 CodeRegs lc, dc_;
                 load_counts(lc, L.cnt[1]);
                 load_counts(dc_, L.cnt[2]);
+                build_lut(lc, L.lsym, L.llut, LBITS, lane);
+                build_lut(dc_, L.dsym, L.dlut, DBITS, lane);
+                __syncthreads();
                 // NEXT / INFLATE / D_NEXT / COPY
                 for (;;) {
                     REFILL();
                     uint32_t used;
-                    const int sym = canon_decode(lc, L.lsym, (uint32_t)bb & 0x7FFFu, used);
+                    const int sym = fast_decode(lc, L.lsym, L.llut, LBITS, (uint32_t)bb & 0x7FFFu, used);
                     if (sym < 0) FAIL(HDLZ_E_BAD_SYMBOL);
                     if (hm == 1u && sym == 287) FAIL(HDLZ_E_BAD_SYMBOL);               // zero leaf, deflate.py:212,:1437-1439
                     TAKE(used);
@@ -286,7 +350,7 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                     const uint32_t tlength = lbase + ((uint32_t)bb & ((1u << leb) - 1u));
                     TAKE(leb);
                     REFILL();
-                    const int ds = canon_decode(dc_, L.dsym, (uint32_t)bb & 0x7FFFu, used);
+                    const int ds = fast_decode(dc_, L.dsym, L.dlut, DBITS, (uint32_t)bb & 0x7FFFu, used);
                     if (ds < 0) FAIL(HDLZ_E_BAD_SYMBOL);
                     TAKE(used);
                     if (ds >= 30) FAIL(HDLZ_E_BAD_DISTANCE);
