@@ -1,34 +1,15 @@
-// hdlz_compress.hip -- STARTC for a batch of independent blocks on gfx950 (CDNA4, wave64).
+// hdlz_compress_small.hip -- STARTC for batches of SMALL uniform blocks (32 <= N <= 1024, CWINDOW <= 32).
 //
-// Replaces the reference's compress FSM (/root/reference/deflate.py:734-1082 + :407-515 +
-// :535-567) with a data-parallel formulation.  Rule names R0..R9 are SURVEY.md 8(a)'s.
-//
-// Mapping: persistent single-wave workgroups; a wave takes blocks blockIdx.x, +gridDim.x, ... and
-// walks each block in tiles of 2048 positions; lane l owns the RUN of 32 consecutive positions
-// [32l, 32l+32) of the tile.  Per tile:
-//   1. tile + 256-byte look-back halo + 16-byte look-ahead staged in LDS (coalesced 16-B loads)
-//   2. match search (R3/R4): each lane builds keys K = (3-byte-string << 8) | 4*window_index for
-//      its own 32 positions and the 32..256 positions before them, all in VGPRs.  For an own key
-//      Ko and a candidate key Kc,  Ko - Kc  equals 4*distance (<= 128) iff the three bytes are
-//      equal and is > 256 (as u32) otherwise, so the MIN over the 32 candidates IS four times the
-//      nearest matching distance: one v_sub + half a v_min3 per compare, no branches.
-//   3. extension (R5): 8-byte LDS gather at p-d+3, xor with the own bytes, count-trailing-zeros.
-//   4. greedy parse ("di += m / di += 1", deflate.py:960,1008): every lane folds its run into a
-//      transfer function "entry skip (0..9) -> exit skip", 10 nibbles packed in 40 bits, by a
-//      backward pass; a 64-step scalar readlane chain composes them across the wave.
-//   5. token bits (R6/R7) from per-wave LDS look-up tables (literal: [byte] -> code|nbits, match:
-//      [len][dist] -> code|nbits), in-lane prefix sums + wave scan -> bit offsets, then every
-//      token is OR-ed into an LDS bit buffer at its own bit offset (ds_or_b32), coalesced dword
-//      flush to HBM; the partial word is carried to the next tile.
-//   6. Adler-32 (R8) by per-lane byte sums / index-weighted sums (v_sad_u8 / v_dot4_u32_u8).
-// Positions >= N in the last tile are zero bytes: they can never match (R3) and each of them is
-// parsed as one 8-bit literal; their bits land behind the real end of the stream and are wiped
-// once before the trailer is written -- so the hot loop carries no per-position validity mask.
-//
-// Cost model (measured, tools/ubench): v_add/sub/and/or/xor/lshr ~2.5 cycles per wave64
-// instruction, every other VALU op (min3, cmp, cndmask, alignbyte, lshl, 64-bit shifts, ...) ~4.2.
-// The kernel is VALU-issue bound, so the design minimises VALU instructions and moves
-// table work to LDS.  No MFMA: nothing here is a dense contraction.
+// The general kernel (hdlz_compress.hip) gives every block a whole 2048-position wave-tile, so a 256-byte
+// block keeps 8 of 64 lanes busy (38 GB/s measured).  Sub-KiB inputs are the reference's own scale
+// (IBSIZE = 512 in the FAST build, deflate.py:64-68; the test bench compresses ~500 bytes,
+// test_deflate.py:329), so this variant PACKS G = floor(64 / ceil(N/32)) blocks into one wave-tile:
+// lane l works on run r = l mod Rb of block g = l div Rb.  Match search, extension, parse and token lookup
+// are the general kernel's code, unchanged -- positions are simply block-relative (a block's first run has
+// no history: d <= p), and the parse needs no reset because no token ever crosses a block end (the last two
+// bytes of a block are always literals, R5).  What is per block here: bit offsets (segmented scan), the
+// LDS bit-buffer region, Adler-32, trailer, length and the flush.  Output is bit-identical to the general
+// kernel (and to the reference); the host picks this path only for fixed-pitch, 16-byte aligned batches.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
@@ -36,98 +17,70 @@
 
 namespace hdlz {
 
-template <int NCH>   // NCH = ceil(cwindow / 32): 1, 2 or 8 chunks of 32 candidate distances
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_compress(CompressArgs a) {
-    __shared__ WaveLds lds;
-    const uint32_t lane = threadIdx.x;
+constexpr int SMALL_OUT_WORDS = 704;          // G * ceil(out_bound(N)/4) is largest for N = 32: 64 * 11
 
-    // ---- per-wave look-up tables (once per wave lifetime)
+struct __attribute__((aligned(16))) SmallLds {
+    uint32_t in[IN_BYTES / 4];
+    uint32_t out[SMALL_OUT_WORDS];
+    uint32_t lut[LUT_LIT + LUT_MATCH];
+    uint32_t ad[2][64];                       // per-lane Adler partials, summed per block by its first lane
+};
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_compress_small(CompressArgs a) {
+    constexpr int NCH = 1;
+    __shared__ SmallLds lds;
+    const uint32_t lane = threadIdx.x;
     for (uint32_t e = lane; e < (uint32_t)LUT_LIT; e += 64) lds.lut[e] = literal_entry(e);
-    for (uint32_t e = lane; e < (uint32_t)LUT_MATCH; e += 64) {
-        if (NCH == 1) lds.lut[LUT_LIT + e] = dist_entry((e & 31u) + 1u) | length_code((e >> 5) + 3u);
-        else lds.lut[LUT_LIT + e] = dist_entry(e + 1u);
-    }
+    for (uint32_t e = lane; e < (uint32_t)LUT_MATCH; e += 64)
+        lds.lut[LUT_LIT + e] = dist_entry((e & 31u) + 1u) | length_code((e >> 5) + 3u);
     __syncthreads();
 
     const uint32_t cw4 = 4u * (uint32_t)a.cwindow;
     const uint32_t kmax = (uint32_t)a.maxmatch;
+    const uint32_t n = a.in_len;                                  // uniform block length
+    const uint32_t Rb = (n + 31u) >> 5;                           // runs (lanes) per block
+    const uint32_t G = 64u / Rb;                                  // blocks per wave-tile
+    const uint32_t Wb = (out_bound(n) + 3u) >> 2;                 // bit-buffer words per block
+    const uint32_t g = lane / Rb, r = lane - g * Rb;              // this lane: run r of block g
+    const uint32_t p_run = r * RUN;                               // block-relative position of the run
     uint8_t* lin8 = reinterpret_cast<uint8_t*>(lds.in);
     const uint8_t* lut8 = reinterpret_cast<const uint8_t*>(lds.lut);
     uint8_t* out8 = reinterpret_cast<uint8_t*>(lds.out);
+    const uint64_t ngroups = (a.nblocks + G - 1u) / G;
 
-    for (uint64_t blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
-        uint64_t off;
-        uint32_t n;
-        if (a.in_off) {
-            off = a.in_off[blk];
-            n = (uint32_t)(a.in_off[blk + 1] - off);
-        } else {
-            off = blk * a.in_pitch;
-            n = a.in_len;
-        }
-        const uint8_t* __restrict__ src = a.in + off;
-        uint32_t* __restrict__ outw = reinterpret_cast<uint32_t*>(a.out + blk * a.out_pitch);
-
-        if (n < 5u) {                               // R0: the reference never starts
-            if (lane == 0) { a.out_len[blk] = 0; a.status[blk] = HDLZ_E_SHORT_INPUT; }
-            continue;
-        }
-        if ((uint64_t)out_bound(n) > a.out_pitch) {
-            if (lane == 0) { a.out_len[blk] = 0; a.status[blk] = HDLZ_E_OUT_CAPACITY; }
-            continue;
-        }
-        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
-        const bool aligned16 = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
-
-        uint32_t gw = 0;            // output words already flushed to HBM
-        uint32_t base_bits = 19;    // R1: 78 9C + bits 1,1,0
-        uint32_t carry_word = 0x78u | (0x9Cu << 8) | (0x3u << 16);
-        uint32_t skip_in = 0;       // positions at the tile start covered by the previous tile's last match
-        uint32_t ad_a = 0, ad_w = 0;   // per-lane Adler partials (sum x, sum (N-p) x mod 65521)
-
-        for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
-            // -------------------------------------------------------------- 1. stage the tile
-            uint32_t keep = 0;
-            if (t0 != 0) keep = lds.in[(TILE / 4) + lane];      // last HALO bytes of the previous tile
-            __syncthreads();                                     // (also orders the previous flush reads)
-            lds.in[lane] = keep;                                 // tile 0: zero halo (never matched: d <= p)
-            {
-                const uint32_t nchunk = (TILE + LOOKAHEAD) / 16;     // 129 16-byte chunks
-                for (uint32_t c = lane; c < nchunk; c += 64) {
-                    const uint32_t p = t0 + c * 16u;                 // first position of the chunk
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (p < n) {
-                        if (aligned16) {
-                            v = *reinterpret_cast<const uint4*>(src + p);
-                        } else {
-                            // realign with aligned dword loads + v_alignbyte
-                            const uint32_t* q = reinterpret_cast<const uint32_t*>(src + p - mis);
-                            const uint32_t nd = (n - p + mis + 3u) >> 2;      // dwords that hold valid bytes
-                            uint32_t d0 = q[0];
-                            uint32_t d1 = nd > 1 ? q[1] : 0, d2 = nd > 2 ? q[2] : 0, d3 = nd > 3 ? q[3] : 0,
-                                     d4 = nd > 4 ? q[4] : 0;
-                            v.x = alignbyte(d1, d0, mis);
-                            v.y = alignbyte(d2, d1, mis);
-                            v.z = alignbyte(d3, d2, mis);
-                            v.w = alignbyte(d4, d3, mis);
-                        }
-                        const uint32_t valid = n - p;                // bytes of this chunk inside the block
-                        if (valid < 16u) {                           // positions >= N must read as zero bytes
-                            uint32_t* vv = reinterpret_cast<uint32_t*>(&v);
+    for (uint64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const uint64_t blk = grp * G + g;
+        const bool lane_ok = (g < G) && (blk < a.nblocks);
+        const uint32_t nrem = lane_ok ? n - min(p_run, n) : 0u;   // positions of the block from this run on
+        const uint32_t nrem_m2 = nrem - 2u;
+        // -------------------------------------------------------------- 1. stage: every lane loads its own run
+        __syncthreads();
+        {
+            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+            if (nrem != 0u) {
+                const uint8_t* src = a.in + blk * a.in_pitch + p_run;
+                v0 = *reinterpret_cast<const uint4*>(src);                    // in_pitch % 16 == 0: whole 16-B pieces are readable
+                if (nrem > 16u) v1 = *reinterpret_cast<const uint4*>(src + 16);
+                // bytes at or beyond N must read as zero
+                uint32_t* vv = reinterpret_cast<uint32_t*>(&v0);
+                uint32_t* ww = reinterpret_cast<uint32_t*>(&v1);
 #pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const uint32_t lo = 4u * k;
-                                uint32_t m = valid <= lo ? 0u : (valid >= lo + 4u ? 0xFFFFFFFFu : ((1u << (8u * (valid - lo))) - 1u));
-                                vv[k] &= m;
-                            }
-                        }
-                    }
-                    *reinterpret_cast<uint4*>(lin8 + HALO + c * 16u) = v;
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t lo = 4u * k;
+                    vv[k] &= nrem <= lo ? 0u : (nrem >= lo + 4u ? 0xFFFFFFFFu : ((1u << (8u * (nrem - lo))) - 1u));
+                    const uint32_t hi = 16u + lo;
+                    ww[k] &= nrem <= hi ? 0u : (nrem >= hi + 4u ? 0xFFFFFFFFu : ((1u << (8u * (nrem - hi))) - 1u));
                 }
             }
-            // zero the bit buffer, seed the carry
-            for (uint32_t w = lane; w < OUT_WORDS; w += 64) lds.out[w] = (w == 0) ? carry_word : 0u;
-            __syncthreads();
+            *reinterpret_cast<uint4*>(lin8 + HALO + lane * RUN) = v0;
+            *reinterpret_cast<uint4*>(lin8 + HALO + lane * RUN + 16) = v1;
+            lds.in[lane] = 0;                                                  // halo in front of lane 0
+            if (lane < LOOKAHEAD / 4) lds.in[(HALO + TILE) / 4 + lane] = 0;    // look-ahead behind lane 63
+        }
+        for (uint32_t w = lane; w < (uint32_t)SMALL_OUT_WORDS; w += 64) lds.out[w] = 0u;
+        __syncthreads();
+        if (lane_ok && r == 0u) lds.out[g * Wb] = 0x78u | (0x9Cu << 8) | (0x3u << 16);   // R1 per block
+        __syncthreads();
 
             // -------------------------------------------------------------- 2. match search
             const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);   // dword index of the run in lds.in
@@ -208,11 +161,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             // afterwards tok[i] = (len-1) << 16 | LUT byte offset of the token  (len-1 = 0 for a literal)
             pin(best); pin(ow);
             PHASE_FENCE();
-            const uint32_t p_run = t0 + lane * RUN;                   // first position of this run
-            const uint32_t lds_run = HALO + lane * RUN;               // its byte offset in lds.in
-            const uint32_t nrem = n - min(p_run, n);                  // positions of the block from p_run on
-            const uint32_t nrem_m2 = nrem - 2u;                       // (wraps when nrem < 2: then nothing is eligible)
-            const uint32_t p4_run = 4u * min(p_run, 1024u);           // 4*p saturated: only p < CWINDOW <= 256 matters
+            const uint32_t lds_run = HALO + lane * RUN;               // byte offset of this run in lds.in
+            const uint32_t p4_run = 4u * p_run;                       // block-relative: a block's first run has no history
             uint32_t tok[RUN];
             static_for<0, RUN>([&](auto I) {
                 constexpr int i = decltype(I)::value;
@@ -268,7 +218,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             uint32_t myskip;
             {
                 const uint32_t plo = (uint32_t)P, phi = (uint32_t)(P >> 32);
-                uint32_t s = skip_in;
+                uint32_t s = 0;                      // no token ever crosses a block end (R5), so skips reset by themselves
                 uint64_t sv[4] = {0, 0, 0, 0};     // entry skips of all 64 lanes, one nibble each (scalar regs)
                 // 4 segments of 16 lanes; the scheduling barriers keep the compiler from hoisting all 128
                 // readlanes to the top (that needed ~260 SGPR spills = v_writelane/v_readlane traffic)
@@ -286,7 +236,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     sv[g] = acc;
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                skip_in = s;
+                (void)s;
                 const uint32_t g = lane >> 4;
                 const uint64_t mine = g == 0 ? sv[0] : g == 1 ? sv[1] : g == 2 ? sv[2] : sv[3];
                 myskip = (uint32_t)(mine >> (4u * (lane & 15u))) & 15u;
@@ -299,11 +249,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             uint32_t code[RUN];
             uint32_t lane_bits = 0;
             {
-                uint32_t c = myskip;
+                uint32_t c = lane_ok ? myskip : 0xFFFFu;        // lanes without a block never start a token
                 static_for<0, RUN>([&](auto I) {
                     constexpr int i = decltype(I)::value;
                     const uint32_t e = *reinterpret_cast<const uint32_t*>(lut8 + (tok[i] & 0xFFFFu));
-                    const bool start = (c == 0u);
+                    const bool start = (c == 0u) & ((uint32_t)i < nrem);   // padding positions of a block emit nothing
                     const uint32_t lenm1 = tok[i] >> 16;
                     c = start ? lenm1 : (c - 1u);
                     uint32_t ee = e;
@@ -316,19 +266,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             }
             pin(code);
             PHASE_FENCE();
-            // wave exclusive scan of lane_bits
+            // wave scan of lane_bits; bit offsets are per block (segmented by the block's first lane)
             uint32_t incl = lane_bits;
 #pragma unroll
             for (int ofs = 1; ofs < 64; ofs <<= 1) {
                 const uint32_t o = __shfl_up(incl, ofs, 64);
                 if (lane >= (uint32_t)ofs) incl += o;
             }
-            const uint32_t tile_bits_all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t first_lane = g * Rb;
+            // (shuffles must be executed by ALL lanes: a source lane that skipped it reads as garbage)
+            const uint32_t prev_incl = (uint32_t)__shfl((int)incl, (int)((first_lane - 1u) & 63u), 64);
+            const uint32_t before_blk = first_lane == 0u ? 0u : prev_incl;
             pin(code); asm volatile("" : "+v"(incl), "+v"(lane_bits));
             PHASE_FENCE();
-            // pass B: OR every token into the LDS bit buffer at its own bit offset
+            // pass B: OR every token into the block's region of the LDS bit buffer
             {
-                uint32_t bp = base_bits + incl - lane_bits;
+                uint32_t bp = 32u * g * Wb + 19u + (incl - lane_bits - before_blk);
+                if (!lane_ok) bp = 0;                             // (emits nothing: all codes are zero)
 #pragma unroll
                 for (int i = 0; i < RUN; i++) {
                     const uint64_t v = (uint64_t)(code[i] & CODE_MASK) << (bp & 31u);
@@ -339,100 +293,59 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     if ((i & 3) == 3) { asm volatile("" : "+v"(bp)); PHASE_FENCE(); }
                 }
             }
-
             pin(ow);
             PHASE_FENCE();
-            // -------------------------------------------------------------- 6. Adler partials
+            // -------------------------------------------------------------- 6. Adler partials per lane -> LDS
             {
-                uint32_t sa = 0, sc = 0;    // sum x_i, sum i*x_i over the run
+                uint32_t sa = 0, sc = 0;
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     sa = __builtin_amdgcn_sad_u8(ow[k], 0u, sa);
                     const uint32_t wts = (uint32_t)(4 * k) | ((uint32_t)(4 * k + 1) << 8) | ((uint32_t)(4 * k + 2) << 16) | ((uint32_t)(4 * k + 3) << 24);
                     sc = __builtin_amdgcn_udot4(ow[k], wts, sc, false);
                 }
-                // sum (N - p) x_p over the run = (N - p_run) * sa - sc ; bytes at p >= N are zero
-                const uint32_t wgt = nrem % ADLER_MOD;
-                ad_a = (ad_a + sa) % ADLER_MOD;
-                ad_w = (ad_w + (wgt * sa) % ADLER_MOD + ADLER_MOD * 8u - (sc % ADLER_MOD)) % ADLER_MOD;
+                lds.ad[0][lane] = sa;                              // <= 8160
+                lds.ad[1][lane] = nrem * sa - sc;                  // sum (N - p) x_p over the run, < 2^24 for N <= 1024
             }
             __syncthreads();
-
-            // -------------------------------------------------------------- 7. flush
-            const bool last = (t0 + TILE >= n);
-            if (!last) {
-                const uint32_t end_bits = base_bits + tile_bits_all;
-                const uint32_t full = end_bits >> 5;
-                for (uint32_t w = lane; w < full; w += 64) outw[gw + w] = lds.out[w];
-                carry_word = lds.out[full];
-                gw += full;
-                base_bits = end_bits & 31u;
-            } else {
-                // every position >= N of this tile was emitted as one 8-bit literal (zero byte, never a match,
-                // and the last two real bytes are always literals so the parse lands exactly on N)
-                const uint32_t ninv = t0 + TILE - n;
-                const uint32_t end_bits = base_bits + tile_bits_all - 8u * ninv;
-                // wipe everything behind the real end: partial word masked, later words zeroed
-                {
-                    const uint32_t ew = end_bits >> 5, rb = end_bits & 31u;
-                    for (uint32_t w = ew + lane; w < OUT_WORDS; w += 64)
-                        lds.out[w] = (w == ew) ? (lds.out[w] & ((1u << rb) - 1u)) : 0u;
-                }
-                // R8: EOB = 7 zero bits, zero pad to a byte, Adler-32 big-endian (s2 then s1)
-                uint32_t s1 = ad_a, s2 = ad_w;
-#pragma unroll
-                for (int ofs = 32; ofs > 0; ofs >>= 1) {
-                    s1 += __shfl_xor(s1, ofs, 64);
-                    s2 += __shfl_xor(s2, ofs, 64);
-                }
-                s1 = (s1 + 1u) % ADLER_MOD;
-                s2 = (s2 + n % ADLER_MOD) % ADLER_MOD;
-                const uint32_t nbytes = (end_bits + 7u + 7u) >> 3;
-                __syncthreads();
-                if (lane == 0) {
-                    out8[nbytes] = (uint8_t)(s2 >> 8);
-                    out8[nbytes + 1] = (uint8_t)s2;
-                    out8[nbytes + 2] = (uint8_t)(s1 >> 8);
-                    out8[nbytes + 3] = (uint8_t)s1;
-                }
-                __syncthreads();
-                const uint32_t total = nbytes + 4u;
-                const uint32_t words = (total + 3u) >> 2;
-                for (uint32_t w = lane; w < words; w += 64) outw[gw + w] = lds.out[w];
-                if (lane == 0) {
-                    a.out_len[blk] = gw * 4u + total;     // R9
-                    a.status[blk] = HDLZ_OK;
-                }
+            // -------------------------------------------------------------- 7. per block: trailer, length, flush
+            // the block's first lane finishes its block (R8/R9)
+            const uint32_t last_lane = min(first_lane + Rb - 1u, 63u);
+            const uint32_t blk_bits = (uint32_t)__shfl((int)incl, (int)last_lane, 64) - before_blk;
+            uint32_t total = 0;
+            if (lane_ok && r == 0u) {
+                uint32_t s1 = 1u, s2 = n;
+                for (uint32_t k = 0; k < Rb; k++) { s1 += lds.ad[0][first_lane + k]; s2 += lds.ad[1][first_lane + k]; }
+                s1 %= ADLER_MOD; s2 %= ADLER_MOD;
+                const uint32_t end_bits = 19u + blk_bits;
+                const uint32_t nbytes = (end_bits + 7u + 7u) >> 3;     // EOB = 7 zero bits, then zero padding
+                uint8_t* ob = out8 + 4u * g * Wb;
+                ob[nbytes] = (uint8_t)(s2 >> 8);
+                ob[nbytes + 1] = (uint8_t)s2;
+                ob[nbytes + 2] = (uint8_t)(s1 >> 8);
+                ob[nbytes + 3] = (uint8_t)s1;
+                total = nbytes + 4u;
+                a.out_len[blk] = total;
+                a.status[blk] = HDLZ_OK;
             }
-        }
+            __syncthreads();
+            for (uint32_t gg = 0; gg < G; gg++) {                       // flush block by block, coalesced dwords
+                const uint64_t b2 = grp * G + gg;
+                if (b2 >= a.nblocks) break;
+                const uint32_t words = ((uint32_t)__builtin_amdgcn_readlane((int)total, (int)(gg * Rb)) + 3u) >> 2;
+                uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.out + b2 * a.out_pitch);
+                for (uint32_t w = lane; w < words; w += 64) dst[w] = lds.out[gg * Wb + w];
+            }
     }
 }
 
-template __global__ void k_compress<1>(CompressArgs);
-template __global__ void k_compress<2>(CompressArgs);
-template __global__ void k_compress<8>(CompressArgs);
-
-hipError_t launch_compress(const CompressArgs& a, hipStream_t stream) {
-    if (a.nblocks == 0) return hipSuccess;
-    // persistent single-wave workgroups: 64 per CU queued (16 resident at 4 waves/SIMD) so that the
-    // hardware dispatcher balances uneven blocks; each wave strides over the batch
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    // uniform small blocks (the reference's own input scale): several blocks per wave-tile
-    if (!a.in_off && a.cwindow <= 32 && a.in_len >= 5u && a.in_len <= 1024u && (a.in_pitch & 15u) == 0 &&
-        (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0 && a.out_pitch >= (uint64_t)out_bound(a.in_len))
-        return launch_compress_small(a, stream, ncu);
-    uint64_t g = (uint64_t)ncu * 64u;
-    if (g > a.nblocks) g = a.nblocks;
-    const dim3 grid((unsigned)g), block(64);
-    if (a.cwindow <= 32) hipLaunchKernelGGL(k_compress<1>, grid, block, 0, stream, a);
-    else if (a.cwindow <= 64) hipLaunchKernelGGL(k_compress<2>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(k_compress<8>, grid, block, 0, stream, a);
+hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int ncu) {
+    const uint32_t Rb = (a.in_len + 31u) >> 5;
+    const uint64_t G = 64u / Rb;
+    uint64_t groups = (a.nblocks + G - 1u) / G;
+    uint64_t grid = (uint64_t)ncu * 64u;
+    if (grid > groups) grid = groups;
+    hipLaunchKernelGGL(k_compress_small, dim3((unsigned)grid), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ __host__ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 hipError_t launch_compress(const CompressArgs& a, hipStream_t stream);
+hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int ncu);
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t stream);
 hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream);
 hipError_t launch_compact(const uint8_t* rows, uint64_t pitch, const uint32_t* len, const uint64_t* off,

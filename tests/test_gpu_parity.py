@@ -130,6 +130,33 @@ def test_compress_wide_windows_large_blocks_every_block(engine, oracle):
         assert zlib.decompress(ho[0, :hl[0]].tobytes()) == h[0].tobytes()
 
 
+def test_compress_small_blocks_packed_kernel(engine, oracle):
+    """uniform blocks of 5..1024 bytes take the packed kernel (several blocks per wave-tile): every block
+    against the oracle, block counts that leave partial groups, MATCH10 on/off, windows <= 32"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    for n, B, cw, mm in [(5, 300, 32, 10), (6, 65, 32, 10), (31, 777, 32, 10), (32, 1000, 32, 10), (33, 513, 32, 5),
+                         (100, 777, 32, 10), (255, 640, 16, 10), (256, 4096, 32, 10), (257, 333, 32, 10),
+                         (500, 1001, 32, 10), (512, 2048, 7, 5), (1000, 130, 32, 10), (1024, 511, 32, 10)]:
+        pitch = (n + 15) // 16 * 16
+        raw = make_blocks(B, max(n, 64), "cuda", seed=n)[:, :pitch if pitch <= max(n, 64) else n]
+        d = torch.zeros((B, pitch), dtype=torch.uint8, device="cuda")
+        d[:, :n] = raw[:, :n]
+        if n % 7 == 3:
+            d[:, :n] = (d[:, :n] % 3) + 48            # match-dense variant
+        out, ol, st = engine.compress_batch(d, in_len=n, cwindow=cw, maxmatch=mm)
+        torch.cuda.synchronize()
+        h, ho, hl, hs = d.cpu().numpy(), out.cpu().numpy(), ol.cpu().numpy(), st.cpu().numpy()
+        flat = np.ascontiguousarray(h[:, :n]).reshape(-1)
+        off = np.arange(B + 1, dtype=np.uint64) * n
+        ro, rl, rs = oracle.compress_batch(flat, off, cw, mm, out_pitch=ho.shape[1], nthreads=8)
+        assert (hs == rs).all() and (rs == 0).all(), (n, B)
+        assert (hl == rl).all(), (n, B, int((hl != rl).sum()))
+        mask = np.arange(ho.shape[1])[None, :] < hl[:, None]
+        assert ((ho == ro) | ~mask).all(), (n, B)
+        assert zlib.decompress(ho[B - 1, :hl[B - 1]].tobytes()) == h[B - 1, :n].tobytes()
+
+
 def test_compress_misaligned_inputs(engine, oracle):
     import torch
     from hdl_deflate_amd.data import family_bytes
