@@ -138,6 +138,19 @@ def main():
     k_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
     k_avg = sum(k_ms) / len(k_ms)
 
+    # ---- achievable HBM ceiling on this box: a plain device copy of the same input (read + write)
+    cp = torch.empty_like(d_in)
+    cp.copy_(d_in)
+    torch.cuda.synchronize()
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(5):
+        cp.copy_(d_in)
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 2.0 * d_in.numel() * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    del cp
+
     # ---- checks outside the timed region
     bad = int((st != 0).sum().item())
     out_bytes_local = int(ol.to(torch.int64).sum().item())
@@ -183,7 +196,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": tsrc, "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg, 4),
-                     "kernel_ms_min": round(k_ms[0], 4),
+                     "kernel_ms_min": round(k_ms[0], 4), "device_copy_GBps": round(copy_gbs, 1),
+                     "frac_of_device_copy": round(achieved / copy_gbs, 4),
                      "note": "bytes = N_in + N_out + 4 per block; this path is VALU-issue bound, not HBM bound "
                              "(DESIGN.md)"},
     }
@@ -309,12 +323,21 @@ def cpu_baseline(d_in, n, a):
 
     probe = d_in[:min(B, 4096)].cpu().numpy()
     run(probe, cores)                                      # warm: library load, thread start-up
-    rate1 = probe.size / run(probe[:512], 1)               # single-thread bytes/s
+    rate1 = probe[:512].size / run(probe[:512], 1)         # single-thread bytes/s
     # bounded sample: about cpu_seconds of single-core-equivalent work per core, capped by the data we have
     S = int(min(B, max(4096, rate1 * cores * a.cpu_seconds * 0.5 / n)))
     sample = d_in[:S].cpu().numpy()
     dt = run(sample, cores)
+    # familiar yardstick: stock zlib level 1, Z_FIXED, one core, on 16 MiB of the same blocks
+    import zlib
+    zs = sample[:min(S, (16 << 20) // n)]
+    t0 = time.perf_counter()
+    for k in range(zs.shape[0]):
+        co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        co.compress(zs[k].tobytes()); co.flush()
+    zl_rate = zs.size / (time.perf_counter() - t0)
     return {"value": round(sample.size / dt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
+            "stock_zlib_level1_zfixed_single_core_MBps": round(zl_rate / 1e6, 1),
             "sample": "first %d blocks of the same workload (%.1f MiB), oracle/hdlz_oracle.c, %d threads, %.2f s"
                       % (S, sample.size / 2 ** 20, cores, dt),
             "single_thread_MBps": round(rate1 / 1e6, 1),
