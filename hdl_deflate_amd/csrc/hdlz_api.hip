@@ -111,4 +111,34 @@ int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t
     return HDLZ_OK;
 }
 
+size_t hdlz_stream_work_bytes(size_t in_len) {
+    return in_len >= 0x80000000ull ? 0 : hdlz::stream_work_bytes((uint32_t)in_len);
+}
+
+int hdlz_compress_stream(const uint8_t* d_in, uint32_t in_len, int cwindow, int maxmatch, uint8_t* d_out,
+                         uint64_t out_cap, uint32_t* d_out_len, uint32_t* d_status, void* d_work,
+                         size_t work_bytes, void* stream) {
+    if (cwindow < 1 || cwindow > 256) return fail_param("cwindow must be in [1,256]");
+    if (maxmatch != 5 && maxmatch != 10) return fail_param("maxmatch must be 5 (MATCH10=False) or 10 (MATCH10=True)");
+    if (!d_in || !d_out || !d_out_len || !d_status || !d_work) return fail_param("null device pointer");
+    if (in_len >= 0x80000000u) return fail_param("in_len too large");
+    if (reinterpret_cast<uintptr_t>(d_out) & 3u) return fail_param("d_out must be 4-byte aligned");
+    if (reinterpret_cast<uintptr_t>(d_work) & 7u) return fail_param("d_work must be 8-byte aligned");
+    if (work_bytes < hdlz::stream_work_bytes(in_len)) return fail_param("d_work smaller than hdlz_stream_work_bytes(in_len)");
+    int rc = check_device();
+    if (rc != HDLZ_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t need = ((uint64_t)hdlz::out_bound(in_len) + 3u) & ~3ull;
+    if (in_len < 5u || out_cap < need) {            // R0 / capacity: same per-stream status as the batch call
+        hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_status),
+                                         in_len < 5u ? HDLZ_E_SHORT_INPUT : HDLZ_E_OUT_CAPACITY, 1, st);
+        if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_out_len), 0, 1, st);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetD32Async");
+        return HDLZ_OK;
+    }
+    hipError_t e = hdlz::launch_compress_stream(d_in, in_len, cwindow, maxmatch, d_out, out_cap, d_out_len, d_status, d_work, st);
+    if (e != hipSuccess) return fail_hip(e, "launch k_stream_*");
+    return HDLZ_OK;
+}
+
 }  // extern "C"

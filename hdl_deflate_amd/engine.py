@@ -60,6 +60,27 @@ class Engine(object):
         self._check(rc, "hdlz_compress_batch")
         return out, out_len, status
 
+    # -- STARTC for ONE large stream, spread over the whole GPU (same bytes as compress_batch with one block)
+    STREAM_MIN = 1 << 16
+
+    def compress_stream(self, d_in, n, cwindow=32, maxmatch=10, out=None, work=None):
+        """d_in: flat uint8 device tensor, readable up to n rounded up to 16.
+        Returns (out uint8[cap], out_len int32[1], status int32[1])."""
+        assert d_in.is_cuda and d_in.dtype == torch.uint8 and d_in.is_contiguous() and d_in.numel() >= (n + 15) // 16 * 16
+        cap = pitch_for(n)
+        if out is None:
+            out = torch.empty(cap, dtype=torch.uint8, device=d_in.device)
+        wb = self.lib.hdlz_stream_work_bytes(n)
+        if work is None:
+            work = torch.empty((wb + 7) // 8, dtype=torch.int64, device=d_in.device)
+        out_len = torch.empty(1, dtype=torch.int32, device=d_in.device)
+        status = torch.empty(1, dtype=torch.int32, device=d_in.device)
+        rc = self.lib.hdlz_compress_stream(d_in.data_ptr(), n, cwindow, maxmatch, out.data_ptr(), out.numel(),
+                                           out_len.data_ptr(), status.data_ptr(), work.data_ptr(),
+                                           work.numel() * work.element_size(), self._stream())
+        self._check(rc, "hdlz_compress_stream")
+        return out, out_len, status
+
     # -- STARTD for a batch
     def inflate_batch(self, d_in, in_off=None, in_len=None, nblocks=None, out_pitch=None, flags=0, obsize=0,
                       out=None):
@@ -103,8 +124,11 @@ class Engine(object):
         host = torch.zeros(pad, dtype=torch.uint8)
         if n:
             host[:n] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
-        d = host.to(self.device).view(1, pad)
-        out, ol, st = self.compress_batch(d, in_len=n, cwindow=cwindow, maxmatch=maxmatch)
+        d = host.to(self.device)
+        if n >= self.STREAM_MIN:
+            out, ol, st = self.compress_stream(d, n, cwindow=cwindow, maxmatch=maxmatch)
+            return int(st.item()), bytes(out[:int(ol.item())].cpu().numpy().tobytes())
+        out, ol, st = self.compress_batch(d.view(1, pad), in_len=n, cwindow=cwindow, maxmatch=maxmatch)
         st = int(st.item())
         return st, bytes(out[0, :int(ol.item())].cpu().numpy().tobytes())
 

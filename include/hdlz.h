@@ -106,6 +106,21 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
 int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, const uint64_t* d_off,
                        uint64_t nblocks, uint8_t* d_archive, void* stream);
 
+/* ---- one LARGE stream on the whole GPU ---------------------------------------------------------------------
+ * Same STARTC semantics and bit-identical output as hdlz_compress_batch with nblocks = 1
+ * (deflate.py:616-633 IDLE/STARTC ... :884-897 CHECKSUM: the reference handles one stream per START), but the
+ * stream's 2 KiB tiles are spread over all compute units (three parallel passes).  Meant for
+ * streams of >= 64 KiB up to the reference's LMAX range; smaller ones are faster through the batch call.
+ *   d_in / in_len   the stream (in_len >= 5, else *d_status = HDLZ_E_SHORT_INPUT); readable up to in_len
+ *                   rounded up to 16 bytes
+ *   d_out / out_cap 4-byte aligned, out_cap >= hdlz_out_bound(in_len) rounded up to 4 (else HDLZ_E_OUT_CAPACITY)
+ *   d_work          device scratch of hdlz_stream_work_bytes(in_len) bytes, 8-byte aligned
+ * Returns HDLZ_OK when the launches were queued; *d_out_len, *d_status as in hdlz_compress_batch. */
+size_t hdlz_stream_work_bytes(size_t in_len);
+int hdlz_compress_stream(const uint8_t* d_in, uint32_t in_len, int cwindow, int maxmatch, uint8_t* d_out,
+                         uint64_t out_cap, uint32_t* d_out_len, uint32_t* d_status, void* d_work,
+                         size_t work_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

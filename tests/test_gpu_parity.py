@@ -130,6 +130,57 @@ def test_compress_wide_windows_large_blocks_every_block(engine, oracle):
         assert zlib.decompress(ho[0, :hl[0]].tobytes()) == h[0].tobytes()
 
 
+def test_compress_stream_multiwave_vs_oracle(engine, oracle):
+    """hdlz_compress_stream: ONE stream spread over the GPU (three passes) must give the oracle's bytes --
+    sizes around tile multiples (2048), match-dense alphabets (matches straddle every tile boundary, all entry
+    skips), families, text, all kernel variants, a misaligned source pointer, and the 16 MiB LMAX-sized stream"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks, make_text_blocks
+    g = torch.Generator(device="cuda")
+    g.manual_seed(99)
+
+    def check(d, n, cw, mm, tag):
+        out, ol, st = engine.compress_stream(d, n, cwindow=cw, maxmatch=mm)
+        torch.cuda.synchronize()
+        assert int(st.item()) == 0, tag
+        got = out[:int(ol.item())].cpu().numpy().tobytes()
+        st_o, ref = oracle.compress(d[:n].cpu().numpy().tobytes(), cw, mm)
+        assert st_o == 0 and got == ref, (tag, len(got), len(ref))
+        return got
+
+    big = 1 << 20
+    dense = {k: torch.randint(0, k, (big + 64,), generator=g, device="cuda", dtype=torch.uint8) + 48 for k in (2, 3, 4)}
+    for n in (65536, 65537, 65541, 2048 * 37 - 1, 2048 * 37 + 4, 2048 * 37 + 5, 2048 * 37 + 6, 100000, 2048 * 64 + 2047,
+              big - 3, big):
+        for nsym, cw, mm in ((2, 32, 10), (3, 32, 5), (4, 64, 10), (2, 256, 10)):
+            if cw == 256 and n > 200000:
+                continue
+            check(dense[nsym], n, cw, mm, ("dense", nsym, n, cw, mm))
+    fam = make_blocks(16, 65536, "cuda", seed=5).reshape(-1)          # 1 MiB of all families back to back
+    txt = make_text_blocks(4, 1 << 20, "cuda", seed=6).reshape(-1)    # 4 MiB pseudo-English
+    for d, n, cw, mm in ((fam, fam.numel() - 16, 32, 10), (fam, 300001, 64, 10), (txt, txt.numel() - 16, 32, 10),
+                         (txt, 1 << 20, 64, 5), (txt, 262144 + 77, 256, 10)):
+        check(d, n, cw, mm, ("mix", n, cw, mm))
+    # source pointer misaligned by 1..3 and by 8 (the dword re-align path of the staging loop)
+    for k in (1, 2, 3, 8):
+        check(txt[k:], 200000 + k, 32, 10, ("misaligned", k))
+    # LMAX-sized stream (deflate.py:73-76: 16 MiB), also through zlib
+    d = make_text_blocks(16, 1 << 20, "cuda", seed=7).reshape(-1)
+    d = torch.cat([d, torch.zeros(16, dtype=torch.uint8, device="cuda")])
+    z = check(d, 1 << 24, 32, 10, "lmax")
+    assert zlib.decompress(z) == d[:1 << 24].cpu().numpy().tobytes()
+    # engine.compress_bytes routes large streams here, small ones through the batch kernel: same answer
+    blob = d[:70000].cpu().numpy().tobytes()
+    st, zz = engine.compress_bytes(blob)
+    assert st == 0 and zz == oracle.compress(blob)[1]
+    # status codes
+    out, ol, st = engine.compress_stream(d, 4)
+    assert int(st.item()) == 1 and int(ol.item()) == 0
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    out, ol, st = engine.compress_stream(d, 70000, out=small)
+    assert int(st.item()) == 2 and int(ol.item()) == 0
+
+
 def test_compress_small_blocks_packed_kernel(engine, oracle):
     """uniform blocks of 5..1024 bytes take the packed kernel (several blocks per wave-tile): every block
     against the oracle, block counts that leave partial groups, MATCH10 on/off, windows <= 32"""
