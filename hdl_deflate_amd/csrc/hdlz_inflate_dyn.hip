@@ -22,11 +22,11 @@
 
 namespace hdlz {
 
-constexpr uint32_t DRING = 4096;     // history ring bytes (power of two)
+constexpr uint32_t DRING = 2048;    // history ring bytes (power of two)
 constexpr uint32_t DCHUNK = 64;
-constexpr uint32_t IWIN = 2048;      // compressed-input window staged in LDS (bytes)
-constexpr uint32_t LBITS = 10;       // instant-table index bits (the reference uses 10 too: InstantMaxBit, deflate.py:256)
-constexpr uint32_t DBITS = 9;
+constexpr uint32_t IWIN = 512;      // compressed-input window staged in LDS (bytes)
+constexpr uint32_t LBITS = 9;       // instant-table index bits (the reference uses 10 too: InstantMaxBit, deflate.py:256)
+constexpr uint32_t DBITS = 8;
 
 struct __attribute__((aligned(16))) DynLds {
     uint8_t ring[DRING];
@@ -198,9 +198,6 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
         auto flush_lines = [&](uint32_t from, uint32_t to) {
             for (uint32_t c0 = from & ~(DCHUNK - 1u); c0 + DCHUNK <= to; c0 += DCHUNK)
                 out[c0 + lane] = L.ring[(c0 + lane) & (DRING - 1u)];
-            // far copies read flushed bytes back through L1/L2
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
 
         for (;;) {
@@ -361,6 +358,12 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                     if ((int32_t)(BITPOS() >> 3) >= isize - 2) FAIL(HDLZ_E_NO_EOF);        // COPY hold, :1600
                     if ((uint64_t)o + tlength > cap) FAIL(HDLZ_E_OUT_CAPACITY);
                     // COPY (deflate.py:1627-1659), lane-parallel: out[o+i] = out[o - D + (i mod D)]
+                    if (distance + tlength > DRING - 512u) {
+                        // far history is read back from HBM: only then must the earlier line flushes have landed
+                        // (a fence per token would stall every match on its predecessors' store acknowledgements)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
                     for (uint32_t i = lane; i < tlength; i += 64u) {
                         const uint32_t src = o - distance + (distance >= tlength ? i : i % distance);
                         uint32_t byte;
