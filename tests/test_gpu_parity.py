@@ -181,6 +181,45 @@ def test_compress_stream_multiwave_vs_oracle(engine, oracle):
     assert int(st.item()) == 2 and int(ol.item()) == 0
 
 
+def test_calls_are_hip_graph_capturable(engine, oracle):
+    """the C-ABI only enqueues asynchronous work on the caller's stream: batch compress, stream compress and
+    inflate captured into ONE HIP graph, replayed on new data in the same buffers, must still match the oracle"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    from hdl_deflate_amd.constants import pitch_for
+    B, n = 512, 2048
+    d = make_blocks(B, n, "cuda", seed=1)
+    big = make_blocks(40, n, "cuda", seed=2).reshape(-1)              # one 80 KiB stream
+    nbig = big.numel() - 16
+    out = torch.empty((B, pitch_for(n)), dtype=torch.uint8, device="cuda")
+    sout = torch.empty(pitch_for(nbig), dtype=torch.uint8, device="cuda")
+    work = torch.empty((engine.lib.hdlz_stream_work_bytes(nbig) + 7) // 8, dtype=torch.int64, device="cuda")
+    back = torch.empty((B, n), dtype=torch.uint8, device="cuda")
+    engine.compress_batch(d, out=out, out_pitch=out.shape[1])          # eager once: device properties get cached
+    engine.compress_stream(big, nbig, out=sout, work=work)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            _, ol, st = engine.compress_batch(d, out=out, out_pitch=out.shape[1])
+            _, sl, ss = engine.compress_stream(big, nbig, out=sout, work=work)
+            _, bl, bs = engine.inflate_batch(out, in_len=None, out_pitch=n, out=back)
+    for seed in (11, 12):
+        d.copy_(make_blocks(B, n, "cuda", seed=seed))
+        big.copy_(make_blocks(40, n, "cuda", seed=seed + 100).reshape(-1))
+        out.zero_(); sout.zero_(); back.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert int((st != 0).sum()) == 0 and int(ss.item()) == 0
+        h, ho, hl = d.cpu().numpy(), out.cpu().numpy(), ol.cpu().numpy()
+        for b in (0, 1, B // 2, B - 1):
+            assert ho[b, :hl[b]].tobytes() == oracle.compress(h[b].tobytes())[1]
+        assert sout[:int(sl.item())].cpu().numpy().tobytes() == oracle.compress(big[:nbig].cpu().numpy().tobytes())[1]
+        # inflate took the full pitch as in_len: trailing zero bytes after the Adler-32 are ignored (D6)
+        assert int((bs != 0).sum()) == 0 and torch.equal(back, d) and int((bl != n).sum()) == 0
+
+
 def test_compress_small_blocks_packed_kernel(engine, oracle):
     """uniform blocks of 5..1024 bytes take the packed kernel (several blocks per wave-tile): every block
     against the oracle, block counts that leave partial groups, MATCH10 on/off, windows <= 32"""

@@ -30,3 +30,33 @@ for mib in (1, 4, 16, 64, 256):
             torch.cuda.synchronize()
             ms = ev0.elapsed_time(ev1) / reps
             print("%4d MiB cw=%-3d %-7s %9.3f ms  %8.2f GB/s  ratio %.3f st=%d" % (mib, cw, name, ms, n / ms / 1e6, int(ol.item()) / n, int(st.item())), flush=True)
+
+# ---- the same calls replayed from a captured HIP graph (the C-ABI only enqueues async work on the caller's
+# stream, so it can be captured; one eager call first: the library caches device properties on first use)
+print("graph replay:")
+for mib in (1, 4, 16):
+    n = mib << 20
+    d = make_text_blocks(mib, 1 << 20, "cuda", seed=3).reshape(-1)
+    d = torch.cat([d, torch.zeros(16, dtype=torch.uint8, device="cuda")])
+    out = torch.empty(((n * 9 + 10 + 7) // 8 + 6 + 15) // 16 * 16, dtype=torch.uint8, device="cuda")
+    work = torch.empty((e.lib.hdlz_stream_work_bytes(n) + 7) // 8, dtype=torch.int64, device="cuda")
+    ref = e.compress_stream(d, n, out=out, work=work)
+    torch.cuda.synchronize()
+    want = out[:int(ref[1].item())].clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            o, ol, st = e.compress_stream(d, n, out=out, work=work)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert int(st.item()) == 0 and torch.equal(out[:int(ol.item())], want)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+        g.replay()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / 20
+    print("%4d MiB cw=32  graph   %9.3f ms  %8.2f GB/s" % (mib, ms, n / ms / 1e6), flush=True)
