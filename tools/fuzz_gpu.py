@@ -80,6 +80,31 @@ def main():
                     return 1
             b0 = int(np.nonzero(okb)[0][0])
             assert zlib.decompress(ho[b0, :hl[b0]].tobytes()) == flat[off[b0]:off[b0 + 1]].tobytes()
+        # the whole flat buffer once more as ONE stream through the multi-wave path (needs >= 5 bytes)
+        if total >= 5 and (cw <= 64 or total <= 300000):
+            so, sl, ss = eng.compress_stream(d_in[mis:], total, cwindow=cw, maxmatch=mm)
+            torch.cuda.synchronize()
+            got = so[:int(sl.item())].cpu().numpy().tobytes()
+            rc, ref = O.compress(flat[mis:mis + total].tobytes(), cw, mm)
+            if int(ss.item()) != rc or got != ref:
+                print("STREAM MISMATCH it=%d seed=%d n=%d cw=%d mm=%d kind=%d mis=%d status %d/%d len %d/%d"
+                      % (it, a.seed, total, cw, mm, kind, mis, int(ss.item()), rc, len(got), len(ref)))
+                return 1
+        # stock zlib streams of the same blocks (dynamic / fixed / stored mix) through the two inflate passes
+        if it % 4 == 0:
+            sel = np.nonzero(lens >= 1)[0][:600]
+            zs = [zlib.compress(flat[off[b]:off[b + 1]].tobytes(), int(rng.integers(0, 10))) for b in sel]
+            if zs:
+                zoff = np.concatenate([[0], np.cumsum([len(z) for z in zs])]).astype(np.int64)
+                zflat = np.frombuffer(b"".join(zs) + bytes(64), dtype=np.uint8).copy()
+                cap = (int(lens[sel].max()) + 15) // 16 * 16 + 16
+                zb, zl, zst = eng.inflate_batch(torch.from_numpy(zflat).cuda(), in_off=torch.from_numpy(zoff).cuda(), out_pitch=cap)
+                torch.cuda.synchronize()
+                hb, hbl, hbs = zb.cpu().numpy(), zl.cpu().numpy(), zst.cpu().numpy()
+                for k, b in enumerate(sel):
+                    if hbs[k] != 0 or hbl[k] != lens[b] or hb[k, :lens[b]].tobytes() != flat[off[b]:off[b + 1]].tobytes():
+                        print("ZLIB-INFLATE MISMATCH it=%d seed=%d k=%d n=%d status %d len %d" % (it, a.seed, k, lens[b], hbs[k], hbl[k]))
+                        return 1
         blocks += B
         nbytes += total
     print("fuzz OK: %d batches, %d blocks, %.1f MiB, seed %d" % (it, blocks, nbytes / 2 ** 20, a.seed))
