@@ -33,6 +33,7 @@ constexpr uint32_t WAVES = 4;                 // independent waves per workgroup
 
 struct __attribute__((aligned(16))) InflateLds {
     uint32_t ring[WAVES][RING_DW * 64];   // per wave: [dword][lane]
+    uint32_t inq[WAVES][64];              // per lane: the stream dword at `ip`, written by LDS-DMA loads (see refill_async)
     uint32_t lit[512];             // literal/length table, see lit_entry()
     uint32_t dst[32];              // distance table indexed by the RAW 5 stream bits
 };
@@ -50,6 +51,24 @@ __device__ __forceinline__ uint32_t load32(const uint8_t* __restrict__ z, uint32
     for (uint32_t k = 0; k < 4u; k++)
         if (ip + k < zn) v |= (uint32_t)z[ip + k] << (8u * k);
     return v;
+}
+
+// ---- asynchronous input refill ---------------------------------------------------------------------------
+// Every lane reads its own stream.  With the next dword prefetched into a VGPR, the wave had to wait for ITS
+// LATEST load before any lane could consume an OLDER one (s_waitcnt counts instructions, not lanes), i.e. one
+// full memory latency per lockstep iteration.  The dword now travels HBM -> LDS directly (global_load_lds_dword:
+// no destination VGPR, so the compiler adds no wait); the consumer waits with vmcnt(ASYNC_K): loads complete in
+// order, so everything issued more than ASYNC_K load instructions ago has landed while the newest ASYNC_K stay in
+// flight.  A lane whose own load is younger than that takes the strict path (vmcnt(0)), wave-uniformly.
+#define ASYNC_K 2
+#define HDLZ_STR2(x) #x
+#define HDLZ_STR(x) HDLZ_STR2(x)
+__device__ __forceinline__ void lds_dma_load32(const uint8_t* gptr, uint32_t lds_base) {
+    // LDS address = M0 + lane * 4; only the lanes active here load / write.  M0 is saved and restored: the compiler
+    // does not expect inline asm to change it.
+    uint32_t save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(save) : "v"(gptr), "s"(lds_base) : "memory");
 }
 
 // RFC1951 tables in closed form (deflate.py:100-110)
@@ -145,15 +164,46 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
     uint64_t fb = 0;            // far-copy buffer: up to 8 source bytes fetched from the flushed output
     uint32_t fbn = 0;
     uint64_t fpre = 0;          // ... and the NEXT 8, requested one refill period ahead (latency hiding)
-    // input prefetch: `pre` always holds the 4 stream bytes at `ip`, loaded one refill period before use,
-    // so the global-load latency is never on the per-iteration critical path
-    uint32_t pre = active ? load32(z, ip, zn) : 0u;
-#define HDLZ_REFILL() do { if (bc <= 32u) { bb |= (uint64_t)pre << bc; bc += 32u; ip += 4u; pre = load32(z, ip, zn); } } while (0)
+    volatile uint32_t* inq = lds.inq[wave];
+    // low half of the flat address = LDS offset; wave-uniform, but derived from threadIdx: pin it to an SGPR
+    const uint32_t inq_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(&lds.inq[wave][0]));
+    uint32_t issued = 0;        // wave-uniform: LDS-DMA load instructions issued so far
+    uint32_t myissue = 0;       // value of `issued` when this lane's pending dword was requested
+    // request the dword at byte `ip` into inq[lane]: LDS-DMA when it lies fully inside the stream, else assembled
+    // from byte loads (zero beyond zn) and written synchronously -- that happens a few times per stream
+#define HDLZ_REQUEST(asyncv) do {                                                                        \
+        if (ip + 4u <= zn) lds_dma_load32(z + ip, inq_base);                                               \
+        else inq[lane] = load32(z, ip, zn);                                                                \
+        myissue = (asyncv);                                                                                \
+    } while (0)
+    // synchronous refill for the rare mid-iteration needs of the slow path
+#define HDLZ_REFILL() do { if (bc <= 32u) {                                                              \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+        bb |= (uint64_t)inq[lane] << bc; bc += 32u; ip += 4u;                                               \
+        inq[lane] = load32(z, ip, zn);                                                                      \
+        myissue = issued - 1000u;                                                                           \
+    } } while (0)
+    if (active) { HDLZ_REQUEST(issued); }
+    issued += 1u;
 
 #define HDLZ_FAIL(code) do { status = (code); out_len = 0; active = false; } while (0)
 #define HDLZ_BITPOS() (8u * ip - bc)
 
     for (uint32_t o = 0;; ++o) {
+        // ------------------------------------------------------------ 0. input refill (uniform control flow)
+        {
+            const bool need = active && rem == 0u && bc <= 32u;
+            if (__ballot(need) != 0ull) {
+                const bool young = need && (issued - myissue) < (uint32_t)ASYNC_K;
+                if (__ballot(young) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(" HDLZ_STR(ASYNC_K) ")" ::: "memory");
+                if (need) {
+                    bb |= (uint64_t)inq[lane] << bc; bc += 32u; ip += 4u;
+                    HDLZ_REQUEST(issued);
+                }
+                issued += 1u;
+            }
+        }
         // ------------------------------------------------------------ 1a. fast path: literal / match inside a fixed block
         bool have = false;
         bool slow = false;
@@ -335,6 +385,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
 #undef HDLZ_FAIL
 #undef HDLZ_BITPOS
 #undef HDLZ_REFILL
+#undef HDLZ_REQUEST
 
     // ---- tail: the bytes of the last, partial chunk are still only in the ring
     if (exists && status == HDLZ_OK) {
