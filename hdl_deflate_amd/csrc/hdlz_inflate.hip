@@ -164,7 +164,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
     uint64_t fb = 0;            // far-copy buffer: up to 8 source bytes fetched from the flushed output
     uint32_t fbn = 0;
     uint64_t fpre = 0;          // ... and the NEXT 8, requested one refill period ahead (latency hiding)
-    volatile uint32_t* inq = lds.inq[wave];
+    // (an LDS-typed pointer: through a generic `volatile uint32_t*` the accesses became flat loads, which wait on vmcnt)
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    lds_vu32* inq = (lds_vu32*)&lds.inq[wave][0];
     // low half of the flat address = LDS offset; wave-uniform, but derived from threadIdx: pin it to an SGPR
     const uint32_t inq_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(&lds.inq[wave][0]));
     uint32_t issued = 0;        // wave-uniform: LDS-DMA load instructions issued so far
@@ -208,8 +210,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
         bool have = false;
         bool slow = false;
         if (active && rem == 0u && srem == 0u) {
-            slow = need_header;
-            HDLZ_REFILL();
+            slow = need_header;                                    // (bc >= 33 here: refilled in step 0)
             const uint32_t e = lds.lit[(uint32_t)bb & 511u];
             const uint32_t nb = e & 15u, type = (e >> 13) & 3u;
             const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;
