@@ -37,7 +37,7 @@
 namespace hdlz {
 
 template <int NCH>   // NCH = ceil(cwindow / 32): 1, 2 or 8 chunks of 32 candidate distances
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_compress(CompressArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 5 : 4, NCH == 1 ? 5 : 4))) void k_compress(CompressArgs a) {
     __shared__ WaveLds lds;
     const uint32_t lane = threadIdx.x;
 
