@@ -388,6 +388,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
 #undef HDLZ_REFILL
 #undef HDLZ_REQUEST
 
+    // no LDS-DMA load may still be in flight when this wave's LDS is handed to another workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- tail: the bytes of the last, partial chunk are still only in the ring
     if (exists && status == HDLZ_OK) {
         const uint32_t c0 = out_len & ~(CHUNK - 1u);
