@@ -109,7 +109,7 @@ int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t
 /* ---- one LARGE stream on the whole GPU ---------------------------------------------------------------------
  * Same STARTC semantics and bit-identical output as hdlz_compress_batch with nblocks = 1
  * (deflate.py:616-633 IDLE/STARTC ... :884-897 CHECKSUM: the reference handles one stream per START), but the
- * stream's 2 KiB tiles are spread over all compute units (three parallel passes).  Meant for
+ * stream's 2 KiB tiles are spread over all compute units (parallel passes joined by scans).  Meant for
  * streams of >= 64 KiB up to the reference's LMAX range; smaller ones are faster through the batch call.
  *   d_in / in_len   the stream (in_len >= 5, else *d_status = HDLZ_E_SHORT_INPUT); readable up to in_len
  *                   rounded up to 16 bytes
