@@ -57,12 +57,10 @@ __device__ __forceinline__ uint32_t load32(const uint8_t* __restrict__ z, uint32
 // Every lane reads its own stream.  With the next dword prefetched into a VGPR, the wave had to wait for ITS
 // LATEST load before any lane could consume an OLDER one (s_waitcnt counts instructions, not lanes), i.e. one
 // full memory latency per lockstep iteration.  The dword now travels HBM -> LDS directly (global_load_lds_dword:
-// no destination VGPR, so the compiler adds no wait); the consumer waits with vmcnt(ASYNC_K): loads complete in
-// order, so everything issued more than ASYNC_K load instructions ago has landed while the newest ASYNC_K stay in
-// flight.  A lane whose own load is younger than that takes the strict path (vmcnt(0)), wave-uniformly.
-#define ASYNC_K 2
-#define HDLZ_STR2(x) #x
-#define HDLZ_STR(x) HDLZ_STR2(x)
+// no destination VGPR, so the compiler adds no wait) and the consumer waits by hand: loads complete in order, so
+// a request with `after` LDS-DMA instructions issued behind it has landed once at most `after` loads are
+// outstanding.  `issued` counts the LDS-DMA instructions the wave has executed (wave-uniform), every lane
+// remembers the count right after its own request, and the wait is vmcnt(min(after over the consuming lanes, 2)).
 __device__ __forceinline__ void lds_dma_load32(const uint8_t* gptr, uint32_t lds_base) {
     // LDS address = M0 + lane * 4; only the lanes active here load / write.  M0 is saved and restored: the compiler
     // does not expect inline asm to change it.
@@ -185,8 +183,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
         inq[lane] = load32(z, ip, zn);                                                                      \
         myissue = issued - 1000u;                                                                           \
     } } while (0)
-    if (active) { HDLZ_REQUEST(issued); }
-    issued += 1u;
+    if (active) { HDLZ_REQUEST(issued + 1u); }
+    if (__ballot(active && ip + 4u <= zn) != 0ull) issued += 1u;      // counts LDS-DMA instructions actually executed
 
 #define HDLZ_FAIL(code) do { status = (code); out_len = 0; active = false; } while (0)
 #define HDLZ_BITPOS() (8u * ip - bc)
@@ -196,14 +194,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
         {
             const bool need = active && rem == 0u && bc <= 32u;
             if (__ballot(need) != 0ull) {
-                const bool young = need && (issued - myissue) < (uint32_t)ASYNC_K;
-                if (__ballot(young) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(" HDLZ_STR(ASYNC_K) ")" ::: "memory");
+                // loads complete in order: a request with `after` LDS-DMA instructions issued behind it has landed once at
+                // most `after` loads are outstanding; wait for the youngest request that is consumed now, no further
+                const uint32_t after = issued - myissue;
+                if (__ballot(need && after < 1u) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (__ballot(need && after < 2u) != 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                bool dma = false;
                 if (need) {
                     bb |= (uint64_t)inq[lane] << bc; bc += 32u; ip += 4u;
-                    HDLZ_REQUEST(issued);
+                    dma = ip + 4u <= zn;
+                    HDLZ_REQUEST(issued + 1u);
                 }
-                issued += 1u;
+                if (__ballot(dma) != 0ull) issued += 1u;          // counts LDS-DMA instructions actually executed
             }
         }
         // ------------------------------------------------------------ 1a. fast path: literal / match inside a fixed block
