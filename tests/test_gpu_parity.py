@@ -220,6 +220,50 @@ def test_calls_are_hip_graph_capturable(engine, oracle):
         assert int((bs != 0).sum()) == 0 and torch.equal(back, d) and int((bl != n).sum()) == 0
 
 
+def test_api_edge_cases(engine, oracle):
+    """empty batches are no-ops, parameter errors are reported by the call (not by a kernel), minimal and
+    unaligned shapes work: every entry point of include/hdlz.h"""
+    import ctypes
+    import torch
+    from hdl_deflate_amd.constants import E_BAD_PARAM, pitch_for
+    L = engine.lib
+    st = torch.cuda.current_stream().cuda_stream
+    # nblocks == 0: nothing is dereferenced
+    assert L.hdlz_compress_batch(None, None, 0, 0, 0, 32, 10, None, 0, None, None, st) == 0
+    assert L.hdlz_inflate_batch(None, None, 0, 0, 0, 0, 0, None, 0, None, None, st) == 0
+    assert L.hdlz_compact_batch(None, 0, None, None, 0, None, st) == 0
+    # parameter errors
+    buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    i32 = torch.zeros(4, dtype=torch.int32, device="cuda")
+    p, q = buf.data_ptr(), i32.data_ptr()
+    assert L.hdlz_compress_batch(p, None, 64, 64, 1, 32, 10, p + 1, 256, q, q, st) == E_BAD_PARAM      # unaligned d_out
+    assert L.hdlz_compress_batch(p, None, 64, 64, 1, 32, 10, p, 250, q, q, st) == E_BAD_PARAM          # out_pitch % 4
+    assert L.hdlz_compress_batch(None, None, 64, 64, 1, 32, 10, p, 256, q, q, st) == E_BAD_PARAM       # null input
+    assert b"null" in L.hdlz_last_error()
+    assert L.hdlz_compress_stream(p, 1000, 0, 10, p, 4096, q, q, p, 1 << 20, st) == E_BAD_PARAM         # cwindow 0
+    assert L.hdlz_compress_stream(p, 1000, 32, 10, p, 4096, q, q, p, 8, st) == E_BAD_PARAM               # workspace too small
+    assert L.hdlz_compress_stream(p, 1000, 32, 10, p, 4096, q, q, p + 4, 1 << 20, st) == E_BAD_PARAM     # workspace alignment
+    assert L.hdlz_stream_work_bytes(1 << 24) >= (1 << 24) // 2048 * 24 and L.hdlz_stream_work_bytes(1 << 40) == 0
+    assert L.hdlz_out_bound(0) == 8 and L.hdlz_out_bound(2048) == 2312
+    assert L.hdlz_status_string(10) == b"BAD_TREE" and L.hdlz_version() >= 1
+    # the smallest stream the reference starts on (N = 5), through every compress entry point
+    five = b"hello"
+    ref = oracle.compress(five)[1]
+    assert engine.compress_bytes(five) == (0, ref)
+    d = torch.frombuffer(bytearray(five) + bytearray(27), dtype=torch.uint8).cuda()
+    so, sl, ss = engine.compress_stream(d, 5)
+    assert int(ss.item()) == 0 and so[:int(sl.item())].cpu().numpy().tobytes() == ref
+    assert engine.inflate_bytes(ref) == (0, five)
+    # a fixed-pitch batch whose pitch is not a multiple of 16 and whose rows are shorter than the pitch
+    rows = torch.randint(97, 100, (33, 1000), dtype=torch.uint8, device="cuda")
+    flat = torch.cat([rows.reshape(-1), torch.zeros(64, dtype=torch.uint8, device="cuda")])
+    out, ol, stt = engine.compress_batch(flat, in_len=900, nblocks=33, out_pitch=pitch_for(1000))
+    # (in_len given with a flat tensor: pitch == in_len, so block b starts at b * 900)
+    h = flat.cpu().numpy()
+    for b in (0, 1, 32):
+        assert int(stt[b]) == 0 and out[b, :int(ol[b])].cpu().numpy().tobytes() == oracle.compress(h[b * 900:(b + 1) * 900].tobytes())[1]
+
+
 def test_compress_small_blocks_packed_kernel(engine, oracle):
     """uniform blocks of 5..1024 bytes take the packed kernel (several blocks per wave-tile): every block
     against the oracle, block counts that leave partial groups, MATCH10 on/off, windows <= 32"""
