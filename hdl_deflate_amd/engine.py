@@ -61,7 +61,7 @@ class Engine(object):
         return out, out_len, status
 
     # -- STARTC for ONE large stream, spread over the whole GPU (same bytes as compress_batch with one block)
-    STREAM_MIN = 1 << 16
+    STREAM_MIN = 1 << 14          # measured crossover with the single-wave batch path: ~8 KiB
 
     def compress_stream(self, d_in, n, cwindow=32, maxmatch=10, out=None, work=None):
         """d_in: flat uint8 device tensor, readable up to n rounded up to 16.

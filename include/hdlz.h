@@ -110,7 +110,8 @@ int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t
  * Same STARTC semantics and bit-identical output as hdlz_compress_batch with nblocks = 1
  * (deflate.py:616-633 IDLE/STARTC ... :884-897 CHECKSUM: the reference handles one stream per START), but the
  * stream's 2 KiB tiles are spread over all compute units (parallel passes joined by scans).  Meant for
- * streams of >= 64 KiB up to the reference's LMAX range; smaller ones are faster through the batch call.
+ * streams of >= 16 KiB (the measured crossover with one wave of the batch call is ~8 KiB) up to the reference's
+ * LMAX range and beyond.
  *   d_in / in_len   the stream (in_len >= 5, else *d_status = HDLZ_E_SHORT_INPUT); readable up to in_len
  *                   rounded up to 16 bytes
  *   d_out / out_cap 4-byte aligned, out_cap >= hdlz_out_bound(in_len) rounded up to 4 (else HDLZ_E_OUT_CAPACITY)
