@@ -25,8 +25,7 @@ namespace hdlz {
 constexpr uint32_t DRING = 2048;    // history ring bytes (power of two)
 constexpr uint32_t DCHUNK = 64;
 constexpr uint32_t IWIN = 512;      // compressed-input window staged in LDS (bytes)
-constexpr uint32_t LBITS = 9;       // instant-table index bits (the reference uses 10 too: InstantMaxBit, deflate.py:256)
-constexpr uint32_t DBITS = 8;
+constexpr uint32_t WCAP = 448;       // output bytes committed per decode window (< 512: see the ring argument at the commit)
 
 struct __attribute__((aligned(16))) DynLds {
     uint8_t ring[DRING];
@@ -39,8 +38,6 @@ struct __attribute__((aligned(16))) DynLds {
     int32_t left[3];
     uint32_t cnt32[16];              // scratch of canon_build
     uint32_t next[16];
-    uint16_t llut[1 << LBITS];       // instant tables: (symbol << 4) | code length, 0 = longer code / no code
-    uint16_t dlut[1 << DBITS];
 };
 
 typedef uint32_t __attribute__((aligned(1))) u32u;
@@ -136,20 +133,46 @@ __device__ __forceinline__ int canon_decode(const CodeRegs& r, const uint16_t* s
     return -1;
 }
 
-// instant table: every lane canonical-decodes the bit patterns lane, lane+64, ... once per block
-__device__ __forceinline__ void build_lut(const CodeRegs& r, const uint16_t* symbol, uint16_t* lut, uint32_t bits, uint32_t lane) {
-    for (uint32_t e = lane; e < (1u << bits); e += 64u) {
-        uint32_t used;
-        const int sym = canon_decode(r, symbol, e, used);     // bits above `bits` are zero: only codes <= bits long count
-        lut[e] = (sym >= 0 && used <= bits) ? (uint16_t)(((uint32_t)sym << 4) | used) : (uint16_t)0;
+// ---- window decode -----------------------------------------------------------------------------------------
+// The token decode of ONE stream is a serial chain, and hipcc runs a wave-uniform chain on the CU's single scalar
+// unit (0.97 instructions per cycle per CU, tools/ubench/salu_rate.hip): ~90 scalar instructions per token was the
+// bound of the first version.  Now all 64 lanes decode speculatively, lane k at bit offset k of the next 64 stream
+// bits (a canonical code needs no table for that: with the codes left-aligned to 15 bits, the codes of length <= l
+// end at hi[l]; the length of the code in front of a lane is found by 15 compare+select steps against per-length
+// words X[l] = hi[l] | first-symbol-index << 16 | (l+1) << 25 held in registers).  A short scalar loop then follows
+// the real chain through the per-lane bit counts, a wave scan gives every chained token its output position, the
+// reference's checks are evaluated per lane in its order, literals are written in parallel and only the LZ copies
+// remain serial (lane-parallel inside each copy).
+struct XCode { uint32_t x[16]; };
+__device__ __forceinline__ void build_x(XCode& X, const uint16_t* count) {
+    uint32_t first = 0, index = 0;
+    X.x[0] = 1u << 25;                                               // shorter than hi[1]: length 1, first symbol 0, base 0
+#pragma unroll
+    for (int l = 1; l < 16; l++) {
+        const uint32_t c = count[l];
+        index += c;
+        X.x[l] = ((first + c) << (15 - l)) | (index << 16) | ((uint32_t)(l + 1) << 25);
+        first = (first + c) << 1;
     }
 }
-// table first, canonical walk for the rare longer codes
-__device__ __forceinline__ int fast_decode(const CodeRegs& r, const uint16_t* symbol, const uint16_t* lut, uint32_t bits,
-                                           uint32_t peek, uint32_t& used) {
-    const uint32_t e = lut[peek & ((1u << bits) - 1u)];
-    if (e != 0u) { used = e & 15u; return (int)(e >> 4); }
-    return canon_decode(r, symbol, peek, used);
+// -> code length (16 = no code starts with these bits) and index into the sorted symbol list
+__device__ __forceinline__ void xwalk(const XCode& X, uint32_t bits15, uint32_t& len, uint32_t& symi) {
+    const uint32_t V = __builtin_bitreverse32(bits15 & 0x7FFFu) >> 17;
+    uint32_t sel = X.x[0];
+#pragma unroll
+    for (int l = 1; l < 16; l++) sel = (V >= (X.x[l] & 0xFFFFu)) ? X.x[l] : sel;
+    len = sel >> 25;
+    const uint32_t base = sel & 0xFFFFu, idx = (sel >> 16) & 0x1FFu;
+    symi = idx + ((V - base) >> (15u - min(len, 15u)));
+}
+__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t lane) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const uint32_t o = __shfl_up(incl, ofs, 64);
+        if (lane >= (uint32_t)ofs) incl += o;
+    }
+    return incl - v;
 }
 
 __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
@@ -317,63 +340,138 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                 if ((int32_t)(BITPOS() >> 3) > isize - 3) FAIL(HDLZ_E_NO_EOF);
             }
             {
-                CodeRegs lc, dc_;
-                load_counts(lc, L.cnt[1]);
-                load_counts(dc_, L.cnt[2]);
-                build_lut(lc, L.lsym, L.llut, LBITS, lane);
-                build_lut(dc_, L.dsym, L.dlut, DBITS, lane);
-                __syncthreads();
-                // NEXT / INFLATE / D_NEXT / COPY
-                for (;;) {
-                    REFILL();
-                    uint32_t used;
-                    const int sym = fast_decode(lc, L.lsym, L.llut, LBITS, (uint32_t)bb & 0x7FFFu, used);
-                    if (sym < 0) FAIL(HDLZ_E_BAD_SYMBOL);
-                    if (hm == 1u && sym == 287) FAIL(HDLZ_E_BAD_SYMBOL);               // zero leaf, deflate.py:212,:1437-1439
-                    TAKE(used);
-                    if ((int32_t)(BITPOS() >> 3) > isize - 3) FAIL(HDLZ_E_NO_EOF);     // deflate.py:1535-1539
-                    if (sym == 256) break;
-                    if (sym < 256) {
-                        if (o >= cap) FAIL(HDLZ_E_OUT_CAPACITY);
-                        if (lane == 0) L.ring[o & (DRING - 1u)] = (uint8_t)sym;
-                        o++;
-                        if ((o & (DCHUNK - 1u)) == 0u) out[o - DCHUNK + lane] = L.ring[(o - DCHUNK + lane) & (DRING - 1u)];
-                        continue;
+                XCode XL, XD;
+                build_x(XL, L.cnt[1]);
+                build_x(XD, L.cnt[2]);
+                uint32_t bp = BITPOS();                             // absolute bit position of the next token
+                for (bool eob = false; !eob;) {
+                    // the window must hold the bits [bp, bp + 64 + 48) and the two dwords a lane's funnel shift reads beyond
+                    if ((bp >> 3) - iwbase >= IWIN - 32u) {         // (also true for the "force a fill" value of iwbase)
+                        __syncthreads();
+                        iwbase = (bp >> 3) & ~3u;
+                        for (uint32_t k = lane; k < IWIN / 4u; k += 64u) L.iwin[k] = dload32(z, iwbase + 4u * k, zn);
+                        __syncthreads();
                     }
-                    const uint32_t token = (uint32_t)sym - 257u;
-                    if (token >= 29u) FAIL(HDLZ_E_BAD_SYMBOL);
-                    uint32_t lbase, leb, dbase, deb;
-                    d_length_info(token, lbase, leb);
-                    const uint32_t tlength = lbase + ((uint32_t)bb & ((1u << leb) - 1u));
-                    TAKE(leb);
-                    REFILL();
-                    const int ds = fast_decode(dc_, L.dsym, L.dlut, DBITS, (uint32_t)bb & 0x7FFFu, used);
-                    if (ds < 0) FAIL(HDLZ_E_BAD_SYMBOL);
-                    TAKE(used);
-                    if (ds >= 30) FAIL(HDLZ_E_BAD_DISTANCE);
-                    d_dist_info((uint32_t)ds, dbase, deb);
-                    const uint32_t distance = dbase + ((uint32_t)bb & ((1u << deb) - 1u));
-                    TAKE(deb);
-                    if (distance > o || distance > obsize) FAIL(HDLZ_E_BAD_DISTANCE);     // deflate.py:1506-1508, D8
-                    if ((int32_t)(BITPOS() >> 3) >= isize - 2) FAIL(HDLZ_E_NO_EOF);        // COPY hold, :1600
-                    if ((uint64_t)o + tlength > cap) FAIL(HDLZ_E_OUT_CAPACITY);
-                    // COPY (deflate.py:1627-1659), lane-parallel: out[o+i] = out[o - D + (i mod D)]
-                    if (distance + tlength > DRING - 512u) {
-                        // far history is read back from HBM: only then must the earlier line flushes have landed
-                        // (a fence per token would stall every match on its predecessors' store acknowledgements)
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    // ---- every lane: the token that would start at bit bp + lane
+                    const uint32_t bitpos = bp + lane;
+                    uint32_t len, symi, sym, tlen = 0, distance = 0, total;
+                    bool lit, eobt, ismatch, valid, mvalid = false;
+                    uint32_t token, dlen = 16, ds = 0;
+                    {
+                        const uint32_t rel = bitpos - 8u * iwbase;
+                        const uint32_t w = rel >> 5, sh = rel & 31u;
+                        const uint32_t d0 = L.iwin[w], d1 = L.iwin[w + 1u], d2 = L.iwin[w + 2u];
+                        const uint64_t x = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) |
+                                           ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+                        xwalk(XL, (uint32_t)x, len, symi);
+                        valid = len <= 15u;
+                        sym = L.lsym[min(symi, 287u)];
+                        lit = valid && sym < 256u;
+                        eobt = valid && sym == 256u;
+                        ismatch = valid && sym > 256u;
+                        token = sym - 257u;
+                        total = len;
+                        if (ismatch && token < 29u) {
+                            uint32_t lbase, leb, dbase, deb, dsymi;
+                            d_length_info(token, lbase, leb);
+                            const uint64_t x1 = x >> len;
+                            tlen = lbase + ((uint32_t)x1 & ((1u << leb) - 1u));
+                            const uint64_t x2 = x1 >> leb;
+                            xwalk(XD, (uint32_t)x2, dlen, dsymi);
+                            if (dlen <= 15u) {
+                                ds = L.dsym[min(dsymi, 31u)];
+                                if (ds < 30u) {
+                                    d_dist_info(ds, dbase, deb);
+                                    distance = dbase + ((uint32_t)(x2 >> dlen) & ((1u << deb) - 1u));
+                                    total = len + leb + dlen + deb;
+                                    mvalid = true;
+                                }
+                            }
+                        }
                     }
-                    for (uint32_t i = lane; i < tlength; i += 64u) {
-                        const uint32_t src = o - distance + (distance >= tlength ? i : i % distance);
-                        uint32_t byte;
-                        if ((o + i) - src <= DRING - 512u) byte = L.ring[src & (DRING - 1u)];   // still in the ring for sure
-                        else byte = out[src];                                   // far history: flushed long ago
-                        L.ring[(o + i) & (DRING - 1u)] = (uint8_t)byte;
+                    // ---- the real chain: token at bit 0, then at the end of each chained token, up to bit 63; it stops
+                    // at anything that is not a plain literal / complete match (their bit count is not trusted)
+                    const bool plain = lit || (ismatch && mvalid);
+                    uint64_t chain = 0;
+                    uint32_t cur = 0;
+                    {
+                        const uint32_t step = plain ? total : 0u;   // 0 = stop
+                        while (cur < 64u) {
+                            chain |= 1ull << cur;
+                            const uint32_t st_ = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)cur);
+                            if (st_ == 0u) break;
+                            cur += st_;
+                        }
                     }
-                    flush_lines(o, o + tlength);
-                    o += tlength;
+                    const bool inchain = (chain >> lane) & 1ull;
+                    const uint32_t outlen = (inchain && plain) ? (lit ? 1u : tlen) : 0u;
+                    const uint32_t excl = wave_excl_sum(outlen, lane);
+                    const uint32_t pos = o + excl;
+                    // ---- the reference's checks, per token, in its order (deflate.py:1409-1445, :1519-1591, :1447-1517, :1600)
+                    constexpr uint32_t ST_EOB = 100, ST_CUT = 101;
+                    uint32_t st = 0;
+                    if (!valid) st = HDLZ_E_BAD_SYMBOL;
+                    else if (hm == 1u && sym == 287u) st = HDLZ_E_BAD_SYMBOL;                        // zero leaf, deflate.py:212,:1437-1439
+                    else if ((int32_t)((bitpos + len) >> 3) > isize - 3) st = HDLZ_E_NO_EOF;         // deflate.py:1535-1539
+                    else if (eobt) st = ST_EOB;
+                    else if (lit) { if (pos >= cap) st = HDLZ_E_OUT_CAPACITY; }
+                    else if (token >= 29u) st = HDLZ_E_BAD_SYMBOL;
+                    else if (dlen > 15u) st = HDLZ_E_BAD_SYMBOL;
+                    else if (ds >= 30u) st = HDLZ_E_BAD_DISTANCE;
+                    else if (distance > pos || distance > obsize) st = HDLZ_E_BAD_DISTANCE;          // deflate.py:1506-1508, D8
+                    else if ((int32_t)((bitpos + total) >> 3) >= isize - 2) st = HDLZ_E_NO_EOF;      // COPY hold, :1600
+                    else if ((uint64_t)pos + tlen > cap) st = HDLZ_E_OUT_CAPACITY;
+                    if (st == 0u && excl + outlen > WCAP) st = ST_CUT;                               // rest of the chain: next window
+                    const uint64_t special = __ballot(inchain && st != 0u);
+                    uint64_t commit = chain;
+                    uint32_t consumed = cur, o_new;
+                    if (special != 0ull) {
+                        const uint32_t f = (uint32_t)__builtin_ctzll(special);
+                        const uint32_t stf = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)f);
+                        if (stf < ST_EOB) FAIL(stf);
+                        commit = chain & ((1ull << f) - 1ull);
+                        consumed = f;
+                        if (stf == ST_EOB) { consumed = f + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f); eob = true; }
+                        o_new = o + (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)f);
+                    } else {
+                        const uint32_t lastl = 63u - (uint32_t)__builtin_clzll(chain);
+                        o_new = o + (uint32_t)__builtin_amdgcn_readlane((int)(excl + outlen), (int)lastl);
+                    }
+                    // ---- commit.  All literals first, in parallel; then the copies in stream order.  Ring argument: a window
+                    // adds at most WCAP < 512 bytes, a copy reads the ring only up to DRING - 512 back, so a literal written
+                    // ahead of a copy can never land in a ring slot that copy still reads.
+                    const bool mine = (commit >> lane) & 1ull;
+                    if (mine && lit) L.ring[pos & (DRING - 1u)] = (uint8_t)sym;
+                    uint64_t mm = __ballot(mine && ismatch);
+                    while (mm != 0ull) {
+                        const uint32_t k = (uint32_t)__builtin_ctzll(mm);
+                        mm &= mm - 1ull;
+                        const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)k);
+                        const uint32_t tlength = (uint32_t)__builtin_amdgcn_readlane((int)tlen, (int)k);
+                        const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)distance, (int)k);
+                        // COPY (deflate.py:1627-1659), lane-parallel: out[P+i] = out[P - D + (i mod D)]
+                        if (D + tlength > DRING - 512u) {
+                            // far history is read back from HBM: only then must the earlier line flushes have landed
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        }
+                        for (uint32_t i = lane; i < tlength; i += 64u) {
+                            const uint32_t src = P - D + (D >= tlength ? i : i % D);
+                            uint32_t byte;
+                            if ((P + i) - src <= DRING - 512u) byte = L.ring[src & (DRING - 1u)];   // still in the ring for sure
+                            else byte = out[src];                               // far history: flushed long ago
+                            L.ring[(P + i) & (DRING - 1u)] = (uint8_t)byte;
+                        }
+                    }
+                    flush_lines(o, o_new);
+                    o = o_new;
+                    bp += consumed;
                 }
+                // hand the bit position back to the scalar bit reader (block headers)
+                ip = bp >> 3; bb = 0; bc = 0;
+                iwbase = ip - IWIN;
+                REFILL();
+                TAKE(bp & 7u);
             }
             if (final_) break;                                                   // D6
         }
