@@ -223,6 +223,25 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                 out[c0 + lane] = L.ring[(c0 + lane) & (DRING - 1u)];
         };
 
+        // the LDS window must hold the 64 + 48 bits from `bitp` on and the two dwords a lane's funnel shift reads beyond
+        auto ensure_window = [&](uint32_t bitp) {
+            if ((bitp >> 3) - iwbase >= IWIN - 32u) {               // (also true for the "force a fill" value of iwbase)
+                __syncthreads();
+                iwbase = (bitp >> 3) & ~3u;
+                for (uint32_t k = lane; k < IWIN / 4u; k += 64u) L.iwin[k] = dload32(z, iwbase + 4u * k, zn);
+                __syncthreads();
+            }
+        };
+        // 64 stream bits from bit `bitpos` on (per lane)
+        auto bits64 = [&](uint32_t bitpos) -> uint64_t {
+            const uint32_t rel = bitpos - 8u * iwbase;
+            const uint32_t w = rel >> 5, sh = rel & 31u;
+            const uint32_t d0 = L.iwin[w], d1 = L.iwin[w + 1u], d2 = L.iwin[w + 2u];
+            return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+        };
+        // hand an absolute bit position back to the scalar bit reader
+#define RESYNC(bitp) do { ip = (bitp) >> 3; bb = 0; bc = 0; iwbase = ip - IWIN; REFILL(); TAKE((bitp) & 7u); } while (0)
+
         for (;;) {
             REFILL();
             // HEADER (deflate.py:677-732)
@@ -281,52 +300,56 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                 for (uint32_t s = lane; s < 320u; s += 64u) L.lengths[s] = 0;
                 __syncthreads();
                 static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                for (uint32_t i = 0; i < ncode; i++) {
-                    REFILL();
-                    if (lane == 0) L.lengths[order[i]] = (uint8_t)((uint32_t)bb & 7u);
-                    TAKE(3u);
+                uint32_t hbp = BITPOS();                            // from here on the header is read through the window
+                {
+                    // the ncode 3-bit lengths of the code-length code: lane i takes its own field (ncode * 3 <= 57 bits)
+                    ensure_window(hbp);
+                    const uint64_t x = bits64(hbp);
+                    if (lane < ncode) L.lengths[order[lane]] = (uint8_t)((uint32_t)(x >> (3u * lane)) & 7u);
+                    hbp += 3u * ncode;
                 }
                 __syncthreads();
                 canon_build(L, 0, L.lengths, L.csym, 19, lane);
                 __syncthreads();
                 if (L.left[0] != 0) FAIL(HDLZ_E_BAD_TREE);
-                CodeRegs cl;
-                load_counts(cl, L.cnt[0]);
+                XCode XC;
+                build_x(XC, L.cnt[0]);
                 __syncthreads();
                 for (uint32_t s = lane; s < 320u; s += 64u) L.lengths[s] = 0;     // reuse as the real length list
                 __syncthreads();
-                // READBL / REPEAT (deflate.py:1116-1164, :1190-1202)
+                // READBL / REPEAT (deflate.py:1116-1164, :1190-1202), window decode: every lane decodes the code-length
+                // symbol (+ its repeat field) that would start at its bit offset; the scalar chain applies them in order
                 uint32_t idx = 0, prev = 0;
                 while (idx < nlen + ndist) {
-                    REFILL();
-                    uint32_t used;
-                    const int sym = canon_decode(cl, L.csym, (uint32_t)bb & 0x7FFFu, used);
-                    if (sym < 0) FAIL(HDLZ_E_BAD_TREE);
-                    TAKE(used);
-                    if (sym < 16) {
-                        if (lane == 0) L.lengths[idx] = (uint8_t)sym;
-                        prev = (uint32_t)sym;
-                        idx++;
-                    } else {
-                        uint32_t rep, val = 0;
-                        if (sym == 16) {
-                            if (idx == 0u) FAIL(HDLZ_E_BAD_TREE);
-                            val = prev;
-                            rep = 3u + ((uint32_t)bb & 3u);
-                            TAKE(2u);
-                        } else if (sym == 17) {
-                            rep = 3u + ((uint32_t)bb & 7u);
-                            TAKE(3u);
-                        } else {
-                            rep = 11u + ((uint32_t)bb & 127u);
-                            TAKE(7u);
-                        }
+                    ensure_window(hbp);
+                    uint32_t packed;                               // bits | sym << 8 | repeat << 16, 0 = no code here
+                    {
+                        const uint64_t x = bits64(hbp + lane);
+                        uint32_t len, symi;
+                        xwalk(XC, (uint32_t)x, len, symi);
+                        const uint32_t sym = L.csym[min(symi, 18u)];
+                        const uint32_t eb = sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u;
+                        const uint32_t ev = (uint32_t)(x >> min(len, 15u)) & ((1u << eb) - 1u);
+                        const uint32_t rep = sym < 16u ? 1u : sym == 18u ? 11u + ev : 3u + ev;
+                        packed = len <= 15u ? ((len + eb) | (sym << 8) | (rep << 16)) : 0u;
+                    }
+                    uint32_t cur = 0;
+                    while (cur < 64u && idx < nlen + ndist) {
+                        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)cur);
+                        if (t == 0u) FAIL(HDLZ_E_BAD_TREE);
+                        const uint32_t sym = (t >> 8) & 255u, rep = t >> 16;
+                        uint32_t val = 0;
+                        if (sym < 16u) val = sym;
+                        else if (sym == 16u) { if (idx == 0u) FAIL(HDLZ_E_BAD_TREE); val = prev; }
                         if (idx + rep > nlen + ndist) FAIL(HDLZ_E_BAD_TREE);
                         for (uint32_t k = lane; k < rep; k += 64u) L.lengths[idx + k] = (uint8_t)val;
                         prev = val;
                         idx += rep;
+                        cur += t & 255u;
                     }
+                    hbp += cur;
                 }
+                RESYNC(hbp);
                 __syncthreads();
                 if (L.lengths[256] == 0) FAIL(HDLZ_E_BAD_TREE);          // no end-of-block code
                 canon_build(L, 1, L.lengths, L.lsym, (int)nlen, lane);
@@ -345,24 +368,14 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                 build_x(XD, L.cnt[2]);
                 uint32_t bp = BITPOS();                             // absolute bit position of the next token
                 for (bool eob = false; !eob;) {
-                    // the window must hold the bits [bp, bp + 64 + 48) and the two dwords a lane's funnel shift reads beyond
-                    if ((bp >> 3) - iwbase >= IWIN - 32u) {         // (also true for the "force a fill" value of iwbase)
-                        __syncthreads();
-                        iwbase = (bp >> 3) & ~3u;
-                        for (uint32_t k = lane; k < IWIN / 4u; k += 64u) L.iwin[k] = dload32(z, iwbase + 4u * k, zn);
-                        __syncthreads();
-                    }
+                    ensure_window(bp);
                     // ---- every lane: the token that would start at bit bp + lane
                     const uint32_t bitpos = bp + lane;
                     uint32_t len, symi, sym, tlen = 0, distance = 0, total;
                     bool lit, eobt, ismatch, valid, mvalid = false;
                     uint32_t token, dlen = 16, ds = 0;
                     {
-                        const uint32_t rel = bitpos - 8u * iwbase;
-                        const uint32_t w = rel >> 5, sh = rel & 31u;
-                        const uint32_t d0 = L.iwin[w], d1 = L.iwin[w + 1u], d2 = L.iwin[w + 2u];
-                        const uint64_t x = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) |
-                                           ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+                        const uint64_t x = bits64(bitpos);
                         xwalk(XL, (uint32_t)x, len, symi);
                         valid = len <= 15u;
                         sym = L.lsym[min(symi, 287u)];
@@ -467,11 +480,7 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                     o = o_new;
                     bp += consumed;
                 }
-                // hand the bit position back to the scalar bit reader (block headers)
-                ip = bp >> 3; bb = 0; bc = 0;
-                iwbase = ip - IWIN;
-                REFILL();
-                TAKE(bp & 7u);
+                RESYNC(bp);                                         // back to the scalar bit reader (block headers)
             }
             if (final_) break;                                                   // D6
         }
@@ -487,6 +496,7 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
         }
         __syncthreads();
 #undef REFILL
+#undef RESYNC
 #undef BITPOS
 #undef TAKE
 #undef FAIL
