@@ -160,7 +160,12 @@ __device__ __forceinline__ void xwalk(const XCode& X, uint32_t bits15, uint32_t&
     const uint32_t V = __builtin_bitreverse32(bits15 & 0x7FFFu) >> 17;
     uint32_t sel = X.x[0];
 #pragma unroll
-    for (int l = 1; l < 16; l++) sel = (V >= (X.x[l] & 0xFFFFu)) ? X.x[l] : sel;
+    for (int l = 1; l < 16; l++) {
+        // sel = (V >= hi[l]) ? X[l] : sel  -- the 16-bit compare reads hi[l] straight out of the packed word (two VALU
+        // instructions per step; the C form needs a third one for the mask)
+        uint64_t m;
+        asm("v_cmp_le_u16_e64 %1, %2, %3\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(sel), "=&s"(m) : "v"(X.x[l]), "v"(V));
+    }
     len = sel >> 25;
     const uint32_t base = sel & 0xFFFFu, idx = (sel >> 16) & 0x1FFu;
     symi = idx + ((V - base) >> (15u - min(len, 15u)));
