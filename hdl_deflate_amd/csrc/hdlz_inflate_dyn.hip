@@ -6,12 +6,11 @@
 // the same stream are handled here too (the stream is restarted from its first block).
 //
 // Per-stream Huffman tables cannot live per LANE in LDS, so the mapping differs from k_inflate:
-// ONE WAVE PER STREAM.  The symbol decode is wave-uniform ("scalar-style": every lane runs the same
-// canonical-code walk, code counts live in registers, symbols in LDS), and the lanes split what is
-// parallel: an LZ copy of length L, distance D is done in ceil(L/64) steps with
+// ONE WAVE PER STREAM, and the 64 lanes decode speculatively at the 64 next bit offsets of the stream ("window
+// decode", see below); an LZ copy of length L, distance D is lane-parallel too, in ceil(L/64) steps with
 //     out[o+i] = out[o - D + (i mod D)]
 // which has no dependency on bytes produced by the same copy, whatever the overlap.  Output goes through
-// a 4 KiB LDS history ring and is flushed to HBM as full 64-byte lines.
+// a 2 KiB LDS history ring and is flushed to HBM as full 64-byte lines.
 // The reference's table layout (10-bit instant table + incremental-mask retry) is FPGA-specific; a
 // canonical count/offset decoder returns the same symbols for every valid code.  Invalid code
 // descriptions are HDLZ_E_BAD_TREE (zlib's acceptance rules: over-subscribed sets rejected, incomplete
@@ -107,32 +106,6 @@ __device__ void canon_build(DynLds& L, int which, const uint8_t* len, uint16_t* 
     }
 }
 
-struct CodeRegs { uint32_t c[16]; };   // counts of one code in registers (wave-uniform)
-
-__device__ __forceinline__ void load_counts(CodeRegs& r, const uint16_t* count) {
-#pragma unroll
-    for (int l = 0; l < 16; l++) r.c[l] = count[l];
-}
-
-// decode one symbol from the next (up to 15) stream bits `peek` (LSB first); returns symbol or -1
-__device__ __forceinline__ int canon_decode(const CodeRegs& r, const uint16_t* symbol, uint32_t peek, uint32_t& used) {
-    const uint32_t rb = __builtin_bitreverse32(peek) >> 17;   // first stream bit = MSB of a 15-bit value
-    uint32_t first = 0, index = 0;
-#pragma unroll
-    for (int l = 1; l < 16; l++) {
-        const uint32_t code = rb >> (15 - l);
-        const uint32_t count = r.c[l];
-        if (code - first < count) {            // (unsigned) also false when code < first
-            used = (uint32_t)l;
-            return (int)symbol[index + (code - first)];
-        }
-        index += count;
-        first = (first + count) << 1;
-    }
-    used = 15;
-    return -1;
-}
-
 // ---- window decode -----------------------------------------------------------------------------------------
 // The token decode of ONE stream is a serial chain, and hipcc runs a wave-uniform chain on the CU's single scalar
 // unit (0.97 instructions per cycle per CU, tools/ubench/salu_rate.hip): ~90 scalar instructions per token was the
@@ -170,17 +143,7 @@ __device__ __forceinline__ void xwalk(const XCode& X, uint32_t bits15, uint32_t&
     const uint32_t base = sel & 0xFFFFu, idx = (sel >> 16) & 0x1FFu;
     symi = idx + ((V - base) >> (15u - min(len, 15u)));
 }
-__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t lane) {
-    uint32_t incl = v;
-#pragma unroll
-    for (int ofs = 1; ofs < 64; ofs <<= 1) {
-        const uint32_t o = __shfl_up(incl, ofs, 64);
-        if (lane >= (uint32_t)ofs) incl += o;
-    }
-    return incl - v;
-}
-
-__global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_inflate_dyn(InflateArgs a) {
     __shared__ DynLds L;
     const uint32_t lane = threadIdx.x;
     for (uint64_t sid = blockIdx.x; sid < a.nstreams; sid += gridDim.x) {
@@ -412,18 +375,23 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                     const bool plain = lit || (ismatch && mvalid);
                     uint64_t chain = 0;
                     uint32_t cur = 0;
+                    uint32_t excl = 0;                              // output bytes of the chained tokens before this one
+                    uint32_t acc = 0;
                     {
-                        const uint32_t step = plain ? total : 0u;   // 0 = stop
+                        // bits | output length << 8; 0 = stop.  The running output offset is written into the chained lanes
+                        // on the way: a wave scan would cost six LDS-crossbar round trips per window.
+                        const uint32_t step = plain ? (total | ((lit ? 1u : tlen) << 8)) : 0u;
                         while (cur < 64u) {
                             chain |= 1ull << cur;
+                            excl = (lane == cur) ? acc : excl;       // (v_writelane with two SGPR operands breaks the constant-bus rule)
                             const uint32_t st_ = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)cur);
                             if (st_ == 0u) break;
-                            cur += st_;
+                            acc += st_ >> 8;
+                            cur += st_ & 255u;
                         }
                     }
                     const bool inchain = (chain >> lane) & 1ull;
                     const uint32_t outlen = (inchain && plain) ? (lit ? 1u : tlen) : 0u;
-                    const uint32_t excl = wave_excl_sum(outlen, lane);
                     const uint32_t pos = o + excl;
                     // ---- the reference's checks, per token, in its order (deflate.py:1409-1445, :1519-1591, :1447-1517, :1600)
                     constexpr uint32_t ST_EOB = 100, ST_CUT = 101;
@@ -452,8 +420,7 @@ __global__ __launch_bounds__(64) void k_inflate_dyn(InflateArgs a) {
                         if (stf == ST_EOB) { consumed = f + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f); eob = true; }
                         o_new = o + (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)f);
                     } else {
-                        const uint32_t lastl = 63u - (uint32_t)__builtin_clzll(chain);
-                        o_new = o + (uint32_t)__builtin_amdgcn_readlane((int)(excl + outlen), (int)lastl);
+                        o_new = o + acc;                            // (no stop inside the window: acc covers the whole chain)
                     }
                     // ---- commit.  All literals first, in parallel; then the copies in stream order.  Ring argument: a window
                     // adds at most WCAP < 512 bytes, a copy reads the ring only up to DRING - 512 back, so a literal written
