@@ -87,16 +87,29 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
                        uint32_t* d_out_len, uint32_t* d_status, void* stream) {
     if (nstreams > 0x7FFFFFFFull * 32) return fail_param("nstreams too large for one launch");
     if (nstreams && (!d_in || !d_out || !d_out_len || !d_status)) return fail_param("null device pointer");
-    if (flags & ~HDLZ_INFLATE_ASSUME_FIXED) return fail_param("unknown flag");
+    if (flags & ~(HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM)) return fail_param("unknown flag");
+    if ((flags & HDLZ_INFLATE_LANE_PER_STREAM) && (flags & HDLZ_INFLATE_WAVE_PER_STREAM)) return fail_param("contradictory mapping flags");
     if ((out_pitch & 3u) || (reinterpret_cast<uintptr_t>(d_out) & 3u)) return fail_param("d_out / out_pitch must be 4-byte aligned");
     int rc = check_device();
     if (rc != HDLZ_OK) return rc;
+    if (nstreams == 0) return HDLZ_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     hdlz::InflateArgs a{d_in, d_in_off, in_pitch, in_len, nstreams, flags, obsize, d_out, out_pitch, d_out_len, d_status};
-    hipError_t e = hdlz::launch_inflate(a, static_cast<hipStream_t>(stream));
+    // mapping: one LANE per stream (k_inflate, 64 streams in lockstep per wave) needs ~10^5 streams to fill the GPU;
+    // below HDLZ_INFLATE_WAVE_THRESHOLD streams one WAVE per stream (k_inflate_dyn, window decode) is faster, for
+    // any block type
+    const bool wave_all = (flags & HDLZ_INFLATE_WAVE_PER_STREAM) ||
+                          (!(flags & HDLZ_INFLATE_LANE_PER_STREAM) && nstreams <= HDLZ_INFLATE_WAVE_THRESHOLD);
+    if (wave_all) {
+        hipError_t e = hdlz::launch_inflate_dyn(a, st, true);
+        if (e != hipSuccess) return fail_hip(e, "launch k_inflate_dyn");
+        return HDLZ_OK;
+    }
+    hipError_t e = hdlz::launch_inflate(a, st);
     if (e != hipSuccess) return fail_hip(e, "launch k_inflate");
     // second pass, same stream: streams in which pass 1 met a dynamic-tree block (status 6) are redone
     // by one wave each; everything else is left untouched
-    e = hdlz::launch_inflate_dyn(a, static_cast<hipStream_t>(stream));
+    e = hdlz::launch_inflate_dyn(a, st, false);
     if (e != hipSuccess) return fail_hip(e, "launch k_inflate_dyn");
     return HDLZ_OK;
 }

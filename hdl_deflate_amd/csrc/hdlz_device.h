@@ -52,7 +52,7 @@ __host__ __device__ __forceinline__ void static_for(F&& f) {
 hipError_t launch_compress(const CompressArgs& a, hipStream_t stream);
 hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int ncu);
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t stream);
-hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream);
+hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream, bool all);
 size_t stream_work_bytes(uint32_t n);
 hipError_t launch_compress_stream(const uint8_t* in, uint32_t n, int cwindow, int maxmatch, uint8_t* out, uint64_t out_cap,
                                   uint32_t* out_len, uint32_t* status, void* work, hipStream_t stream);

@@ -24,6 +24,7 @@ namespace hdlz {
 constexpr uint32_t DRING = 2048;    // history ring bytes (power of two)
 constexpr uint32_t DCHUNK = 64;
 constexpr uint32_t IWIN = 512;      // compressed-input window staged in LDS (bytes)
+constexpr uint32_t DYN_ALL = 0x80000000u;   // internal flag bit: this kernel is the only pass, every stream is its
 constexpr uint32_t WCAP = 448;       // output bytes committed per decode window (< 512: see the ring argument at the commit)
 
 struct __attribute__((aligned(16))) DynLds {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     __shared__ DynLds L;
     const uint32_t lane = threadIdx.x;
     for (uint64_t sid = blockIdx.x; sid < a.nstreams; sid += gridDim.x) {
-        if (a.status[sid] != HDLZ_E_DYNAMIC_UNSUPPORTED) continue;   // pass 1 finished this stream
+        if (!(a.flags & DYN_ALL) && a.status[sid] != HDLZ_E_DYNAMIC_UNSUPPORTED) continue;   // pass 1 finished this stream
         uint64_t off;
         uint32_t zn;
         if (a.in_off) {
@@ -156,6 +157,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         } else {
             off = sid * a.in_pitch;
             zn = a.in_len;
+        }
+        if (zn < 5u) {                              // R0/D0: the reference never starts (only reachable when this kernel is the first pass)
+            if (lane == 0) { a.out_len[sid] = 0; a.status[sid] = HDLZ_E_SHORT_INPUT; }
+            continue;
         }
         const uint8_t* __restrict__ z = a.in + off;
         uint8_t* __restrict__ out = a.out + sid * a.out_pitch;
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             REFILL();
             // HEADER (deflate.py:677-732)
             const uint32_t final_ = (uint32_t)bb & 1u;
-            const uint32_t hm = (uint32_t)(bb >> 1) & 3u;
+            const uint32_t hm = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) ? 1u : ((uint32_t)(bb >> 1) & 3u);   // DYNAMIC=False build: deflate.py:724-732
             if (hm == 3u) FAIL(HDLZ_E_BAD_BTYPE);
             if (hm == 0u) {
                 // stored (deflate.py:709-717, COPY :1603-1626)
@@ -475,8 +480,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
 }
 
-hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream) {
-    if (a.nstreams == 0 || (a.flags & HDLZ_INFLATE_ASSUME_FIXED)) return hipSuccess;
+// second pass after k_inflate (streams it flagged with HDLZ_E_DYNAMIC_UNSUPPORTED), or -- `all` -- the only pass
+hipError_t launch_inflate_dyn(const InflateArgs& a0, hipStream_t stream, bool all) {
+    if (a0.nstreams == 0 || (!all && (a0.flags & HDLZ_INFLATE_ASSUME_FIXED))) return hipSuccess;
+    InflateArgs a = a0;
+    if (all) a.flags |= DYN_ALL;
     uint64_t g = a.nstreams < 65536u ? a.nstreams : 65536u;
     hipLaunchKernelGGL(k_inflate_dyn, dim3((unsigned)g), dim3(64), 0, stream, a);
     return hipGetLastError();

@@ -56,6 +56,11 @@ enum {
 
 /* inflate flags */
 #define HDLZ_INFLATE_ASSUME_FIXED 1u /* DYNAMIC=False build: every block is decoded as BTYPE=1 (deflate.py:724-732) */
+/* mapping hints (results are identical): by default batches of at most HDLZ_INFLATE_WAVE_THRESHOLD streams are decoded
+ * one wave per stream, larger ones one lane per stream with a wave-per-stream second pass for dynamic-tree streams */
+#define HDLZ_INFLATE_LANE_PER_STREAM 2u
+#define HDLZ_INFLATE_WAVE_PER_STREAM 4u
+#define HDLZ_INFLATE_WAVE_THRESHOLD 49152u
 
 int hdlz_version(void);
 const char* hdlz_status_string(int status);

@@ -11,6 +11,8 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
+MAPPINGS = (2, 4)       # hdlz_inflate_batch mapping hints: HDLZ_INFLATE_LANE_PER_STREAM, HDLZ_INFLATE_WAVE_PER_STREAM
+
 
 _r = random.Random(8)
 DYN_TEXT = bytes(_r.choice(b"eeeeeeeeetttttttaaaaaooooiiinnn  shrdlucmfwypvbgkqjxz") for _ in range(4000))
@@ -346,11 +348,12 @@ def test_inflate_golden_vectors(engine):
     for v in g["vectors"]:
         flags = 1 if "DYNAMIC=False" in v["build"] else 0
         obsize = 32768 if "OBSIZE=32768" in v["build"] else 512
-        st, out = engine.inflate_bytes(bytes.fromhex(v["z_hex"]), flags=flags, obsize=obsize)
-        if v["error"] is None:
-            assert st == 0 and out.hex() == v["out_hex"], v["name"]
-        else:
-            assert st == 5 and out == b"", v["name"]
+        for mapping in MAPPINGS:                 # lane-per-stream (+ dynamic second pass) and wave-per-stream decoders
+            st, out = engine.inflate_bytes(bytes.fromhex(v["z_hex"]), flags=flags | mapping, obsize=obsize)
+            if v["error"] is None:
+                assert st == 0 and out.hex() == v["out_hex"], (v["name"], mapping)
+            else:
+                assert st == 5 and out == b"", (v["name"], mapping)
 
 
 def test_inflate_random_vs_oracle_and_zlib(engine, oracle):
@@ -371,14 +374,15 @@ def test_inflate_random_vs_oracle_and_zlib(engine, oracle):
     flat = b"".join(streams) + bytes(64)
     off = np.cumsum([0] + [len(s) for s in streams]).astype(np.int64)
     d_in = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
-    out, ol, st = engine.inflate_batch(d_in, in_off=torch.from_numpy(off).cuda(), out_pitch=5008)
-    out, ol, st = out.cpu().numpy(), ol.cpu().numpy(), st.cpu().numpy()
-    for k, (z, data) in enumerate(zip(streams, plain)):
-        rc, ref = oracle.inflate(z)
-        assert st[k] == rc, (k, st[k], rc)
-        assert out[k, :ol[k]].tobytes() == ref
-        if rc == 0:
-            assert ref == data
+    for mapping in MAPPINGS:
+        out, ol, st = engine.inflate_batch(d_in, in_off=torch.from_numpy(off).cuda(), out_pitch=5008, flags=mapping)
+        out, ol, st = out.cpu().numpy(), ol.cpu().numpy(), st.cpu().numpy()
+        for k, (z, data) in enumerate(zip(streams, plain)):
+            rc, ref = oracle.inflate(z)
+            assert st[k] == rc, (k, st[k], rc, mapping)
+            assert out[k, :ol[k]].tobytes() == ref, (k, mapping)
+            if rc == 0:
+                assert ref == data
 
 
 def test_inflate_dynamic_streams_vs_oracle(engine, oracle):
@@ -406,12 +410,13 @@ def test_inflate_dynamic_streams_vs_oracle(engine, oracle):
     off = np.cumsum([0] + [len(s) for s in streams]).astype(np.int64)
     d_in = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
     cap = 20000 + 16
-    out, ol, st = engine.inflate_batch(d_in, in_off=torch.from_numpy(off).cuda(), out_pitch=cap)
-    out, ol, st = out.cpu().numpy(), ol.cpu().numpy(), st.cpu().numpy()
-    for k, z in enumerate(streams):
-        rc, ref = oracle.inflate(z, out_cap=cap)
-        assert st[k] == rc, (k, int(st[k]), rc, len(z))
-        assert out[k, :ol[k]].tobytes() == ref, k
+    for mapping in MAPPINGS:
+        out, ol, st = engine.inflate_batch(d_in, in_off=torch.from_numpy(off).cuda(), out_pitch=cap, flags=mapping)
+        out, ol, st = out.cpu().numpy(), ol.cpu().numpy(), st.cpu().numpy()
+        for k, z in enumerate(streams):
+            rc, ref = oracle.inflate(z, out_cap=cap)
+            assert st[k] == rc, (k, int(st[k]), rc, len(z), mapping)
+            assert out[k, :ol[k]].tobytes() == ref, (k, mapping)
 
 
 def test_inflate_error_statuses(engine, oracle):
@@ -419,9 +424,10 @@ def test_inflate_error_statuses(engine, oracle):
              zlib.compress(DYN_TEXT, 9),               # dynamic block
              b"\x78\x9c\x03"]                                                          # short
     for z in cases:
-        st, out = engine.inflate_bytes(z)
-        rc, ref = oracle.inflate(z)
-        assert st == rc and out == ref
+        for mapping in MAPPINGS:
+            st, out = engine.inflate_bytes(z, flags=mapping)
+            rc, ref = oracle.inflate(z)
+            assert st == rc and out == ref, mapping
     assert engine.inflate_bytes(cases[1]) == (0, DYN_TEXT)
     # output capacity
     z = zlib.compressobj(strategy=zlib.Z_FIXED).compress(b"x" * 1000)

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""lane-per-stream vs wave-per-stream inflate as a function of the batch size (stock-zlib Z_FIXED streams of 2 KiB):
+where is the crossover that HDLZ_INFLATE_WAVE_THRESHOLD encodes?"""
+import sys, os, zlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from hdl_deflate_amd import Engine, INFLATE_LANE_PER_STREAM, INFLATE_WAVE_PER_STREAM
+from hdl_deflate_amd.data import make_blocks
+e = Engine()
+n = 2048
+h = make_blocks(4096, n, "cuda", seed=4, families=(1, 2, 4)).cpu().numpy()
+zs = []
+for k in range(4096):
+    c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+    zs.append(c.compress(h[k].tobytes()) + c.flush())
+for B in (64, 1024, 4096, 16384, 32768, 65536, 262144):
+    reps = (B + 4095) // 4096
+    sel = (zs * reps)[:B]
+    lens = np.array([len(z) for z in sel], dtype=np.int64)
+    off = np.zeros(B + 1, np.int64); np.cumsum(lens, out=off[1:])
+    zin = torch.from_numpy(np.frombuffer(b"".join(sel) + bytes(64), dtype=np.uint8).copy()).cuda()
+    zoff = torch.from_numpy(off).cuda()
+    line = "%7d streams:" % B
+    for name, fl in (("lane", INFLATE_LANE_PER_STREAM), ("wave", INFLATE_WAVE_PER_STREAM)):
+        fn = lambda: e.inflate_batch(zin, in_off=zoff, out_pitch=n, flags=fl)
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): back, bl, bs = fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        assert int((bs != 0).sum()) == 0
+        line += "  %s %8.3f ms %7.1f GB/s" % (name, ms, B * n / ms / 1e6)
+    print(line, flush=True)
