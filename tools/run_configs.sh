@@ -9,3 +9,5 @@ echo "## cfg[2] 64 KiB text, CW256/M10";            $B --cpu-seconds 0 --data te
 echo "## cfg[4] shape per GPU: 16384 x 64 KiB families, CW32/M10"; $B --cpu-seconds 0 --block-size 65536 --blocks 16384 2>&1 | tail -1
 echo "## cfg[0] shape: 2^20 x 256 B, CW32/M10";     $B --cpu-seconds 0 --block-size 256 --blocks 1048576 2>&1 | tail -1
 echo "## cfg[3] inflate 2^20 zlib Z_FIXED streams";  $B --mode inflate --steps 3 --warmup 1 2>&1 | tail -1
+echo "## next-row: inflate 262144 stock-zlib default-strategy (dynamic trees) streams over 2 KiB text"; $B --mode inflate --steps 3 --warmup 1 --cpu-seconds 0 --data text --zlib-strategy default --blocks 262144 2>&1 | tail -1
+echo "## next-row: inflate 32768 stock-zlib default-strategy streams over 16 KiB text"; $B --mode inflate --steps 3 --warmup 1 --cpu-seconds 0 --data text --zlib-strategy default --block-size 16384 --blocks 32768 2>&1 | tail -1
