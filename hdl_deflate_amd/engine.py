@@ -54,6 +54,18 @@ class Engine(object):
             out = torch.empty((nb, out_pitch), dtype=torch.uint8, device=d_in.device)
         out_len = torch.empty(nb, dtype=torch.int32, device=d_in.device)
         status = torch.empty(nb, dtype=torch.int32, device=d_in.device)
+        if in_off is None and nb <= self.FEW_BLOCKS and ilen >= self.LARGE_BLOCK and pitch % 16 == 0:
+            # a handful of large blocks: one wave per block would leave the GPU idle (a 1 MiB block is 5.5 ms on a
+            # wave, 0.06 ms spread over the GPU), so each block goes through the single-stream path in turn
+            flat = d_in.reshape(-1)
+            work = torch.empty((self.lib.hdlz_stream_work_bytes(ilen) + 7) // 8, dtype=torch.int64, device=d_in.device)
+            for b in range(nb):
+                rc = self.lib.hdlz_compress_stream(flat.data_ptr() + b * pitch, ilen, cwindow, maxmatch,
+                                                   out.data_ptr() + b * out_pitch, out_pitch,
+                                                   out_len.data_ptr() + 4 * b, status.data_ptr() + 4 * b,
+                                                   work.data_ptr(), work.numel() * 8, self._stream())
+                self._check(rc, "hdlz_compress_stream")
+            return out, out_len, status
         rc = self.lib.hdlz_compress_batch(d_in.data_ptr(), off_ptr, pitch, ilen, nb, cwindow, maxmatch,
                                           out.data_ptr(), out_pitch, out_len.data_ptr(), status.data_ptr(),
                                           self._stream())
@@ -62,6 +74,7 @@ class Engine(object):
 
     # -- STARTC for ONE large stream, spread over the whole GPU (same bytes as compress_batch with one block)
     STREAM_MIN = 1 << 14          # measured crossover with the single-wave batch path: ~8 KiB
+    FEW_BLOCKS, LARGE_BLOCK = 64, 1 << 18     # compress_batch: this few blocks of at least this size -> stream path per block
 
     def compress_stream(self, d_in, n, cwindow=32, maxmatch=10, out=None, work=None):
         """d_in: flat uint8 device tensor, readable up to n rounded up to 16.

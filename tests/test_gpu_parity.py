@@ -171,6 +171,17 @@ def test_compress_stream_multiwave_vs_oracle(engine, oracle):
     d = torch.cat([d, torch.zeros(16, dtype=torch.uint8, device="cuda")])
     z = check(d, 1 << 24, 32, 10, "lmax")
     assert zlib.decompress(z) == d[:1 << 24].cpu().numpy().tobytes()
+    # a handful of large blocks through compress_batch = the stream path per block: same bytes as the batch kernel
+    few = d[:5 << 19].view(5, 1 << 19)
+    fo, fl, fs = engine.compress_batch(few)
+    saved = engine.FEW_BLOCKS
+    engine.FEW_BLOCKS = 0
+    bo, bl_, bs_ = engine.compress_batch(few)
+    engine.FEW_BLOCKS = saved
+    torch.cuda.synchronize()
+    assert int((fs != 0).sum()) == 0 and torch.equal(fl, bl_)
+    for b in range(5):
+        assert torch.equal(fo[b, :int(fl[b])], bo[b, :int(bl_[b])])
     # engine.compress_bytes routes large streams here, small ones through the batch kernel: same answer
     blob = d[:70000].cpu().numpy().tobytes()
     st, zz = engine.compress_bytes(blob)
