@@ -60,3 +60,15 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
                 txt = open(os.path.join(root, f), errors="ignore").read()
                 assert "oracle" not in txt.lower(), (root, f)
+
+
+def test_stream_kernel_is_generated_from_the_tile_phases(tmp_path):
+    """hdlz_compress_stream.hip re-uses the tile phases of hdlz_compress.hip textually (tools/gen_stream_kernel.py);
+    the committed file must be what the generator produces from the committed phases -- no silent drift"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "stream.hip"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_stream_kernel.py"), str(out)], check=True, capture_output=True)
+    with open(os.path.join(root, "hdl_deflate_amd", "csrc", "hdlz_compress_stream.hip")) as f:
+        assert f.read() == out.read_text()
