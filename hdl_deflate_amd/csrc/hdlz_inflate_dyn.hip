@@ -50,14 +50,16 @@ __device__ __forceinline__ uint32_t dload32(const uint8_t* __restrict__ z, uint3
     return v;
 }
 
+// RFC1951 3.2.5 in closed form, branch-free (these run per lane inside the window decode)
 __device__ __forceinline__ void d_length_info(uint32_t token, uint32_t& base, uint32_t& eb) {
-    if (token < 8u) { base = 3u + token; eb = 0; }
-    else if (token == 28u) { base = 258u; eb = 0; }
-    else { eb = (token >> 2) - 1u; base = 3u + ((4u + (token & 3u)) << eb); }
+    const uint32_t e = max(token >> 2, 1u) - 1u;                     // 0 for token < 8
+    const uint32_t b = token < 8u ? token : ((4u + (token & 3u)) << e);
+    eb = token == 28u ? 0u : e;
+    base = token == 28u ? 258u : 3u + b;
 }
 __device__ __forceinline__ void d_dist_info(uint32_t dc, uint32_t& base, uint32_t& eb) {
-    if (dc < 4u) { base = 1u + dc; eb = 0; }
-    else { eb = (dc >> 1) - 1u; base = 1u + ((2u + (dc & 1u)) << eb); }
+    eb = max(dc >> 1, 1u) - 1u;                                      // 0 for dc < 4
+    base = 1u + (dc < 4u ? dc : ((2u + (dc & 1u)) << eb));
 }
 
 // canonical code construction, wave-parallel (all 64 lanes call it; n <= 320):
