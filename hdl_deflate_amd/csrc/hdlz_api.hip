@@ -9,6 +9,11 @@
 namespace {
 thread_local char g_err[256] = "";
 
+__global__ void k_set_result(uint32_t* out_len, uint32_t* status, uint32_t code) {
+    *out_len = 0;
+    *status = code;
+}
+
 int fail_param(const char* what) {
     snprintf(g_err, sizeof(g_err), "bad parameter: %s", what);
     return HDLZ_E_BAD_PARAM;
@@ -143,10 +148,11 @@ int hdlz_compress_stream(const uint8_t* d_in, uint32_t in_len, int cwindow, int 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t need = ((uint64_t)hdlz::out_bound(in_len) + 3u) & ~3ull;
     if (in_len < 5u || out_cap < need) {            // R0 / capacity: same per-stream status as the batch call
-        hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_status),
-                                         in_len < 5u ? HDLZ_E_SHORT_INPUT : HDLZ_E_OUT_CAPACITY, 1, st);
-        if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_out_len), 0, 1, st);
-        if (e != hipSuccess) return fail_hip(e, "hipMemsetD32Async");
+        // (a kernel, not hipMemsetD32Async: 32-bit memsets did not survive HIP-graph capture on this stack)
+        hipLaunchKernelGGL(k_set_result, dim3(1), dim3(1), 0, st, d_out_len, d_status,
+                           in_len < 5u ? (uint32_t)HDLZ_E_SHORT_INPUT : (uint32_t)HDLZ_E_OUT_CAPACITY);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail_hip(e, "launch k_set_result");
         return HDLZ_OK;
     }
     hipError_t e = hdlz::launch_compress_stream(d_in, in_len, cwindow, maxmatch, d_out, out_cap, d_out_len, d_status, d_work, st);
