@@ -423,9 +423,10 @@ hipError_t launch_compress(const CompressArgs& a, hipStream_t stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    // uniform small blocks (the reference's own input scale): several blocks per wave-tile
-    if (!a.in_off && a.cwindow <= 32 && a.in_len >= 5u && a.in_len <= 1024u && (a.in_pitch & 15u) == 0 &&
-        (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0 && a.out_pitch >= (uint64_t)out_bound(a.in_len))
+    // small blocks (the reference's own input scale): several blocks per wave-tile -- uniform 16-byte aligned batches,
+    // or ragged ones whose caller states an upper bound on the block lengths in in_len
+    if (a.cwindow <= 32 && a.in_len >= 5u && a.in_len <= 1024u && a.out_pitch >= (uint64_t)out_bound(a.in_len) &&
+        (a.in_off || ((a.in_pitch & 15u) == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0)))
         return launch_compress_small(a, stream, ncu);
     uint64_t g = (uint64_t)ncu * 64u;
     if (g > a.nblocks) g = a.nblocks;

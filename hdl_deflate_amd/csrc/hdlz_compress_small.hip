@@ -1,4 +1,4 @@
-// hdlz_compress_small.hip -- STARTC for batches of SMALL uniform blocks (32 <= N <= 1024, CWINDOW <= 32).
+// hdlz_compress_small.hip -- STARTC for batches of SMALL blocks (N <= 1024, CWINDOW <= 32), uniform or ragged.
 //
 // The general kernel (hdlz_compress.hip) gives every block a whole 2048-position wave-tile, so a 256-byte
 // block keeps 8 of 64 lanes busy (38 GB/s measured).  Sub-KiB inputs are the reference's own scale
@@ -9,7 +9,9 @@
 // no history: d <= p), and the parse needs no reset because no token ever crosses a block end (the last two
 // bytes of a block are always literals, R5).  What is per block here: bit offsets (segmented scan), the
 // LDS bit-buffer region, Adler-32, trailer, length and the flush.  Output is bit-identical to the general
-// kernel (and to the reference); the host picks this path only for fixed-pitch, 16-byte aligned batches.
+// kernel (and to the reference).  Fixed-pitch, 16-byte aligned batches take two 16-byte loads per lane; ragged batches
+// (in_off, with in_len = an upper bound on the block lengths: every block gets ceil(bound/32) lanes) re-align their
+// bytes from aligned dword loads.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
@@ -37,7 +39,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     const uint32_t cw4 = 4u * (uint32_t)a.cwindow;
     const uint32_t kmax = (uint32_t)a.maxmatch;
-    const uint32_t n = a.in_len;                                  // uniform block length
+    const uint32_t n = a.in_len;                                  // block length (fixed pitch) or its upper bound (ragged)
+    const bool ragged = a.in_off != nullptr;
     const uint32_t Rb = (n + 31u) >> 5;                           // runs (lanes) per block
     const uint32_t G = 64u / Rb;                                  // blocks per wave-tile
     const uint32_t Wb = (out_bound(n) + 3u) >> 2;                 // bit-buffer words per block
@@ -50,17 +53,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     for (uint64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const uint64_t blk = grp * G + g;
-        const bool lane_ok = (g < G) && (blk < a.nblocks);
-        const uint32_t nrem = lane_ok ? n - min(p_run, n) : 0u;   // positions of the block from this run on
+        const bool has_blk = (g < G) && (blk < a.nblocks);
+        uint64_t boff = 0;
+        uint32_t nb = n;                                          // this lane's block: offset and length
+        if (has_blk) {
+            if (ragged) { boff = a.in_off[blk]; nb = (uint32_t)(a.in_off[blk + 1] - boff); }
+            else boff = blk * a.in_pitch;
+        }
+        const bool lane_ok = has_blk && nb >= 5u && nb <= n;      // R0: shorter blocks never start (status below)
+        if (has_blk && !lane_ok && r == 0u) {                     // (nb > n: the caller's bound on the lengths was wrong)
+            a.out_len[blk] = 0;
+            a.status[blk] = nb < 5u ? HDLZ_E_SHORT_INPUT : HDLZ_E_BAD_PARAM;
+        }
+        const uint32_t nrem = lane_ok ? nb - min(p_run, nb) : 0u; // positions of the block from this run on
         const uint32_t nrem_m2 = nrem - 2u;
         // -------------------------------------------------------------- 1. stage: every lane loads its own run
         __syncthreads();
         {
             uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
             if (nrem != 0u) {
-                const uint8_t* src = a.in + blk * a.in_pitch + p_run;
-                v0 = *reinterpret_cast<const uint4*>(src);                    // in_pitch % 16 == 0: whole 16-B pieces are readable
-                if (nrem > 16u) v1 = *reinterpret_cast<const uint4*>(src + 16);
+                const uint8_t* src = a.in + boff + p_run;
+                if (!ragged) {
+                    v0 = *reinterpret_cast<const uint4*>(src);                // in_pitch % 16 == 0: whole 16-B pieces are readable
+                    if (nrem > 16u) v1 = *reinterpret_cast<const uint4*>(src + 16);
+                } else {
+                    // any alignment: aligned dwords that hold valid bytes only, re-aligned with v_alignbyte
+                    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
+                    const uint32_t* q = reinterpret_cast<const uint32_t*>(src - mis);
+                    const uint32_t nd = (min(nrem, (uint32_t)RUN) + mis + 3u) >> 2;      // dwords with valid bytes (<= 9)
+                    uint32_t dwd[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) dwd[k] = (uint32_t)k < nd ? q[k] : 0u;
+                    v0.x = alignbyte(dwd[1], dwd[0], mis); v0.y = alignbyte(dwd[2], dwd[1], mis);
+                    v0.z = alignbyte(dwd[3], dwd[2], mis); v0.w = alignbyte(dwd[4], dwd[3], mis);
+                    v1.x = alignbyte(dwd[5], dwd[4], mis); v1.y = alignbyte(dwd[6], dwd[5], mis);
+                    v1.z = alignbyte(dwd[7], dwd[6], mis); v1.w = alignbyte(dwd[8], dwd[7], mis);
+                }
                 // bytes at or beyond N must read as zero
                 uint32_t* vv = reinterpret_cast<uint32_t*>(&v0);
                 uint32_t* ww = reinterpret_cast<uint32_t*>(&v1);
@@ -314,7 +342,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const uint32_t blk_bits = (uint32_t)__shfl((int)incl, (int)last_lane, 64) - before_blk;
             uint32_t total = 0;
             if (lane_ok && r == 0u) {
-                uint32_t s1 = 1u, s2 = n;
+                uint32_t s1 = 1u, s2 = nb;
                 for (uint32_t k = 0; k < Rb; k++) { s1 += lds.ad[0][first_lane + k]; s2 += lds.ad[1][first_lane + k]; }
                 s1 %= ADLER_MOD; s2 %= ADLER_MOD;
                 const uint32_t end_bits = 19u + blk_bits;

@@ -50,6 +50,8 @@ class Engine(object):
             if max_len is None:
                 max_len = ilen if in_off is None else int((in_off[1:] - in_off[:-1]).max().item()) if nb else 0
             out_pitch = pitch_for(max_len)
+        if in_off is not None and max_len is not None:
+            ilen = max_len               # ragged: upper bound on the block lengths (lets the library pack small blocks)
         if out is None:
             out = torch.empty((nb, out_pitch), dtype=torch.uint8, device=d_in.device)
         out_len = torch.empty(nb, dtype=torch.int32, device=d_in.device)

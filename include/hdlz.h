@@ -14,7 +14,9 @@
  *     retains caller memory; all work is enqueued asynchronously on `stream` (a hipStream_t
  *     passed as void*; NULL = the default stream);
  *   - block b of a batch is d_in[in_off[b] .. in_off[b+1]) when d_in_off != NULL, otherwise
- *     d_in[b*in_pitch .. b*in_pitch + in_len);
+ *     d_in[b*in_pitch .. b*in_pitch + in_len); with d_in_off, hdlz_compress_batch takes in_len as an optional
+ *     upper bound on the block lengths (0 = unknown): a bound <= 1024 lets it pack several small blocks per wave
+ *     (a block longer than a stated bound gets HDLZ_E_BAD_PARAM in its status word);
  *   - output of block b goes to d_out + b*out_pitch; out_pitch % 4 == 0 and d_out 4-byte
  *     aligned (16 recommended); d_out_len[b] receives the byte count (the reference's final
  *     o_oprogress, deflate.py:814 / :1554), d_status[b] one of HDLZ_OK / HDLZ_E_*;

@@ -304,6 +304,38 @@ def test_compress_small_blocks_packed_kernel(engine, oracle):
         assert zlib.decompress(ho[B - 1, :hl[B - 1]].tobytes()) == h[B - 1, :n].tobytes()
 
 
+def test_compress_small_ragged_blocks_packed_kernel(engine, oracle):
+    """ragged batches of small blocks (in_off, any alignment) with a stated length bound take the packed kernel too:
+    every block against the oracle, incl. blocks shorter than 5 bytes (SHORT_INPUT), empty blocks, a leading
+    misalignment, and a block that violates the stated bound (BAD_PARAM in its status word only)"""
+    import torch
+    rng = np.random.default_rng(21)
+    for maxlen, B, cw, mm, mis in [(40, 3000, 32, 10, 0), (300, 5000, 32, 10, 3), (700, 2000, 16, 5, 1), (1024, 1500, 32, 10, 7),
+                                   (33, 4000, 5, 10, 2)]:
+        lens = rng.integers(0, maxlen + 1, size=B)
+        lens[:8] = [0, 1, 4, 5, 6, maxlen, maxlen, 31]
+        total = int(lens.sum())
+        nsym = int(rng.choice([2, 4, 26, 256]))
+        data = (rng.integers(0, nsym, size=total, dtype=np.uint8) + (0 if nsym == 256 else 97)).astype(np.uint8)
+        flat = np.concatenate([np.zeros(mis, np.uint8), data, np.zeros(64, np.uint8)])
+        off = (np.concatenate([[0], np.cumsum(lens)]) + mis).astype(np.int64)
+        d_in, d_off = torch.from_numpy(flat).cuda(), torch.from_numpy(off).cuda()
+        out, ol, st = engine.compress_batch(d_in, in_off=d_off, cwindow=cw, maxmatch=mm)       # engine passes max(len) as the bound
+        torch.cuda.synchronize()
+        ho, hl, hs = out.cpu().numpy(), ol.cpu().numpy(), st.cpu().numpy()
+        ro, rl, rs = oracle.compress_batch(flat, off.astype(np.uint64), cw, mm, out_pitch=ho.shape[1], nthreads=8)
+        assert (hs == rs).all(), (maxlen, np.nonzero(hs != rs)[0][:5], hs[hs != rs][:5], rs[hs != rs][:5])
+        assert (hl == rl).all(), (maxlen, int((hl != rl).sum()))
+        mask = np.arange(ho.shape[1])[None, :] < rl[:, None]
+        assert ((ho == ro) | ~mask).all(), maxlen
+    # a wrong bound: only the offending block reports it
+    lens = np.array([100, 200, 50], dtype=np.int64)
+    flat = np.concatenate([rng.integers(97, 100, size=350, dtype=np.uint8), np.zeros(64, np.uint8)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    out, ol, st = engine.compress_batch(torch.from_numpy(flat).cuda(), in_off=torch.from_numpy(off).cuda(), max_len=128)
+    assert st.cpu().tolist() == [0, 8, 0] and int(ol[1]) == 0
+
+
 def test_compress_misaligned_inputs(engine, oracle):
     import torch
     from hdl_deflate_amd.data import family_bytes
