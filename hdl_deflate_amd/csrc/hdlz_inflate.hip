@@ -189,6 +189,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
 #define HDLZ_FAIL(code) do { status = (code); out_len = 0; active = false; } while (0)
 #define HDLZ_BITPOS() (8u * ip - bc)
 
+    bool any_stored = false;    // wave-uniform: some lane is inside a stored block (set by the slow path, which is where they start)
     for (uint32_t o = 0;; ++o) {
         // ------------------------------------------------------------ 0. input refill (uniform control flow)
         {
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
                 fbn = 0;
                 if (distance >= FAR_BUF_MIN) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
             }
+            any_stored = any_stored || (__ballot(active && srem != 0u) != 0ull);
         }
         if (__ballot(active) == 0ull) break;
 
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
         bool wrote = false;        // this lane put a byte into the ring in this iteration
         uint32_t byte = lit;
         bool stored_done = false;
-        if (__ballot(active && srem != 0u) != 0ull) {              // stored COPY (deflate.py:1603-1616): rare, uniform branch
+        if (any_stored) {                                          // stored COPY (deflate.py:1603-1616): rare, uniform branch
             if (active && srem != 0u) {
                 HDLZ_REFILL();
                 if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize) { HDLZ_FAIL(HDLZ_E_NO_EOF); }
@@ -351,12 +353,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
             ring8[ring_addr(o, lane)] = (uint8_t)byte;
             wrote = true;
         }
-        if (__ballot(stored_done) != 0ull) {                       // a stored block just ended (deflate.py:1617-1626)
+        if (any_stored) {                                          // a stored block may just have ended (deflate.py:1617-1626)
             if (active && stored_done) {
                 if ((int32_t)(HDLZ_BITPOS() >> 3) >= isize) { HDLZ_FAIL(HDLZ_E_NO_EOF); }
                 else if (final_) { out_len = o + 1u; active = false; }
                 else need_header = true;
             }
+            any_stored = __ballot(active && srem != 0u) != 0ull;    // leave stored mode when the last such block ended
         }
 
         // ------------------------------------------------------------ 3. flush 64 bytes per stream every 64 iterations
