@@ -198,9 +198,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
                 // loads complete in order: a request with `after` LDS-DMA instructions issued behind it has landed once at
                 // most `after` loads are outstanding; wait for the youngest request that is consumed now, no further
                 const uint32_t after = issued - myissue;
-                if (__ballot(need && after < 1u) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (__ballot(need && after < 2u) != 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                if (__ballot(need && after < 2u) == 0ull) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the usual case first
+                else if (__ballot(need && after < 1u) == 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 bool dma = false;
                 if (need) {
                     bb |= (uint64_t)inq[lane] << bc; bc += 32u; ip += 4u;
