@@ -56,9 +56,11 @@ class Engine(object):
             out = torch.empty((nb, out_pitch), dtype=torch.uint8, device=d_in.device)
         out_len = torch.empty(nb, dtype=torch.int32, device=d_in.device)
         status = torch.empty(nb, dtype=torch.int32, device=d_in.device)
-        if in_off is None and nb <= self.FEW_BLOCKS and ilen >= self.LARGE_BLOCK and pitch % 16 == 0:
-            # a handful of large blocks: one wave per block would leave the GPU idle (a 1 MiB block is 5.5 ms on a
-            # wave, 0.06 ms spread over the GPU), so each block goes through the single-stream path in turn
+        if in_off is None and ilen >= self.LARGE_BLOCK and pitch % 16 == 0 and nb * self.STREAM_CALL_S < ilen / 180e6:
+            # a few large blocks: one wave per block would leave the GPU idle (a 1 MiB block is 5.5 ms on a wave, 0.06 ms
+            # spread over the GPU), so each block goes through the single-stream path in turn.  The estimate: a stream
+            # call costs ~50 us end to end (ten dependent kernels; side streams do not help, the host launch rate is the limit:
+            # 64 x 1 MiB 3.1 ms, 256 x 1 MiB 12.8 ms measured) against N / 180 MB/s for a single wave.
             flat = d_in.reshape(-1)
             work = torch.empty((self.lib.hdlz_stream_work_bytes(ilen) + 7) // 8, dtype=torch.int64, device=d_in.device)
             for b in range(nb):
@@ -76,7 +78,7 @@ class Engine(object):
 
     # -- STARTC for ONE large stream, spread over the whole GPU (same bytes as compress_batch with one block)
     STREAM_MIN = 1 << 14          # measured crossover with the single-wave batch path: ~8 KiB
-    FEW_BLOCKS, LARGE_BLOCK = 64, 1 << 18     # compress_batch: this few blocks of at least this size -> stream path per block
+    LARGE_BLOCK, STREAM_CALL_S = 1 << 18, 50e-6   # compress_batch: few large blocks -> stream path per block (see there)
 
     def compress_stream(self, d_in, n, cwindow=32, maxmatch=10, out=None, work=None):
         """d_in: flat uint8 device tensor, readable up to n rounded up to 16.

@@ -174,10 +174,10 @@ def test_compress_stream_multiwave_vs_oracle(engine, oracle):
     # a handful of large blocks through compress_batch = the stream path per block: same bytes as the batch kernel
     few = d[:5 << 19].view(5, 1 << 19)
     fo, fl, fs = engine.compress_batch(few)
-    saved = engine.FEW_BLOCKS
-    engine.FEW_BLOCKS = 0
+    saved = engine.STREAM_CALL_S
+    engine.STREAM_CALL_S = 1e9                       # never: one wave per block
     bo, bl_, bs_ = engine.compress_batch(few)
-    engine.FEW_BLOCKS = saved
+    engine.STREAM_CALL_S = saved
     torch.cuda.synchronize()
     assert int((fs != 0).sum()) == 0 and torch.equal(fl, bl_)
     for b in range(5):
