@@ -129,25 +129,41 @@ int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t
     return HDLZ_OK;
 }
 
-size_t hdlz_stream_work_bytes(size_t in_len) {
-    return in_len >= 0x80000000ull ? 0 : hdlz::stream_work_bytes((uint32_t)in_len);
+size_t hdlz_stream_work_bytes(size_t in_len) { return hdlz_streams_work_bytes(in_len, 1); }
+
+size_t hdlz_streams_work_bytes(size_t in_len, uint64_t nblocks) {
+    if (in_len >= 0x80000000ull || nblocks == 0 || nblocks > 0xFFFFFFFFull) return 0;
+    if (((in_len + 2047) / 2048) * nblocks >= 0x80000000ull) return 0;          // tile indices are 32-bit
+    return hdlz::stream_work_bytes((uint32_t)in_len, (uint32_t)nblocks);
 }
 
 int hdlz_compress_stream(const uint8_t* d_in, uint32_t in_len, int cwindow, int maxmatch, uint8_t* d_out,
                          uint64_t out_cap, uint32_t* d_out_len, uint32_t* d_status, void* d_work,
                          size_t work_bytes, void* stream) {
+    return hdlz_compress_streams(d_in, 0, in_len, 1, cwindow, maxmatch, d_out, out_cap, d_out_len, d_status, d_work,
+                                 work_bytes, stream);
+}
+
+int hdlz_compress_streams(const uint8_t* d_in, uint64_t in_pitch, uint32_t in_len, uint64_t nblocks, int cwindow,
+                          int maxmatch, uint8_t* d_out, uint64_t out_pitch, uint32_t* d_out_len, uint32_t* d_status,
+                          void* d_work, size_t work_bytes, void* stream) {
     if (cwindow < 1 || cwindow > 256) return fail_param("cwindow must be in [1,256]");
     if (maxmatch != 5 && maxmatch != 10) return fail_param("maxmatch must be 5 (MATCH10=False) or 10 (MATCH10=True)");
+    if (nblocks == 0) return HDLZ_OK;
     if (!d_in || !d_out || !d_out_len || !d_status || !d_work) return fail_param("null device pointer");
     if (in_len >= 0x80000000u) return fail_param("in_len too large");
     if (reinterpret_cast<uintptr_t>(d_out) & 3u) return fail_param("d_out must be 4-byte aligned");
+    if (nblocks > 1 && (out_pitch & 3u)) return fail_param("out_pitch must be a multiple of 4");
     if (reinterpret_cast<uintptr_t>(d_work) & 7u) return fail_param("d_work must be 8-byte aligned");
-    if (work_bytes < hdlz::stream_work_bytes(in_len)) return fail_param("d_work smaller than hdlz_stream_work_bytes(in_len)");
+    const size_t need_work = hdlz_streams_work_bytes(in_len, nblocks);
+    if (need_work == 0) return fail_param("in_len x nblocks too large for one call");
+    if (work_bytes < need_work) return fail_param("d_work smaller than hdlz_streams_work_bytes(in_len, nblocks)");
     int rc = check_device();
     if (rc != HDLZ_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t need = ((uint64_t)hdlz::out_bound(in_len) + 3u) & ~3ull;
-    if (in_len < 5u || out_cap < need) {            // R0 / capacity: same per-stream status as the batch call
+    if (in_len < 5u || out_pitch < need) {            // R0 / capacity: same per-stream status as the batch call
+        if (nblocks > 1) return fail_param(in_len < 5u ? "in_len < 5" : "out_pitch smaller than hdlz_out_bound(in_len)");
         // (a kernel, not hipMemsetD32Async: 32-bit memsets did not survive HIP-graph capture on this stack)
         hipLaunchKernelGGL(k_set_result, dim3(1), dim3(1), 0, st, d_out_len, d_status,
                            in_len < 5u ? (uint32_t)HDLZ_E_SHORT_INPUT : (uint32_t)HDLZ_E_OUT_CAPACITY);
@@ -155,7 +171,8 @@ int hdlz_compress_stream(const uint8_t* d_in, uint32_t in_len, int cwindow, int 
         if (e != hipSuccess) return fail_hip(e, "launch k_set_result");
         return HDLZ_OK;
     }
-    hipError_t e = hdlz::launch_compress_stream(d_in, in_len, cwindow, maxmatch, d_out, out_cap, d_out_len, d_status, d_work, st);
+    hipError_t e = hdlz::launch_compress_streams(d_in, in_pitch, in_len, (uint32_t)nblocks, cwindow, maxmatch, d_out, out_pitch,
+                                                 d_out_len, d_status, d_work, st);
     if (e != hipSuccess) return fail_hip(e, "launch k_stream_*");
     return HDLZ_OK;
 }

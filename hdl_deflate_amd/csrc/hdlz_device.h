@@ -53,9 +53,10 @@ hipError_t launch_compress(const CompressArgs& a, hipStream_t stream);
 hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int ncu);
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t stream);
 hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream, bool all);
-size_t stream_work_bytes(uint32_t n);
-hipError_t launch_compress_stream(const uint8_t* in, uint32_t n, int cwindow, int maxmatch, uint8_t* out, uint64_t out_cap,
-                                  uint32_t* out_len, uint32_t* status, void* work, hipStream_t stream);
+size_t stream_work_bytes(uint32_t n, uint32_t nblocks);
+hipError_t launch_compress_streams(const uint8_t* in, uint64_t in_pitch, uint32_t n, uint32_t nblocks, int cwindow, int maxmatch,
+                                   uint8_t* out, uint64_t out_pitch, uint32_t* out_len, uint32_t* status, void* work,
+                                   hipStream_t stream);
 hipError_t launch_compact(const uint8_t* rows, uint64_t pitch, const uint32_t* len, const uint64_t* off,
                           uint64_t nblocks, uint8_t* archive, hipStream_t stream);
 

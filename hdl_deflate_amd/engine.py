@@ -56,19 +56,15 @@ class Engine(object):
             out = torch.empty((nb, out_pitch), dtype=torch.uint8, device=d_in.device)
         out_len = torch.empty(nb, dtype=torch.int32, device=d_in.device)
         status = torch.empty(nb, dtype=torch.int32, device=d_in.device)
-        if in_off is None and ilen >= self.LARGE_BLOCK and pitch % 16 == 0 and nb * self.STREAM_CALL_S < ilen / 180e6:
-            # a few large blocks: one wave per block would leave the GPU idle (a 1 MiB block is 5.5 ms on a wave, 0.06 ms
-            # spread over the GPU), so each block goes through the single-stream path in turn.  The estimate: a stream
-            # call costs ~50 us end to end (ten dependent kernels; side streams do not help, the host launch rate is the limit:
-            # 64 x 1 MiB 3.1 ms, 256 x 1 MiB 12.8 ms measured) against N / 180 MB/s for a single wave.
-            flat = d_in.reshape(-1)
-            work = torch.empty((self.lib.hdlz_stream_work_bytes(ilen) + 7) // 8, dtype=torch.int64, device=d_in.device)
-            for b in range(nb):
-                rc = self.lib.hdlz_compress_stream(flat.data_ptr() + b * pitch, ilen, cwindow, maxmatch,
-                                                   out.data_ptr() + b * out_pitch, out_pitch,
-                                                   out_len.data_ptr() + 4 * b, status.data_ptr() + 4 * b,
-                                                   work.data_ptr(), work.numel() * 8, self._stream())
-                self._check(rc, "hdlz_compress_stream")
+        if in_off is None and ilen >= self.LARGE_BLOCK and pitch % 16 == 0 and nb <= self.MANY_WAVES and \
+                self.lib.hdlz_streams_work_bytes(ilen, nb) != 0:
+            # few large blocks: one wave per block (hdlz_compress_batch) would leave the GPU idle (a 1 MiB block is 5.5 ms
+            # on a wave); all tiles of all blocks go through the stream passes together instead (same bytes)
+            work = torch.empty((self.lib.hdlz_streams_work_bytes(ilen, nb) + 7) // 8, dtype=torch.int64, device=d_in.device)
+            rc = self.lib.hdlz_compress_streams(d_in.data_ptr(), pitch, ilen, nb, cwindow, maxmatch, out.data_ptr(), out_pitch,
+                                                out_len.data_ptr(), status.data_ptr(), work.data_ptr(),
+                                                work.numel() * 8, self._stream())
+            self._check(rc, "hdlz_compress_streams")
             return out, out_len, status
         rc = self.lib.hdlz_compress_batch(d_in.data_ptr(), off_ptr, pitch, ilen, nb, cwindow, maxmatch,
                                           out.data_ptr(), out_pitch, out_len.data_ptr(), status.data_ptr(),
@@ -78,7 +74,8 @@ class Engine(object):
 
     # -- STARTC for ONE large stream, spread over the whole GPU (same bytes as compress_batch with one block)
     STREAM_MIN = 1 << 14          # measured crossover with the single-wave batch path: ~8 KiB
-    LARGE_BLOCK, STREAM_CALL_S = 1 << 18, 50e-6   # compress_batch: few large blocks -> stream path per block (see there)
+    LARGE_BLOCK, MANY_WAVES = 1 << 16, 1200   # compress_batch: up to this many blocks of at least this size -> stream passes
+                                              # (a wave does ~180 MB/s, the stream passes ~250 GB/s: crossover ~1400 blocks)
 
     def compress_stream(self, d_in, n, cwindow=32, maxmatch=10, out=None, work=None):
         """d_in: flat uint8 device tensor, readable up to n rounded up to 16.

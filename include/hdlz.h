@@ -126,6 +126,15 @@ int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t
  *   d_work          device scratch of hdlz_stream_work_bytes(in_len) bytes, 8-byte aligned
  * Returns HDLZ_OK when the launches were queued; *d_out_len, *d_status as in hdlz_compress_batch. */
 size_t hdlz_stream_work_bytes(size_t in_len);
+
+/* The same for nblocks blocks of in_len bytes each (block b at d_in + b*in_pitch -> d_out + b*out_pitch, one stream per
+ * block as in hdlz_compress_batch): all tiles of all blocks share the passes.  For batches of a few to a few thousand
+ * LARGE blocks (>= 256 KiB), where one wave per block (hdlz_compress_batch) leaves the GPU idle.  in_len >= 5 and
+ * out_pitch >= hdlz_out_bound(in_len) rounded up to 4 are parameter errors here (not per-block statuses). */
+size_t hdlz_streams_work_bytes(size_t in_len, uint64_t nblocks);
+int hdlz_compress_streams(const uint8_t* d_in, uint64_t in_pitch, uint32_t in_len, uint64_t nblocks, int cwindow,
+                          int maxmatch, uint8_t* d_out, uint64_t out_pitch, uint32_t* d_out_len, uint32_t* d_status,
+                          void* d_work, size_t work_bytes, void* stream);
 int hdlz_compress_stream(const uint8_t* d_in, uint32_t in_len, int cwindow, int maxmatch, uint8_t* d_out,
                          uint64_t out_cap, uint32_t* d_out_len, uint32_t* d_status, void* d_work,
                          size_t work_bytes, void* stream);

@@ -171,17 +171,21 @@ def test_compress_stream_multiwave_vs_oracle(engine, oracle):
     d = torch.cat([d, torch.zeros(16, dtype=torch.uint8, device="cuda")])
     z = check(d, 1 << 24, 32, 10, "lmax")
     assert zlib.decompress(z) == d[:1 << 24].cpu().numpy().tobytes()
-    # a handful of large blocks through compress_batch = the stream path per block: same bytes as the batch kernel
-    few = d[:5 << 19].view(5, 1 << 19)
-    fo, fl, fs = engine.compress_batch(few)
-    saved = engine.STREAM_CALL_S
-    engine.STREAM_CALL_S = 1e9                       # never: one wave per block
-    bo, bl_, bs_ = engine.compress_batch(few)
-    engine.STREAM_CALL_S = saved
-    torch.cuda.synchronize()
-    assert int((fs != 0).sum()) == 0 and torch.equal(fl, bl_)
-    for b in range(5):
-        assert torch.equal(fo[b, :int(fl[b])], bo[b, :int(bl_[b])])
+    # batches of large blocks through compress_batch = hdlz_compress_streams (all tiles of all blocks share the passes):
+    # same bytes as one wave per block, incl. blocks that are not a multiple of the tile size and match-saturated blocks
+    for nbk, nbytes, src_t in ((5, 1 << 19, d), (37, (1 << 18) + 1234, d), (3, 300000, dense[2])):
+        few = torch.zeros((nbk, (nbytes + 15) // 16 * 16), dtype=torch.uint8, device="cuda")
+        few[:, :nbytes] = src_t[:nbk * nbytes].view(nbk, nbytes)
+        fo, fl, fs = engine.compress_batch(few, in_len=nbytes)
+        saved = engine.MANY_WAVES
+        engine.MANY_WAVES = 0                          # never: one wave per block
+        bo, bl_, bs_ = engine.compress_batch(few, in_len=nbytes)
+        engine.MANY_WAVES = saved
+        torch.cuda.synchronize()
+        assert int((fs != 0).sum()) == 0 and int((bs_ != 0).sum()) == 0 and torch.equal(fl, bl_), (nbk, nbytes)
+        for b in range(nbk):
+            assert torch.equal(fo[b, :int(fl[b])], bo[b, :int(bl_[b])]), (nbk, nbytes, b)
+        assert fo[0, :int(fl[0])].cpu().numpy().tobytes() == oracle.compress(few[0, :nbytes].cpu().numpy().tobytes())[1]
     # engine.compress_bytes routes large streams here, small ones through the batch kernel: same answer
     blob = d[:70000].cpu().numpy().tobytes()
     st, zz = engine.compress_bytes(blob)

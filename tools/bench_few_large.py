@@ -3,12 +3,12 @@ import torch
 from hdl_deflate_amd import Engine
 from hdl_deflate_amd.data import make_text_blocks
 e = Engine()
-for nb, mib in ((4, 16), (64, 1), (256, 1), (512, 0.25), (1024, 0.25)):
+for nb, mib in ((4, 16), (64, 1), (256, 1), (512, 0.25), (1024, 0.25), (256, 0.0625), (1024, 0.0625), (1200, 0.0625)):
     n = int(mib * (1 << 20))
     d = make_text_blocks(nb, n, "cuda", seed=1)
     res = {}
-    for name, few in (("stream-path", 0.0), ("one-wave-per-block", 1e9)):
-        e.STREAM_CALL_S = few
+    for name, few in (("stream-path", 1 << 30), ("one-wave-per-block", 0)):
+        e.MANY_WAVES = few
         fn = lambda: e.compress_batch(d)
         o, ol, st = fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
