@@ -106,6 +106,24 @@ def main():
                     if hbs[k] != 0 or hbl[k] != lens[b] or hb[k, :lens[b]].tobytes() != flat[off[b]:off[b + 1]].tobytes():
                         print("ZLIB-INFLATE MISMATCH it=%d seed=%d k=%d n=%d status %d len %d" % (it, a.seed, k, lens[b], hbs[k], hbl[k]))
                         return 1
+        # now and then: a fixed-pitch batch of a few LARGE blocks cut from the same data (hdlz_compress_streams: all tiles of
+        # all blocks share the stream passes), every block against the oracle
+        if it % 8 == 5 and total >= 200000 and (cw <= 64 or total <= 400000):
+            nbk = int(rng.integers(2, 12))
+            nbytes_ = int(rng.integers(65536, max(65537, min(total // nbk, 700000))))
+            if nbytes_ * nbk <= total and nbytes_ >= 65536:
+                pitch_ = (nbytes_ + 15) // 16 * 16
+                big = torch.zeros((nbk, pitch_), dtype=torch.uint8, device="cuda")
+                big[:, :nbytes_] = d_in[mis:mis + nbk * nbytes_].view(nbk, nbytes_)
+                bo, bl2, bs2 = eng.compress_batch(big, in_len=nbytes_, cwindow=cw, maxmatch=mm)
+                torch.cuda.synchronize()
+                hb2, hl2, hs2 = bo.cpu().numpy(), bl2.cpu().numpy(), bs2.cpu().numpy()
+                foff = (np.arange(nbk + 1, dtype=np.uint64) * nbytes_)
+                ro2, rl2, rs2 = O.compress_batch(flat[mis:mis + nbk * nbytes_], foff, cw, mm, out_pitch=hb2.shape[1], nthreads=16)
+                mask2 = np.arange(hb2.shape[1])[None, :] < rl2[:, None]
+                if not ((hs2 == rs2).all() and (hl2 == rl2).all() and ((hb2 == ro2) | ~mask2).all()):
+                    print("STREAMS MISMATCH it=%d seed=%d nbk=%d n=%d cw=%d mm=%d kind=%d" % (it, a.seed, nbk, nbytes_, cw, mm, kind))
+                    return 1
         blocks += B
         nbytes += total
     print("fuzz OK: %d batches, %d blocks, %.1f MiB, seed %d" % (it, blocks, nbytes / 2 ** 20, a.seed))
