@@ -28,6 +28,7 @@ struct __attribute__((aligned(16))) SmallLds {
     uint32_t ad[2][64];                       // per-lane Adler partials, summed per block by its first lane
 };
 
+template <bool RAGGED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_compress_small(CompressArgs a) {
     constexpr int NCH = 1;
     __shared__ SmallLds lds;
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint32_t cw4 = 4u * (uint32_t)a.cwindow;
     const uint32_t kmax = (uint32_t)a.maxmatch;
     const uint32_t n = a.in_len;                                  // block length (fixed pitch) or its upper bound (ragged)
-    const bool ragged = a.in_off != nullptr;
+    constexpr bool ragged = RAGGED;                                // (a template parameter: the uniform path stays as lean as it was)
     const uint32_t Rb = (n + 31u) >> 5;                           // runs (lanes) per block
     const uint32_t G = 64u / Rb;                                  // blocks per wave-tile
     const uint32_t Wb = (out_bound(n) + 3u) >> 2;                 // bit-buffer words per block
@@ -367,13 +368,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
+template __global__ void k_compress_small<false>(CompressArgs);
+template __global__ void k_compress_small<true>(CompressArgs);
+
 hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int ncu) {
     const uint32_t Rb = (a.in_len + 31u) >> 5;
     const uint64_t G = 64u / Rb;
     uint64_t groups = (a.nblocks + G - 1u) / G;
     uint64_t grid = (uint64_t)ncu * 64u;
     if (grid > groups) grid = groups;
-    hipLaunchKernelGGL(k_compress_small, dim3((unsigned)grid), dim3(64), 0, stream, a);
+    if (a.in_off) hipLaunchKernelGGL(k_compress_small<true>, dim3((unsigned)grid), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(k_compress_small<false>, dim3((unsigned)grid), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 
