@@ -28,6 +28,14 @@ def load_golden(name):
         return json.load(f)
 
 
+def large_vectors():
+    """tests/golden/compress_large_vectors.json (oracle/gen_golden_large.py) decoded: [(vector dict, input, output)]"""
+    import base64
+    import zlib
+    g = load_golden("compress_large_vectors.json")
+    return [(v, zlib.decompress(base64.b64decode(v["in_b64z"])), base64.b64decode(v["out_b64"])) for v in g["vectors"]]
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """the CPU oracle (checker only; see oracle/hdlz_oracle.c header)"""

@@ -53,6 +53,23 @@ def test_compress_golden_vectors_bit_exact(engine):
             assert zlib.decompress(o).hex() == v["in_hex"]
 
 
+def test_compress_large_golden_vectors_bit_exact(engine):
+    """multi-tile / wide-window vectors recorded from the executed reference (16..64 KiB, CWINDOW 32/64/256): through
+    the one-wave-per-block kernels (ragged batch) AND through the multi-wave stream passes"""
+    import torch
+    from conftest import large_vectors
+    by_cfg = {}
+    for v, data, ref in large_vectors():
+        by_cfg.setdefault((v["cwindow"], v["maxmatch"]), []).append((v, data, ref))
+    for (cw, mm), vs in sorted(by_cfg.items()):
+        outs, st = _ragged(torch, engine, [d for _, d, _ in vs], cwindow=cw, maxmatch=mm)
+        for (v, data, ref), o, s in zip(vs, outs, st):
+            assert s == 0 and o == ref, (cw, mm, v["name"])
+        for v, data, ref in vs:
+            s, o = engine.compress_bytes(data, cwindow=cw, maxmatch=mm)        # >= 16 KiB: hdlz_compress_stream
+            assert s == 0 and o == ref, ("stream", cw, mm, v["name"])
+
+
 def test_compress_random_vs_oracle(engine, oracle):
     import torch
     r = random.Random(2026)

@@ -52,6 +52,23 @@ def test_compress_golden_all_configs(oracle):
     assert {(32, 10), (32, 5), (64, 10), (256, 10), (256, 5), (16, 10), (48, 10)} <= configs
 
 
+def test_compress_large_golden_multi_tile(oracle):
+    """16..64 KiB vectors from the executed reference (oracle/gen_golden_large.py): multi-tile blocks at every window
+    width, incl. the four 64 KiB family blocks whose lengths SURVEY.md 8(c) could only derive"""
+    from conftest import large_vectors
+    vs = large_vectors()
+    assert len(vs) >= 24
+    seen = set()
+    for v, data, ref in vs:
+        assert len(data) == v["n"] and sha16(data) == v["in_sha256_16"] and sha16(ref) == v["out_sha256_16"]
+        rc, out = oracle.compress(data, v["cwindow"], v["maxmatch"])
+        assert rc == oracle.OK and out == ref, (v["config"], v["name"])
+        seen.add((v["cwindow"], v["maxmatch"], v["n"] >= 65536))
+    assert {(32, 10, True), (64, 10, True), (256, 10, False), (256, 5, False), (32, 5, False), (64, 5, False)} <= seen
+    lens = {v["name"]: v["out_len"] for v, _, _ in vs if v["config"] == "cw32_m10"}
+    assert [lens["fam%d_65536" % f] for f in (1, 2, 3, 4)] == [21131, 33322, 69124, 27087]     # SURVEY.md 8(c)
+
+
 def test_survey_known_answers(oracle):
     for data, hexout in SURVEY_KAT:
         rc, out = oracle.compress(data)
