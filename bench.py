@@ -2,18 +2,26 @@
 """bench.py -- the hot path on BASELINE.json's metric: MB/s of uncompressed input consumed by
 STARTC (CWINDOW=32, MATCH10, static tree), whole job, plus the compression ratio.
 
-Workload at N=1 = BASELINE configs[1]: 2^20 x 2 KiB synthetic blocks per GPU (families 1..4 of
-test_deflate.py:38-66, every block distinct, 2 GiB >> 256 MB Infinity Cache), resident in HBM before
-the timed region.  A "step" = one hdlz_compress_batch launch over all of the rank's blocks (+ for
-N>1 the RCCL all-gather of the per-block output lengths).  Weak scaling: per-GPU work
-is fixed, value = bytes all ranks consumed / max-over-ranks time.
+--gpus 1 (default).  Headline = BASELINE configs[1]: 2^20 x 2 KiB synthetic blocks (families 1..4 of
+  test_deflate.py:38-66, every block distinct, 2 GiB >> 256 MB Infinity Cache), resident in HBM before the
+  timed region; a "step" = one hdlz_compress_batch launch over all blocks.  The same JSON line carries a
+  "secondary" array with the other single-GPU configurations of BASELINE.json, each with its own roofline:
+    * configs[4] shape on one GPU: the WHOLE 8 GiB job of 131 072 x 64 KiB blocks, CWINDOW=32 (north_star's
+      target shape; its ms_per_step is T(1) of the strong-scaling curve below)
+    * configs[2]: CWINDOW=64 + MATCH10 on 64 KiB blocks of Zipf pseudo-English (enwik8 is not obtainable:
+      no network), next to CWINDOW=32 on the same data (ratio vs throughput)
+    * configs[3]: inflate of 2^20 stock-zlib Z_FIXED streams, DYNAMIC=False semantics, every stream checked
+--gpus N > 1 (one rank per GPU, launched by torch.distributed.run).  BASELINE configs[4] as written: the 8 GiB
+  job of 131 072 x 64 KiB blocks is split into contiguous shards of B/N blocks (shard.shard_range); a step =
+  the rank's hdlz_compress_batch launch + the RCCL all-gather of the uint32[B/N] output lengths
+  (SURVEY 8(e)); STRONG scaling: total work is fixed, value = 8 GiB / max-over-ranks step time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (k_compress): algorithmic bytes per launch (N_in + N_out + 4 per block,
-                  SURVEY 8(d)) / average launch duration measured with HIP events on the launch stream,
-                  against the 8 TB/s HBM3E peak
-  cpu_baseline -- the CPU oracle (a port: oracle/hdlz_oracle.c) timed on this box's host cores on a
-                  bounded sample of the same blocks (rank 0, N=1 only)
+  roofline     -- dominant kernel: algorithmic bytes per launch (N_in + N_out + 4 per block) /
+                  average launch duration measured with HIP events on the launch stream, against the 8 TB/s
+                  HBM3E peak
+  cpu_baseline -- the CPU oracle (a port: oracle/hdlz_oracle.c) timed on this box's host cores on a bounded
+                  sample of the same blocks (rank 0, N=1 only)
 """
 import argparse
 import json
@@ -26,6 +34,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+CFG5_BLOCKS, CFG5_BLOCK = 131072, 65536          # BASELINE configs[4]: 8 GiB of 64 KiB blocks
 
 
 def measured_traffic(key):
@@ -38,40 +47,191 @@ def measured_traffic(key):
         return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=1 << 20, help="blocks per GPU")
-    ap.add_argument("--block-size", type=int, default=2048)
-    ap.add_argument("--cwindow", type=int, default=32)
-    ap.add_argument("--maxmatch", type=int, default=10)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
-    ap.add_argument("--verify", type=int, default=256, help="blocks checked against zlib outside the timed region")
-    ap.add_argument("--data", default="families", choices=["families", "text"],
-                    help="families = test_deflate.py families 1-4 (BASELINE configs[1]); text = Zipf pseudo-English "
-                         "(enwik8 stand-in for configs[2]: enwik8 cannot be fetched, no network)")
-    ap.add_argument("--zlib-strategy", default="fixed", choices=["fixed", "default"],
-                    help="inflate mode: fixed = Z_FIXED streams (configs[3]); default = stock zlib streams with "
-                         "dynamic trees (exercises the second pass k_inflate_dyn, SURVEY 8(f) rank 1)")
-    ap.add_argument("--mode", default="compress", choices=["compress", "inflate"],
-                    help="compress = BASELINE metric (default); inflate = configs[3] side metric (1 GPU)")
-    a = ap.parse_args()
-    if a.mode == "inflate":
-        return bench_inflate(a)
+def kname_for(cwindow):
+    return "k_compress<%d>" % (1 if cwindow <= 32 else 2 if cwindow <= 64 else 8)
 
+
+def roofline(kname, algo_bytes, k_ms, traffic_key=None, extra=None):
+    k_avg = sum(k_ms) / len(k_ms)
+    achieved = algo_bytes / (k_avg * 1e-3) / 1e9
+    traffic, tsrc = measured_traffic(traffic_key) if traffic_key else (None, None)
+    r = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg, 4), "kernel_ms_min": round(min(k_ms), 4),
+         "launches_timed": len(k_ms)}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def time_steps(torch, dist, step, steps, warmup, world, cdev):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize; max over ranks"""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, last
+
+
+def kernel_ms(torch, launch, n):
+    """duration of single launches: HIP events on the launch stream (torch's current stream = the stream handed to the C-ABI)"""
+    evs = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    return sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+
+
+def zlib_spot_check(torch, d_in, d_out, ol, count):
+    import zlib
+    B = d_in.shape[0]
+    idx = torch.linspace(0, B - 1, min(count, B)).long().unique().to(d_in.device)
+    hi, ho, hl = d_in[idx].cpu().numpy(), d_out[idx].cpu().numpy(), ol[idx].cpu().numpy()
+    for k in range(len(idx)):
+        assert zlib.decompress(ho[k, :hl[k]].tobytes()) == hi[k].tobytes(), "zlib round trip failed"
+
+
+def run_compress(torch, eng, d_in, cwindow, maxmatch, steps, warmup, verify, d_out=None):
+    """single-GPU compress measurement of one workload -> dict (wall step time, kernel durations, sizes)"""
+    from hdl_deflate_amd.constants import pitch_for
+    B, n = d_in.shape
+    pitch = pitch_for(n)
+    if d_out is None:
+        d_out = torch.empty((B, pitch), dtype=torch.uint8, device=d_in.device)
+
+    def step():
+        return eng.compress_batch(d_in, cwindow=cwindow, maxmatch=maxmatch, out=d_out, out_pitch=pitch)
+
+    dt, (out, ol, st) = time_steps(torch, None, step, steps, warmup, 1, None)
+    k_ms = kernel_ms(torch, step, max(3, steps))
+    assert int((st != 0).sum().item()) == 0, "blocks failed"
+    out_bytes = int(ol.to(torch.int64).sum().item())
+    if verify:
+        zlib_spot_check(torch, d_in, d_out, ol, verify)
+    return {"dt": dt, "k_ms": k_ms, "in_bytes": B * n, "out_bytes": out_bytes, "B": B, "n": n, "d_out": d_out, "ol": ol}
+
+
+def compress_entry(name, workload, r, cwindow, maxmatch, steps, warmup, traffic_key=None):
+    algo = r["in_bytes"] + r["out_bytes"] + 4 * r["B"]
+    return {"name": name, "metric": "compress_input_throughput (CWINDOW=%d, MATCH10=%s, static tree)" % (cwindow, maxmatch == 10),
+            "value": round(r["in_bytes"] / (r["dt"] / steps) / 1e6, 1), "unit": "MB/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(r["dt"] / steps * 1e3, 4), "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload, "cwindow": cwindow, "maxmatch": maxmatch, "blocks": r["B"], "block_bytes": r["n"]},
+            "compression_ratio_out_over_in": round(r["out_bytes"] / r["in_bytes"], 4),
+            "roofline": roofline(kname_for(cwindow), algo, r["k_ms"], traffic_key)}
+
+
+# ------------------------------------------------------------------------------------------------ N = 1
+def main_single(a):
+    import torch
+    import hdl_deflate_amd
+    from hdl_deflate_amd.data import make_blocks, make_text_blocks
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    eng = hdl_deflate_amd.Engine(dev)
+    B, n = a.blocks, a.block_size
+    if a.data == "text":
+        d_in = make_text_blocks(B, n, dev, seed=0)
+    else:
+        d_in = make_blocks(B, n, dev, seed=0)
+    torch.cuda.synchronize()
+    r = run_compress(torch, eng, d_in, a.cwindow, a.maxmatch, a.steps, a.warmup, a.verify)
+
+    # achievable HBM ceiling on this box: a plain device copy of the same input (read + write)
+    cp = torch.empty_like(d_in)
+    cp.copy_(d_in)
+    torch.cuda.synchronize()
+    c_ms = kernel_ms(torch, lambda: cp.copy_(d_in), 5)
+    copy_gbs = 2.0 * d_in.numel() / (sum(c_ms) / len(c_ms) * 1e-3) / 1e9
+    del cp
+
+    value = r["in_bytes"] / (r["dt"] / a.steps) / 1e6
+    algo = r["in_bytes"] + r["out_bytes"] + 4 * B
+    kname = kname_for(a.cwindow)
+    rl = roofline(kname, algo, r["k_ms"], "%s|blocks=%d|block=%d|data=%s" % (kname, B, n, a.data),
+                  {"device_copy_GBps": round(copy_gbs, 1),
+                   "note": "bytes = N_in + N_out + 4 per block; this path is VALU-issue bound, not HBM bound (DESIGN.md)"})
+    rl["frac_of_device_copy"] = round(rl["achieved"] / copy_gbs, 4)
+    res = {
+        "metric": "compress_input_throughput (CWINDOW=%d, MATCH10=%s, static tree)" % (a.cwindow, a.maxmatch == 10),
+        "value": round(value, 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(r["dt"] / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": ("BASELINE configs[1]: %d x %d B blocks, families 1-4 (test_deflate.py:38-66), "
+                                "distinct blocks, HBM-resident" % (B, n)) if a.data == "families" else
+                               ("%d x %d B blocks of Zipf pseudo-English (enwik8 stand-in), HBM-resident" % (B, n)),
+                   "cwindow": a.cwindow, "maxmatch": a.maxmatch, "blocks_per_gpu": B, "block_bytes": n,
+                   "parallelism": "single GPU; --gpus N block-shards BASELINE configs[4] (8 GiB of 64 KiB blocks) over N ranks"},
+        "per_gpu_MBps": round(value, 1),
+        "compression_ratio_out_over_in": round(r["out_bytes"] / r["in_bytes"], 4),
+        "roofline": rl,
+    }
+    if a.cpu_seconds > 0:
+        res["cpu_baseline"] = cpu_baseline(d_in, n, a)
+    del r, d_in
+    torch.cuda.empty_cache()
+
+    if a.secondary:
+        sec = []
+        # -- configs[4] shape, whole job on one GPU (= T(1) of the strong-scaling curve of --gpus N)
+        d5 = make_blocks(a.cfg5_blocks, CFG5_BLOCK, dev, seed=0)
+        r5 = run_compress(torch, eng, d5, 32, 10, a.steps, a.warmup, 16)
+        sec.append(compress_entry("configs[4]-shape, 1 GPU", "BASELINE configs[4] on ONE GPU: %d x 64 KiB blocks (%.1f GiB), families 1-4, "
+                                  "CWINDOW=32 -- north_star's target block shape; ms_per_step = T(1) of `bench.py --gpus N`"
+                                  % (a.cfg5_blocks, a.cfg5_blocks * CFG5_BLOCK / 2 ** 30), r5, 32, 10, a.steps, a.warmup,
+                                  "k_compress<1>|blocks=%d|block=65536|data=families" % a.cfg5_blocks))
+        d_out5 = r5["d_out"]
+        del r5, d5
+        # -- configs[2]: CWINDOW=64 + MATCH10 on 64 KiB text blocks, next to CWINDOW=32 on the same data
+        dt_ = make_text_blocks(a.text_blocks, CFG5_BLOCK, dev, seed=0)
+        d_out_t = d_out5[:a.text_blocks]
+        r64 = run_compress(torch, eng, dt_, 64, 10, a.steps, a.warmup, 16, d_out=d_out_t)
+        e64 = compress_entry("configs[2]", "BASELINE configs[2]: CWINDOW=64 + MATCH10 on %d x 64 KiB blocks of Zipf pseudo-English "
+                             "(enwik8 stand-in: enwik8 cannot be fetched, no network)" % a.text_blocks, r64, 64, 10, a.steps, a.warmup,
+                             "k_compress<2>|blocks=%d|block=65536|data=text" % a.text_blocks)
+        r32 = run_compress(torch, eng, dt_, 32, 10, a.steps, a.warmup, 0, d_out=d_out_t)
+        e64["same_data_cwindow32"] = {"value": round(r32["in_bytes"] / (r32["dt"] / a.steps) / 1e6, 1), "unit": "MB/s",
+                                      "compression_ratio_out_over_in": round(r32["out_bytes"] / r32["in_bytes"], 4)}
+        sec.append(e64)
+        del r64, r32, dt_, d_out_t, d_out5
+        torch.cuda.empty_cache()
+        # -- configs[3]: inflate
+        sec.append(bench_inflate(a, eng, cpu=False))
+        res["secondary"] = sec
+    print(json.dumps(res), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------ N > 1
+def main_sharded(a):
+    """BASELINE configs[4]: strong scaling of the 8 GiB job over N ranks, RCCL all-gather of the lengths"""
     import torch
     import torch.distributed as dist
     import hdl_deflate_amd
-    from hdl_deflate_amd.data import make_blocks, make_text_blocks
-    from hdl_deflate_amd.shard import gather_lengths
+    from hdl_deflate_amd.data import make_blocks
+    from hdl_deflate_amd.shard import LengthGather, shard_range
     from hdl_deflate_amd.constants import pitch_for
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, "launch with torchrun --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus)
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus)
     ndev = torch.cuda.device_count()
     backend = os.environ.get("HDLZ_BENCH_BACKEND", "nccl")   # "gloo": functional check of the N>1 flow on fewer GPUs
     if backend == "nccl":
@@ -79,135 +239,61 @@ def main():
     local = min(local, ndev - 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
 
     eng = hdl_deflate_amd.Engine(dev)
-    B, n = a.blocks, a.block_size
-    nblocks_total = B * world
-    # rank r owns the contiguous block range [r*B, (r+1)*B) of the job (weak scaling)
-    if a.data == "text":
-        d_in = make_text_blocks(B, n, dev, seed=rank)
-    else:
-        d_in = make_blocks(B, n, dev, seed=0, first_block=rank * B)
+    total, n = a.cfg5_blocks, CFG5_BLOCK
+    b0, b1 = shard_range(total, rank, world)               # contiguous shard of the job
+    B = b1 - b0
+    d_in = make_blocks(B, n, dev, seed=0, first_block=b0)  # the same blocks the 1-GPU run holds at [b0, b1)
     pitch = pitch_for(n)
     d_out = torch.empty((B, pitch), dtype=torch.uint8, device=dev)
+    lg = LengthGather(total, dev)
     torch.cuda.synchronize()
 
     def step():
-        out, ol, st = eng.compress_batch(d_in, cwindow=a.cwindow, maxmatch=a.maxmatch, out=d_out, out_pitch=pitch)
-        all_len = gather_lengths(ol, nblocks_total) if world > 1 else ol
-        return ol, st, all_len
+        out, ol, st = eng.compress_batch(d_in, cwindow=32, maxmatch=10, out=d_out, out_pitch=pitch)
+        return ol, st, lg.gather(ol)                       # the ONLY exchange step: uint32[B/N] lengths
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
+    dt, (ol, st, all_len) = time_steps(torch, dist, step, a.steps, a.warmup, world, cdev)
+    k_ms = kernel_ms(torch, lambda: eng.compress_batch(d_in, cwindow=32, maxmatch=10, out=d_out, out_pitch=pitch), max(3, a.steps))
+    g_ms = kernel_ms(torch, lambda: lg.gather(ol), max(3, a.steps)) if backend == "nccl" else [0.0]
 
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ol, st, all_len = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    cdev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # ---- kernel-only duration of the dominant kernel: HIP events on the launch stream (= torch's
-    # current stream, which is the stream handed to the C-ABI), separate launches
-    evs = []
-    for _ in range(max(3, a.steps)):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        eng.compress_batch(d_in, cwindow=a.cwindow, maxmatch=a.maxmatch, out=d_out, out_pitch=pitch)
-        e1.record()
-        evs.append((e0, e1))
-    torch.cuda.synchronize()
-    k_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-    k_avg = sum(k_ms) / len(k_ms)
-
-    # ---- achievable HBM ceiling on this box: a plain device copy of the same input (read + write)
-    cp = torch.empty_like(d_in)
-    cp.copy_(d_in)
-    torch.cuda.synchronize()
-    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    c0.record()
-    for _ in range(5):
-        cp.copy_(d_in)
-    c1.record()
-    torch.cuda.synchronize()
-    copy_gbs = 2.0 * d_in.numel() * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-    del cp
-
-    # ---- checks outside the timed region
-    bad = int((st != 0).sum().item())
-    out_bytes_local = int(ol.to(torch.int64).sum().item())
-    in_bytes_local = B * n
-    tot = torch.tensor([out_bytes_local, in_bytes_local, bad], dtype=torch.int64, device=cdev)
-    if world > 1:
-        dist.all_reduce(tot)
-        assert int(all_len.to(torch.int64).sum().item()) == int(tot[0].item())
+    tot = torch.tensor([int(ol.to(torch.int64).sum().item()), B * n, int((st != 0).sum().item())], dtype=torch.int64, device=cdev)
+    dist.all_reduce(tot)
     out_bytes, in_bytes, bad = (int(x) for x in tot.tolist())
     assert bad == 0, "%d blocks failed" % bad
+    assert all_len.numel() == total and int(all_len.to(torch.int64).sum().item()) == out_bytes, "gathered lengths disagree"
+    assert torch.equal(all_len[b0:b1].to(ol.device), ol.to(torch.int32)), "own shard not at its place in the gathered lengths"
     if rank == 0 and a.verify:
-        import zlib
-        idx = torch.linspace(0, B - 1, a.verify).long().unique()
-        hi = d_in[idx.to(dev)].cpu().numpy()
-        ho = d_out[idx.to(dev)].cpu().numpy()
-        hl = ol[idx.to(dev)].cpu().numpy()
-        for k in range(len(idx)):
-            assert zlib.decompress(ho[k, :hl[k]].tobytes()) == hi[k].tobytes(), "zlib round trip failed"
-
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    ms_per_step = dt / a.steps * 1e3
-    value = in_bytes / (dt / a.steps) / 1e6                      # MB/s, whole job
-    algo_bytes = in_bytes_local + out_bytes_local + 4 * B        # per launch (one GPU)
-    achieved = algo_bytes / (k_avg * 1e-3) / 1e9
-    kname = "k_compress<%d>" % (1 if a.cwindow <= 32 else 2 if a.cwindow <= 64 else 8)
-    traffic, tsrc = measured_traffic("%s|blocks=%d|block=%d|data=%s" % (kname, B, n, a.data))
-    res = {
-        "metric": "compress_input_throughput (CWINDOW=%d, MATCH10=%s, static tree)" % (a.cwindow, a.maxmatch == 10),
-        "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[1]: %d x %d B blocks per GPU, families 1-4 (test_deflate.py:38-66), "
-                                "distinct blocks, HBM-resident" % (B, n)) if a.data == "families" else
-                               ("%d x %d B blocks per GPU of Zipf pseudo-English (enwik8 stand-in), HBM-resident" % (B, n)),
-                   "cwindow": a.cwindow, "maxmatch": a.maxmatch, "blocks_per_gpu": B, "block_bytes": n,
-                   "parallelism": "block-shard x%d (length all-gather only)" % world},
-        "per_gpu_MBps": round(value / world, 1),
-        "compression_ratio_out_over_in": round(out_bytes / in_bytes, 4),
-        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_source": tsrc, "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg, 4),
-                     "kernel_ms_min": round(k_ms[0], 4), "device_copy_GBps": round(copy_gbs, 1),
-                     "frac_of_device_copy": round(achieved / copy_gbs, 4),
-                     "note": "bytes = N_in + N_out + 4 per block; this path is VALU-issue bound, not HBM bound "
-                             "(DESIGN.md)"},
-    }
-    if world == 1 and a.cpu_seconds > 0:
-        res["cpu_baseline"] = cpu_baseline(d_in, n, a)
-    print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        zlib_spot_check(torch, d_in, d_out, ol, min(a.verify, 32))
+    if rank == 0:
+        algo = B * n + int(ol.to(torch.int64).sum().item()) + 4 * B
+        value = in_bytes / (dt / a.steps) / 1e6
+        res = {"metric": "compress_input_throughput (CWINDOW=32, MATCH10=True, static tree)", "value": round(value, 1),
+               "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[4]: %d x 64 KiB blocks (%.1f GiB total, fixed), families 1-4, contiguous "
+                                      "shards of %d blocks per rank, HBM-resident" % (total, total * n / 2 ** 30, B),
+                          "cwindow": 32, "maxmatch": 10, "blocks_total": total, "blocks_per_gpu": B, "block_bytes": n,
+                          "parallelism": "block-shard x%d; one all-gather of uint32[%d] lengths per step over %s (no payload "
+                                         "crosses xGMI)" % (world, B, "RCCL" if backend == "nccl" else backend)},
+               "per_gpu_MBps": round(value / world, 1),
+               "compression_ratio_out_over_in": round(out_bytes / in_bytes, 4),
+               "length_allgather_ms_avg": round(sum(g_ms) / len(g_ms), 4),
+               "roofline": roofline("k_compress<1>", algo, k_ms, None, {"note": "rank 0's shard; per-GPU figure"}),
+               "note": "T(1) of this job is the ms_per_step of the 'configs[4]-shape, 1 GPU' entry of `bench.py --gpus 1`"}
+        print(json.dumps(res), flush=True)
+    dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------------------------ inflate
 def _zfixed_chunk(args):
     import zlib
     buf, n, strat = args
@@ -215,10 +301,10 @@ def _zfixed_chunk(args):
     for k in range(0, len(buf), n):
         co = zlib.compressobj(strategy=zlib.Z_FIXED if strat == "fixed" else zlib.Z_DEFAULT_STRATEGY, wbits=15)
         out.append(co.compress(buf[k:k + n]) + co.flush())
-    return out
+    return b"".join(out), [len(z) for z in out]
 
 
-def bench_inflate(a):
+def bench_inflate(a, eng=None, cpu=True):
     """BASELINE configs[3]: B stock-zlib Z_FIXED streams (wbits=15) over 2 KiB blocks of families 1/2/4
     (family 3 would make zlib emit stored blocks, which the DYNAMIC=False reference mis-decodes), made on
     the host cores with stock zlib outside the timed region; DYNAMIC=False semantics
@@ -230,19 +316,21 @@ def bench_inflate(a):
     from hdl_deflate_amd.data import make_blocks
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    eng = hdl_deflate_amd.Engine(dev)
-    B, n = a.blocks, a.block_size
+    if eng is None:
+        eng = hdl_deflate_amd.Engine(dev)
+    B, n = a.streams, a.stream_block
     d_plain = make_blocks(B, n, dev, seed=4, families=(1, 2, 4))
     host = d_plain.cpu().numpy()
     nproc = min(os.cpu_count() or 1, 64)
-    per = (B + nproc - 1) // nproc
+    per = (B + nproc * 4 - 1) // (nproc * 4)
     with mp.get_context("fork").Pool(nproc) as pool:
         parts = pool.map(_zfixed_chunk, [(host[k:k + per].tobytes(), n, a.zlib_strategy) for k in range(0, B, per)])
-    streams = [z for p in parts for z in p]
-    lens = np.fromiter((len(z) for z in streams), dtype=np.int64, count=B)
+    del host
+    lens = np.fromiter((l for _, ls in parts for l in ls), dtype=np.int64, count=B)
     off = np.zeros(B + 1, np.int64)
     np.cumsum(lens, out=off[1:])
-    flat = np.frombuffer(b"".join(streams) + bytes(64), dtype=np.uint8)
+    flat = np.frombuffer(b"".join(p for p, _ in parts) + bytes(64), dtype=np.uint8)
+    del parts
     d_in = torch.from_numpy(flat.copy()).to(dev)
     d_off = torch.from_numpy(off).to(dev)
     d_out = torch.empty((B, n), dtype=torch.uint8, device=dev)
@@ -251,45 +339,28 @@ def bench_inflate(a):
     def step():
         return eng.inflate_batch(d_in, in_off=d_off, out_pitch=n, flags=flags, out=d_out)
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out, ol, st = step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    evs = []
-    for _ in range(max(3, a.steps)):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        step()
-        e1.record()
-        evs.append((e0, e1))
-    torch.cuda.synchronize()
-    k_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-    k_avg = sum(k_ms) / len(k_ms)
+    dt, (out, ol, st) = time_steps(torch, None, step, a.steps, a.warmup, 1, None)
+    k_ms = kernel_ms(torch, step, max(3, a.steps))
     assert int((st != 0).sum().item()) == 0 and int((ol != n).sum().item()) == 0
     assert torch.equal(d_out, d_plain), "inflate output differs from the original blocks"
     z_bytes, u_bytes = int(off[-1]), B * n
     algo = z_bytes + u_bytes + 4 * B
-    achieved = algo / (k_avg * 1e-3) / 1e9
-    traffic, tsrc = measured_traffic("k_inflate|streams=%d|block=%d" % (B, n))
-    res = {"metric": "inflate_output_throughput (zlib Z_FIXED streams, DYNAMIC=False)" if a.zlib_strategy == "fixed"
+    fixed = a.zlib_strategy == "fixed"
+    res = {"name": "configs[3]",
+           "metric": "inflate_output_throughput (zlib Z_FIXED streams, DYNAMIC=False)" if fixed
            else "inflate_output_throughput (stock zlib streams, dynamic trees, two passes)",
            "value": round(u_bytes / (dt / a.steps) / 1e6, 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": "BASELINE configs[3]: %d zlib %s streams over %d B blocks, families 1/2/4, "
-                                  "HBM-resident" % (B, "Z_FIXED" if a.zlib_strategy == "fixed" else "default-strategy (dynamic trees)", n),
+           "config": {"workload": "BASELINE configs[3]: %d zlib %s streams over %d B blocks, families 1/2/4, every stream "
+                                  "compared with its original block, HBM-resident"
+                                  % (B, "Z_FIXED" if fixed else "default-strategy (dynamic trees)", n),
                       "streams": B, "block_bytes": n},
            "input_MBps": round(z_bytes / (dt / a.steps) / 1e6, 1),
            "compression_ratio_out_over_in": round(z_bytes / u_bytes, 4),
-           "roofline": {"bound": "hbm", "kernel": "k_inflate", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "traffic_source": tsrc, "algorithmic_bytes_per_launch": algo, "kernel_ms_avg": round(k_avg, 4),
-                        "kernel_ms_min": round(k_ms[0], 4)}}
-    if a.cpu_seconds > 0:
+           "roofline": roofline("k_inflate" if fixed else "k_inflate + k_inflate_dyn", algo, k_ms,
+                                "k_inflate|streams=%d|block=%d" % (B, n))}
+    if cpu and a.cpu_seconds > 0:
         from oracle import oracle as O
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         S = min(B, 1 << 19)
@@ -299,7 +370,7 @@ def bench_inflate(a):
         assert (s2 == 0).all()
         res["cpu_baseline"] = {"value": round(S * n / dtc / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
                                "sample": "first %d streams, oracle/hdlz_oracle.c inflate, %d threads, %.2f s" % (S, cores, dtc)}
-    print(json.dumps(res), flush=True)
+    return res
 
 
 def cpu_baseline(d_in, n, a):
@@ -341,7 +412,41 @@ def cpu_baseline(d_in, n, a):
             "sample": "first %d blocks of the same workload (%.1f MiB), oracle/hdlz_oracle.c, %d threads, %.2f s"
                       % (S, sample.size / 2 ** 20, cores, dt),
             "single_thread_MBps": round(rate1 / 1e6, 1),
+            "note": "a stated baseline, not a target: the GPU/CPU ratio says nothing about kernel quality (roofline.frac does)",
             "reference_constants": {"fpga_100MHz_3cyc_per_byte_MBps": 33, "standin_sim_KBps": "0.5-1 (BASELINE.md)"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=1 << 20, help="headline: blocks (N=1)")
+    ap.add_argument("--block-size", type=int, default=2048)
+    ap.add_argument("--cwindow", type=int, default=32)
+    ap.add_argument("--maxmatch", type=int, default=10)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
+    ap.add_argument("--verify", type=int, default=256, help="blocks checked against zlib outside the timed region")
+    ap.add_argument("--data", default="families", choices=["families", "text"],
+                    help="families = test_deflate.py families 1-4 (BASELINE configs[1]); text = Zipf pseudo-English")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="N=1: headline only (skip the configs[4]-shape / configs[2] / configs[3] entries)")
+    ap.add_argument("--cfg5-blocks", type=int, default=CFG5_BLOCKS, help="total 64 KiB blocks of the configs[4] job")
+    ap.add_argument("--text-blocks", type=int, default=16384, help="64 KiB text blocks of the configs[2] entry (1 GiB)")
+    ap.add_argument("--streams", type=int, default=1 << 20, help="inflate: zlib streams (configs[3])")
+    ap.add_argument("--stream-block", type=int, default=2048, help="inflate: plain bytes per stream")
+    ap.add_argument("--zlib-strategy", default="fixed", choices=["fixed", "default"],
+                    help="inflate: fixed = Z_FIXED streams (configs[3]); default = stock zlib streams with dynamic trees "
+                         "(exercises the second pass k_inflate_dyn, SURVEY 8(f) rank 1)")
+    ap.add_argument("--mode", default="compress", choices=["compress", "inflate"],
+                    help="compress = BASELINE metric (default); inflate = only the configs[3] side metric (1 GPU)")
+    a = ap.parse_args()
+    if a.mode == "inflate":
+        print(json.dumps(bench_inflate(a)), flush=True)
+    elif a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        main_sharded(a)
+    else:
+        main_single(a)
 
 
 if __name__ == "__main__":

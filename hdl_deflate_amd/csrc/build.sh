@@ -1,19 +1,28 @@
 #!/bin/bash
 # Builds hdl_deflate_amd/lib/libhdlz.so for gfx950 (cross-compiles without a GPU).
+# A/B builds: HDLZ_VARIANT=name HDLZ_DEFS="-DX=1 ..." build.sh  ->  lib/libhdlz_name.so (own object directory);
+# select it at run time with HDLZ_LIB=hdl_deflate_amd/lib/libhdlz_name.so (see _lib.py, tools/ab.sh).
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../lib"
-mkdir -p "$out" "$here/_obj"
+var="${HDLZ_VARIANT:-}"
+objdir="$here/_obj${var:+_$var}"
+lib="$out/libhdlz${var:+_$var}.so"
+mkdir -p "$out" "$objdir"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${HDLZ_DEFS:-}"
+srcs="hdlz_compress hdlz_compress_small hdlz_compress_stream hdlz_inflate hdlz_inflate_dyn hdlz_compact hdlz_api"
 pids=()
-for f in hdlz_compress hdlz_compress_small hdlz_compress_stream hdlz_inflate hdlz_inflate_dyn hdlz_compact hdlz_api; do
-  src="$here/$f.hip"; obj="$here/_obj/$f.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$here/hdlz_device.h" -nt "$obj" ] || [ "$here/hdlz_compress_common.h" -nt "$obj" ] || [ "$here/../../include/hdlz.h" -nt "$obj" ]; then
+for f in $srcs; do
+  src="$here/$f.hip"; obj="$objdir/$f.o"
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$here/hdlz_device.h" -nt "$obj" ] || [ "$here/hdlz_compress_common.h" -nt "$obj" ] || [ "$here/../../include/hdlz.h" -nt "$obj" ] || [ "${BASH_SOURCE[0]}" -nt "$obj" ]; then
     ( "$HIPCC" $FLAGS -c "$src" -o "$obj" ) &
     pids+=($!)
   fi
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libhdlz.so" "$here/_obj/hdlz_compress.o" "$here/_obj/hdlz_compress_small.o" "$here/_obj/hdlz_compress_stream.o" "$here/_obj/hdlz_inflate.o" "$here/_obj/hdlz_inflate_dyn.o" "$here/_obj/hdlz_compact.o" "$here/_obj/hdlz_api.o"
-echo "built $out/libhdlz.so"
+rc=0
+for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || rc=1; }; done
+[ $rc -eq 0 ] || { echo "compile failed" >&2; exit 1; }
+objs=""; for f in $srcs; do objs="$objs $objdir/$f.o"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$lib" $objs
+echo "built $lib"

@@ -92,7 +92,11 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
                        uint32_t* d_out_len, uint32_t* d_status, void* stream) {
     if (nstreams > 0x7FFFFFFFull * 32) return fail_param("nstreams too large for one launch");
     if (nstreams && (!d_in || !d_out || !d_out_len || !d_status)) return fail_param("null device pointer");
-    if (flags & ~(HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM)) return fail_param("unknown flag");
+    if (flags & ~(HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_ONEBLOCK))
+        return fail_param("unknown flag");
+    // the kernels keep stream lengths and bit positions in 32 bits (8 * length must not wrap)
+    if (!d_in_off && in_len >= 0x10000000u) return fail_param("in_len too large (streams are limited to 256 MiB - 1)");
+    if (!d_in_off && nstreams > 1 && in_pitch < in_len) return fail_param("in_pitch < in_len");
     if ((flags & HDLZ_INFLATE_LANE_PER_STREAM) && (flags & HDLZ_INFLATE_WAVE_PER_STREAM)) return fail_param("contradictory mapping flags");
     if ((out_pitch & 3u) || (reinterpret_cast<uintptr_t>(d_out) & 3u)) return fail_param("d_out / out_pitch must be 4-byte aligned");
     int rc = check_device();

@@ -1,11 +1,17 @@
-// hdlz_compress_common.h -- constants and device helpers shared by the compress kernels
-// (hdlz_compress.hip: one block per wave, any size; hdlz_compress_small.hip: several small blocks per wave-tile)
+// hdlz_compress_common.h -- constants, device helpers and THE TILE PHASES shared by all compress kernels
+// (hdlz_compress.hip: one block per wave, any size; hdlz_compress_small.hip: several small blocks per wave-tile;
+//  hdlz_compress_stream.hip: one large stream / a few large blocks spread over the whole GPU)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
 
 namespace hdlz {
+
+// waves per SIMD the CWINDOW <= 32 kernels are register-capped for (96 VGPRs at 5)
+#ifndef HDLZ_W1
+#define HDLZ_W1 5
+#endif
 
 constexpr int RUN = 32;             // positions per lane
 constexpr int TILE = 64 * RUN;      // 2048 positions per wave-tile
@@ -29,6 +35,8 @@ struct __attribute__((aligned(16))) WaveLds {
 // fence for the instruction scheduler + value fences: keep independent phases from being overlapped
 // (that blew the VGPR budget to 239 and spilled ~200 SGPR lane masks in the first version)
 #define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// a comment in the ISA at a phase boundary (tools/phase_count.py counts the instructions between two marks)
+#define HDLZ_MARK(name) do { PHASE_FENCE(); asm volatile("; @@PHASE " name ::: "memory"); PHASE_FENCE(); } while (0)
 template <int N>
 __device__ __forceinline__ void pin(uint32_t (&a)[N]) {
 #pragma unroll
@@ -86,6 +94,302 @@ __device__ __forceinline__ uint32_t dist_entry(uint32_t d) {
 }
 // 7-bit code of length symbol 254+m (no extra bits for m <= 10)
 __device__ __forceinline__ uint32_t length_code(uint32_t m) { return __builtin_bitreverse32(m - 2u) >> 25; }
+
+// =====================================================================================================================
+// The tile phases.  ONE source for all compress kernels: k_compress (one block per wave, hdlz_compress.hip),
+// k_compress_small (several small blocks per wave-tile, hdlz_compress_small.hip) and the multi-wave stream passes
+// k_stream_tails / _xfer / _tile (hdlz_compress_stream.hip).  A wave-tile is 2048 positions, lane l owns the RUN of 32
+// consecutive positions [32l, 32l+32); `in` is the staged input (byte index = position - tile start + halo).
+// Everything is forced inline: the phases are straight-line code over register arrays, and the value fences (pin) and
+// scheduling barriers (PHASE_FENCE) inside them are what keeps hipcc from overlapping the phases.
+// =====================================================================================================================
+
+// ---- the lane's own 32 bytes + 16 bytes of look-ahead
+__device__ __forceinline__ void load_own(const uint32_t* in, uint32_t run_dw, uint32_t (&ow)[12]) {
+    const uint4 v0 = *reinterpret_cast<const uint4*>(&in[run_dw]);
+    const uint4 v1 = *reinterpret_cast<const uint4*>(&in[run_dw + 4]);
+    const uint4 v2 = *reinterpret_cast<const uint4*>(&in[run_dw + 8]);
+    ow[0] = v0.x; ow[1] = v0.y; ow[2] = v0.z; ow[3] = v0.w;
+    ow[4] = v1.x; ow[5] = v1.y; ow[6] = v1.z; ow[7] = v1.w;
+    ow[8] = v2.x; ow[9] = v2.y; ow[10] = v2.z; ow[11] = v2.w;
+}
+
+// ---- phase 2, match search (R3/R4; the reference's matcher3 x CWINDOW + first-set-bit pick, deflate.py:407-421, :975-994):
+// best[i] = 4 * (nearest distance d in [1, 32*NCH] with x[p-d .. p-d+2] == x[p .. p+2]) for own position i; a value > 128 * NCH
+// (NCH > 1: 0xFFFFFFFF) = none.
+// Keys K = (3-byte string) << 8 | 4 * window index: Ko - Kc (u32 wrap) is 4*distance (<= 128) iff the strings are equal and
+// > 256 otherwise, so the MIN over a chunk of 32 candidates is four times the nearest matching distance: one v_sub and
+// half a v_min3 per compare.  Windows > 32 iterate chunks of 32 distances far -> near.
+// (The lane's own bytes are loaded here and die with the keys: the 32 own keys + 32 running minima + the candidate
+// bytes are the register peak of the whole kernel; later phases reload the 48 bytes from LDS, three ds_read_b128.)
+template <int NCH>
+__device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw, uint32_t (&best)[RUN]) {
+    uint32_t ko[RUN];
+    uint32_t ow0;
+    {
+        uint32_t ow[12];
+        load_own(in, run_dw, ow);
+        static_for<0, RUN>([&](auto I) { constexpr int i = decltype(I)::value; ko[i] = key3<i>(ow, (uint32_t)(4 * (i + 32))); });
+        ow0 = ow[0];
+    }
+    pin(ko); asm volatile("" : "+v"(ow0));
+    PHASE_FENCE();
+#pragma unroll
+    for (int i = 0; i < RUN; i++) best[i] = 0xFFFFFFFFu;
+
+#pragma unroll 1
+    for (int k = NCH - 1; k >= 0; k--) {                      // far chunks first, nearer ones overwrite
+        uint32_t cd[17];                                      // 64 candidate positions + 2 bytes
+        const uint32_t cdw = run_dw - 8u * (uint32_t)(k + 1);
+        {
+            const uint4 c0 = *reinterpret_cast<const uint4*>(&in[cdw]);
+            const uint4 c1 = *reinterpret_cast<const uint4*>(&in[cdw + 4]);
+            cd[0] = c0.x; cd[1] = c0.y; cd[2] = c0.z; cd[3] = c0.w;
+            cd[4] = c1.x; cd[5] = c1.y; cd[6] = c1.z; cd[7] = c1.w;
+            if (NCH == 1) {
+                cd[8] = ow0;                                  // candidate 31 needs the first own bytes
+#pragma unroll
+                for (int j = 9; j < 17; j++) cd[j] = 0;      // unused: own keys double as candidates
+            } else {
+                const uint4 c2 = *reinterpret_cast<const uint4*>(&in[cdw + 8]);
+                const uint4 c3 = *reinterpret_cast<const uint4*>(&in[cdw + 12]);
+                cd[8] = c2.x; cd[9] = c2.y; cd[10] = c2.z; cd[11] = c2.w;
+                cd[12] = c3.x; cd[13] = c3.y; cd[14] = c3.z; cd[15] = c3.w;
+                cd[16] = in[cdw + 16];
+            }
+        }
+        uint32_t m[RUN];
+#pragma unroll
+        for (int i = 0; i < RUN; i++) m[i] = 0xFFFFFFFFu;
+        // candidate-major order: two candidate keys live at a time, 32 running minima
+        static_for<0, 63>([&](auto J) {
+            constexpr int j = decltype(J)::value;             // handles candidates j and j+1 (j even)
+            if constexpr ((j & 1) == 0) {
+                uint32_t kc0, kc1;
+                if constexpr (NCH == 1 && j >= 32) {          // own position j-32 IS candidate j (same tag 4j)
+                    // pin in place: without it the scheduler precomputes all ~500 own-vs-own differences
+                    asm volatile("" : "+v"(ko[j - 32]), "+v"(ko[j - 31]));
+                    kc0 = ko[j - 32];
+                    kc1 = ko[j - 31];
+                } else {
+                    kc0 = key3<j>(cd, (uint32_t)(4 * j));
+                    kc1 = key3<j + 1>(cd, (uint32_t)(4 * (j + 1)));
+                }
+                // own index i pairs with candidates j in [i, i+31]
+                static_for<0, RUN>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    constexpr bool use0 = (j >= i) && (j <= i + 31);
+                    constexpr bool use1 = (j + 1 >= i) && (j + 1 <= i + 31);
+                    if constexpr (use0 && use1) m[i] = umin3(m[i], ko[i] - kc0, ko[i] - kc1);
+                    else if constexpr (use0) m[i] = min(m[i], ko[i] - kc0);
+                    else if constexpr (use1) m[i] = min(m[i], ko[i] - kc1);
+                });
+                if constexpr ((j & 7) == 6) { pin(m); PHASE_FENCE(); }
+            }
+        });
+        // NCH == 1: the raw minimum IS the result (>= 256 = "none"; make_tokens' position test rejects those values)
+#pragma unroll
+        for (int i = 0; i < RUN; i++) {
+            if (NCH == 1) best[i] = m[i];
+            else if (m[i] < 256u) best[i] = m[i] + 128u * (uint32_t)k;
+        }
+    }
+}
+
+// ---- phase 3, eligibility + extension (R3/R5; SEARCHF / SEARCH10, deflate.py:899-964, :1018-1062):
+// tok[i] = (len-1) << 16 | LUT byte offset of the token  (len-1 = 0 for a literal).
+//   lds_run  byte offset of the run in `in`;  nrem = positions of the block from the run's first position on (0 = none)
+//   p4_run   4 * min(block-relative position of the run, 32 * NCH): with that clamp `d4 <= p4_run + 4i` is at once R4's
+//            d <= p, the "a candidate exists" test AND -- for NCH == 1, where best[] holds raw minima -- the rejection of
+//            the >= 256 values that stand for "no match" (p4_run + 4i <= 128 + 124)
+//   FULLWIN  cwindow == 32 * NCH: every distance the search can return is inside the window (no cw4 compare)
+// Measured and dropped (profiles/r02_tokens_ab.txt): the candidate's 8 bytes from ONE unaligned ds_read_b64 -- 8 VALU
+// instructions fewer per position, but gfx950's LDS splits unaligned 64-bit reads: LDS busy 57 -> 82 %, 1 % slower.
+template <int NCH, bool FULLWIN>
+__device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run, uint32_t (&ow)[12], uint32_t (&best)[RUN],
+                                            uint32_t cw4, uint32_t kmax, uint32_t p4_run, uint32_t nrem, uint32_t (&tok)[RUN]) {
+    pin(best); pin(ow);
+    PHASE_FENCE();
+    const uint32_t nrem_m5 = nrem - 5u;                       // (wraps when nrem < 5: then nothing is eligible)
+    const uint32_t kmax_m3 = kmax - 3u;
+    // token word of a match of length len = l3 + 3 at distance d:  (len-1) << 16 | LUT offset
+    //   CWINDOW <= 32: LUT [len-3][d-1] -> l3 * (65536 + 128) + 4d + K;   wider: LUT [d-1] -> l3 * 65536 + 4d + K
+    const uint32_t tok_k = (2u << 16) + LUT_MATCH_BYTE - 4u;
+    const uint32_t tok_mul = NCH == 1 ? 65664u : 65536u;
+    static_for<0, RUN>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const uint32_t d4 = best[i];
+        // R3: 1 <= p <= N-5;  R4: d <= min(CWINDOW, p)   ('&': no short-circuit branches)
+        bool ok = (d4 <= p4_run + (uint32_t)(4 * i)) & (nrem >= (uint32_t)(i + 5));
+        if constexpr (!FULLWIN) ok = ok & (d4 <= cw4);
+        // distance for the gather; for "no match" any in-range value will do (the result is discarded)
+        const uint32_t d = (NCH == 1) ? ((d4 & 0xFCu) >> 2) : (ok ? (d4 >> 2) : 1u);
+        // R5: common prefix of x[p+3..p+10] and x[p-d+3..p-d+10]
+        const uint32_t q = lds_run + (uint32_t)(i + 3) - d;   // byte offset of the candidate's 4th byte
+        const uint32_t qd = q >> 2;
+        const uint32_t a0 = in[qd], a1 = in[qd + 1], a2 = in[qd + 2];
+        const uint32_t clo = alignbyte(a1, a0, q), chi = alignbyte(a2, a1, q);      // (v_alignbyte takes the shift from q[1:0])
+        constexpr int o = i + 3;
+        uint32_t olo, ohi;
+        if constexpr ((o & 3) == 0) { olo = ow[o >> 2]; ohi = ow[(o >> 2) + 1]; }
+        else { olo = alignbyte(ow[(o >> 2) + 1], ow[o >> 2], o & 3); ohi = alignbyte(ow[(o >> 2) + 2], ow[(o >> 2) + 1], o & 3); }
+        // equal low BITS of the two 8-byte windows.  Only 7 bytes can matter (len <= 10): a sentinel in the top bit of
+        // the eighth bounds the count at 63 (-> 7 bytes) and keeps ffbl away from its "no bit set" value
+        const uint32_t zhi = ffbl((chi ^ ohi) | 0x80000000u) | 32u;
+        const uint32_t zb = min(ffbl(clo ^ olo), zhi);           // ffbl(0) = 0xFFFFFFFF: "no difference in the low half"
+        // len - 3 = min(equal bytes, Kmax - 3, N-2-p - 3): a match never covers the last two bytes
+        const uint32_t l3 = umin3(zb >> 3, kmax_m3, nrem_m5 - (uint32_t)i);
+        // literal byte -> LUT offset 4*byte
+        constexpr int bsh = 8 * (i & 3);
+        uint32_t lit;
+        if constexpr (bsh == 0) lit = (ow[i >> 2] << 2) & 0x3FCu;
+        else lit = (ow[i >> 2] >> (bsh - 2)) & 0x3FCu;
+        uint32_t mt;     // l3 * tok_mul + d4 + tok_k  (hipcc folds the C form into a quarter-rate v_mul_lo_u32)
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(mt) : "v"(l3), "s"(tok_mul), "v"(d4 + tok_k));
+        tok[i] = ok ? mt : lit;
+        if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(tok); pin(ow); PHASE_FENCE(); }
+    });
+}
+
+// ---- phase 4a, greedy parse of one run ("di += m / di += 1", deflate.py:960,1008 -- a serial chain in the reference) folded
+// into a TRANSFER FUNCTION "entry skip (0..9) -> exit skip": nibble s of the result = exit skip for entry skip s.
+// Backward pass: E[i] = exit skip if a token starts at local index i; nibbles of P hold E[i+1..i+10].
+__device__ __forceinline__ uint64_t run_transfer(const uint32_t (&tok)[RUN]) {
+    uint64_t P = 0x9876543210ull;
+#pragma unroll
+    for (int i = RUN - 1; i >= 0; i--) {
+        const uint32_t sh = (tok[i] >> 16) * 4u;              // 4 * (len-1)
+        const uint32_t e = (uint32_t)(P >> sh) & 15u;
+        P = (P << 4) | e;
+    }
+    return P;
+}
+
+// ---- phase 4b: compose the 64 run functions across the wave (serial, on the scalar unit).  s: in = entry skip of lane 0,
+// out = exit skip of lane 63; returns this lane's entry skip.
+__device__ __forceinline__ uint32_t chain_skips(uint64_t P, uint32_t lane, uint32_t& s) {
+    const uint32_t plo = (uint32_t)P, phi = (uint32_t)(P >> 32);
+    uint64_t sv[4] = {0, 0, 0, 0};     // entry skips of all 64 lanes, one nibble each (scalar regs)
+    // 4 segments of 16 lanes; the scheduling barriers keep the compiler from hoisting all 128
+    // readlanes to the top (that needed ~260 SGPR spills = v_writelane/v_readlane traffic)
+    static_for<0, 4>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int l = 0; l < 16; l++) {
+            acc |= (uint64_t)s << (4 * l);
+            // NB: readlane returns a signed int -- cast before widening or bit 31 smears into the high half
+            const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, g * 16 + l) << 32) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)plo, g * 16 + l);
+            s = (uint32_t)(f >> (4u * s)) & 15u;
+        }
+        sv[g] = acc;
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    const uint32_t g = lane >> 4;
+    const uint64_t mine = g == 0 ? sv[0] : g == 1 ? sv[1] : g == 2 ? sv[2] : sv[3];
+    return (uint32_t)(mine >> (4u * (lane & 15u))) & 15u;
+}
+
+// ---- phase 5a, token bits (R6/R7; DISTANCE deflate.py:836-882, literal emit :1005-1016) from the per-wave LDS LUTs:
+// code[i] = LUT entry (code | nbits << 27) of every token START, 0 elsewhere; returns the lane's bit count.
+//   c0      this lane's entry skip (a value >= 32 = the lane starts no token at all)
+//   LIMIT   only positions i < nlimit may start a token (padding positions of a packed small block)
+template <int NCH, bool LIMIT>
+__device__ __forceinline__ uint32_t token_codes(const uint8_t* lut8, uint32_t (&tok)[RUN], uint32_t c0, uint32_t nlimit,
+                                                uint32_t (&code)[RUN]) {
+    uint32_t lane_bits = 0;
+    uint32_t c = c0;
+    static_for<0, RUN>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const uint32_t e = *reinterpret_cast<const uint32_t*>(lut8 + (tok[i] & 0xFFFFu));
+        bool start = (c == 0u);
+        if constexpr (LIMIT) start = start & ((uint32_t)i < nlimit);
+        const uint32_t lenm1 = tok[i] >> 16;
+        c = start ? lenm1 : (c - 1u);
+        uint32_t ee = e;
+        if constexpr (NCH != 1)                               // wide windows: [dist] LUT + computed length code
+            ee |= lenm1 ? (__builtin_bitreverse32(lenm1 - 1u) >> 25) : 0u;
+        code[i] = start ? ee : 0u;
+        lane_bits += code[i] >> NB_SHIFT;
+        if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(code); asm volatile("" : "+v"(c), "+v"(lane_bits)); PHASE_FENCE(); }
+    });
+    return lane_bits;
+}
+
+// inclusive wave scan (all 64 lanes must call it)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const uint32_t o = __shfl_up(v, ofs, 64);
+        if (lane >= (uint32_t)ofs) v += o;
+    }
+    return v;
+}
+
+// ---- phase 5b, the bit writer (put / do_flush, deflate.py:535-567): OR every token into the LDS bit buffer at its own
+// bit offset (ds_or_b32), the lane's first token at bit `bp`
+__device__ __forceinline__ void scatter_codes(uint8_t* out8, const uint32_t (&code)[RUN], uint32_t bp) {
+#pragma unroll
+    for (int i = 0; i < RUN; i++) {
+        const uint64_t v = (uint64_t)(code[i] & CODE_MASK) << (bp & 31u);
+        uint32_t* w = reinterpret_cast<uint32_t*>(out8 + ((bp >> 3) & ~3u));
+        __hip_atomic_fetch_or(w, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or(w + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bp += code[i] >> NB_SHIFT;
+        if ((i & 3) == 3) { asm volatile("" : "+v"(bp)); PHASE_FENCE(); }
+    }
+}
+
+// ---- phase 6, Adler-32 partials of the run (deflate.py:826-831, :888-897): sa = sum x_i, sc = sum i * x_i (i = 0..31)
+__device__ __forceinline__ void adler_run(const uint32_t (&ow)[12], uint32_t& sa, uint32_t& sc) {
+    sa = 0; sc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        sa = __builtin_amdgcn_sad_u8(ow[k], 0u, sa);
+        const uint32_t wts = (uint32_t)(4 * k) | ((uint32_t)(4 * k + 1) << 8) | ((uint32_t)(4 * k + 2) << 16) | ((uint32_t)(4 * k + 3) << 24);
+        sc = __builtin_amdgcn_udot4(ow[k], wts, sc, false);
+    }
+}
+
+// fill the per-wave LUTs (literal: [byte] -> code|nbits; match: [len-3][dist-1] (CWINDOW <= 32) or [dist-1])
+template <int NCH>
+__device__ __forceinline__ void fill_luts(uint32_t* lut, uint32_t lane) {
+    for (uint32_t e = lane; e < (uint32_t)LUT_LIT; e += 64) lut[e] = literal_entry(e);
+    for (uint32_t e = lane; e < (uint32_t)LUT_MATCH; e += 64) {
+        if (NCH == 1) lut[LUT_LIT + e] = dist_entry((e & 31u) + 1u) | length_code((e >> 5) + 3u);
+        else lut[LUT_LIT + e] = dist_entry(e + 1u);
+    }
+}
+
+// one 16-byte chunk of a block at position p (p < n), from a source of any alignment; bytes at or beyond n read as zero
+__device__ __forceinline__ uint4 load_chunk16(const uint8_t* __restrict__ src, uint32_t p, uint32_t n, bool aligned16, uint32_t mis) {
+    uint4 v;
+    if (aligned16) {
+        v = *reinterpret_cast<const uint4*>(src + p);
+    } else {
+        // realign with aligned dword loads + v_alignbyte
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(src + p - mis);
+        const uint32_t nd = (n - p + mis + 3u) >> 2;      // dwords that hold valid bytes
+        uint32_t d0 = q[0];
+        uint32_t d1 = nd > 1 ? q[1] : 0, d2 = nd > 2 ? q[2] : 0, d3 = nd > 3 ? q[3] : 0, d4 = nd > 4 ? q[4] : 0;
+        v.x = alignbyte(d1, d0, mis);
+        v.y = alignbyte(d2, d1, mis);
+        v.z = alignbyte(d3, d2, mis);
+        v.w = alignbyte(d4, d3, mis);
+    }
+    const uint32_t valid = n - p;                // bytes of this chunk inside the block
+    if (valid < 16u) {                           // positions >= N must read as zero bytes
+        uint32_t* vv = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t lo = 4u * k;
+            const uint32_t m = valid <= lo ? 0u : (valid >= lo + 4u ? 0xFFFFFFFFu : ((1u << (8u * (valid - lo))) - 1u));
+            vv[k] &= m;
+        }
+    }
+    return v;
+}
 
 
 }  // namespace hdlz

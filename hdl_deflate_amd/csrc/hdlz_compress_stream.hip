@@ -1,7 +1,7 @@
 // hdlz_compress_stream.hip -- STARTC for ONE large stream, spread over the whole GPU.
 //
-// GENERATED by tools/gen_stream_kernel.py from the tile phases of hdlz_compress.hip (match search, extension,
-// backward parse, token lookup and bit scatter are textually the general kernel's) -- edit the generator.
+// The tile phases (match search, extension, backward parse, token lookup, bit scatter) are the shared device functions of
+// hdlz_compress_common.h -- the same source k_compress and k_compress_small are built from.
 //
 // The reference processes exactly one stream per START (deflate.py:616-633); the batch kernel gives a
 // stream to ONE wave, which is right for millions of blocks but leaves a single 16 MiB stream (the LMAX
@@ -50,17 +50,14 @@ struct StreamArgs {
     uint2* ad;           // [ntiles] Adler partials of the tile: sum of bytes, sum (N - p) x_p mod 65521
 };
 
+constexpr bool FULLWIN = false;      // the stream passes keep the per-position window compare (one build per NCH)
 constexpr uint64_t XF_IDENT = 0x9876543210ull;                     // transfer function: identity
 constexpr uint64_t XF_MARK = 0xFFFFFFFFFFFFFFFFull;                  // "not known yet: needs the full pass"
 
 #define HDLZ_STREAM_PROLOGUE()                                                                         \
     __shared__ WaveLds lds;                                                                            \
     const uint32_t lane = threadIdx.x;                                                                 \
-    for (uint32_t e = lane; e < (uint32_t)LUT_LIT; e += 64) lds.lut[e] = literal_entry(e);             \
-    for (uint32_t e = lane; e < (uint32_t)LUT_MATCH; e += 64) {                                        \
-        if (NCH == 1) lds.lut[LUT_LIT + e] = dist_entry((e & 31u) + 1u) | length_code((e >> 5) + 3u);  \
-        else lds.lut[LUT_LIT + e] = dist_entry(e + 1u);                                                \
-    }                                                                                                  \
+    fill_luts<NCH>(lds.lut, lane);                                                                     \
     __syncthreads();                                                                                   \
     const uint32_t cw4 = 4u * (uint32_t)a.cwindow;                                                     \
     const uint32_t kmax = (uint32_t)a.maxmatch;                                                        \
@@ -77,6 +74,19 @@ constexpr uint64_t XF_MARK = 0xFFFFFFFFFFFFFFFFull;                  // "not kno
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);                            \
     const bool aligned16 = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
 
+// ---- stage tile t: [t0 - 256, t0 + 2048 + 16) straight from HBM (no carried halo: tiles are independent)
+__device__ __forceinline__ void stage_tile(uint8_t* lin8, const uint8_t* __restrict__ src, uint32_t t0, uint32_t n, bool aligned16,
+                                           uint32_t mis, uint32_t lane) {
+    __syncthreads();
+    const uint32_t nchunk = (HALO + TILE + LOOKAHEAD) / 16;          // 145 16-byte chunks
+    for (uint32_t c = lane; c < nchunk; c += 64) {
+        const int64_t p = (int64_t)t0 - HALO + (int64_t)c * 16;       // first position of the chunk
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (p >= 0 && p < (int64_t)n) v = load_chunk16(src, (uint32_t)p, n, aligned16, mis);
+        *reinterpret_cast<uint4*>(lin8 + c * 16u) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ pass A
 template <int NCH>
 __global__ __launch_bounds__(64) void k_stream_xfer(StreamArgs a) {
@@ -85,174 +95,22 @@ __global__ __launch_bounds__(64) void k_stream_xfer(StreamArgs a) {
         if (a.xfer[t] != XF_MARK) continue;                          // k_stream_tails already has this tile's function
         HDLZ_TILE_COORDS(t)
 
-        // ---- stage tile t: [t0 - 256, t0 + 2048 + 16) straight from HBM (no carried halo: tiles are independent)
-        __syncthreads();
-        {
-            const uint32_t nchunk = (HALO + TILE + LOOKAHEAD) / 16;          // 145 16-byte chunks
-            for (uint32_t c = lane; c < nchunk; c += 64) {
-                const int64_t p = (int64_t)t0 - HALO + (int64_t)c * 16;       // first position of the chunk
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (p >= 0 && p < (int64_t)n) {
-                    if (aligned16) {
-                        v = *reinterpret_cast<const uint4*>(src + p);
-                    } else {
-                        const uint32_t* q = reinterpret_cast<const uint32_t*>(src + p - mis);
-                        const uint32_t nd = (uint32_t)(((int64_t)n - p + mis + 3) >> 2);
-                        uint32_t d0 = q[0];
-                        uint32_t d1 = nd > 1 ? q[1] : 0, d2 = nd > 2 ? q[2] : 0, d3 = nd > 3 ? q[3] : 0, d4 = nd > 4 ? q[4] : 0;
-                        v.x = alignbyte(d1, d0, mis); v.y = alignbyte(d2, d1, mis);
-                        v.z = alignbyte(d3, d2, mis); v.w = alignbyte(d4, d3, mis);
-                    }
-                    const uint32_t valid = (uint32_t)((int64_t)n - p < 16 ? (int64_t)n - p : 16);
-                    if (valid < 16u) {
-                        uint32_t* vv = reinterpret_cast<uint32_t*>(&v);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const uint32_t lo = 4u * k;
-                            vv[k] &= valid <= lo ? 0u : (valid >= lo + 4u ? 0xFFFFFFFFu : ((1u << (8u * (valid - lo))) - 1u));
-                        }
-                    }
-                }
-                *reinterpret_cast<uint4*>(lin8 + c * 16u) = v;
-            }
-        }
+        stage_tile(lin8, src, t0, n, aligned16, mis, lane);
         for (uint32_t w = lane; w < OUT_WORDS; w += 64) lds.out[w] = 0u;
         __syncthreads();
         const uint32_t p_run = t0 + lane * RUN;
-        const uint32_t lds_run = HALO + lane * RUN;
         const uint32_t nrem = n - min(p_run, n);
-            // -------------------------------------------------------------- 2. match search
-            const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);   // dword index of the run in lds.in
-            uint32_t ow[12];                                          // own 32 bytes + 16 look-ahead
-            {
-                const uint4 v0 = *reinterpret_cast<const uint4*>(&lds.in[run_dw]);
-                const uint4 v1 = *reinterpret_cast<const uint4*>(&lds.in[run_dw + 4]);
-                const uint4 v2 = *reinterpret_cast<const uint4*>(&lds.in[run_dw + 8]);
-                ow[0] = v0.x; ow[1] = v0.y; ow[2] = v0.z; ow[3] = v0.w;
-                ow[4] = v1.x; ow[5] = v1.y; ow[6] = v1.z; ow[7] = v1.w;
-                ow[8] = v2.x; ow[9] = v2.y; ow[10] = v2.z; ow[11] = v2.w;
-            }
-            uint32_t ko[RUN];
-            static_for<0, RUN>([&](auto I) { constexpr int i = decltype(I)::value; ko[i] = key3<i>(ow, (uint32_t)(4 * (i + 32))); });
-
-            pin(ko); pin(ow);
-            PHASE_FENCE();
-            uint32_t best[RUN];                                       // 4 * nearest distance, huge = none
-#pragma unroll
-            for (int i = 0; i < RUN; i++) best[i] = 0xFFFFFFFFu;
-
-#pragma unroll 1
-            for (int k = NCH - 1; k >= 0; k--) {                      // far chunks first, nearer ones overwrite
-                uint32_t cd[17];                                      // 64 candidate positions + 2 bytes
-                const uint32_t cdw = run_dw - 8u * (uint32_t)(k + 1);
-                {
-                    const uint4 c0 = *reinterpret_cast<const uint4*>(&lds.in[cdw]);
-                    const uint4 c1 = *reinterpret_cast<const uint4*>(&lds.in[cdw + 4]);
-                    cd[0] = c0.x; cd[1] = c0.y; cd[2] = c0.z; cd[3] = c0.w;
-                    cd[4] = c1.x; cd[5] = c1.y; cd[6] = c1.z; cd[7] = c1.w;
-                    if (NCH == 1) {
-                        cd[8] = ow[0];                                // candidate 31 needs the first own bytes
-#pragma unroll
-                        for (int j = 9; j < 17; j++) cd[j] = 0;      // unused: own keys double as candidates
-                    } else {
-                        const uint4 c2 = *reinterpret_cast<const uint4*>(&lds.in[cdw + 8]);
-                        const uint4 c3 = *reinterpret_cast<const uint4*>(&lds.in[cdw + 12]);
-                        cd[8] = c2.x; cd[9] = c2.y; cd[10] = c2.z; cd[11] = c2.w;
-                        cd[12] = c3.x; cd[13] = c3.y; cd[14] = c3.z; cd[15] = c3.w;
-                        cd[16] = lds.in[cdw + 16];
-                    }
-                }
-                uint32_t m[RUN];
-#pragma unroll
-                for (int i = 0; i < RUN; i++) m[i] = 0xFFFFFFFFu;
-                // candidate-major order: two candidate keys live at a time, 32 running minima
-                static_for<0, 63>([&](auto J) {
-                    constexpr int j = decltype(J)::value;             // handles candidates j and j+1 (j even)
-                    if constexpr ((j & 1) == 0) {
-                        uint32_t kc0, kc1;
-                        if constexpr (NCH == 1 && j >= 32) {          // own position j-32 IS candidate j (same tag 4j)
-                            // pin in place: without it the scheduler precomputes all ~500 own-vs-own differences
-                            asm volatile("" : "+v"(ko[j - 32]), "+v"(ko[j - 31]));
-                            kc0 = ko[j - 32];
-                            kc1 = ko[j - 31];
-                        } else {
-                            kc0 = key3<j>(cd, (uint32_t)(4 * j));
-                            kc1 = key3<j + 1>(cd, (uint32_t)(4 * (j + 1)));
-                        }
-                        // own index i pairs with candidates j in [i, i+31]
-                        static_for<0, RUN>([&](auto I) {
-                            constexpr int i = decltype(I)::value;
-                            constexpr bool use0 = (j >= i) && (j <= i + 31);
-                            constexpr bool use1 = (j + 1 >= i) && (j + 1 <= i + 31);
-                            if constexpr (use0 && use1) m[i] = umin3(m[i], ko[i] - kc0, ko[i] - kc1);
-                            else if constexpr (use0) m[i] = min(m[i], ko[i] - kc0);
-                            else if constexpr (use1) m[i] = min(m[i], ko[i] - kc1);
-                        });
-                        if constexpr ((j & 7) == 6) { pin(m); PHASE_FENCE(); }
-                    }
-                });
-#pragma unroll
-                for (int i = 0; i < RUN; i++)
-                    if (m[i] < 256u) best[i] = m[i] + 128u * (uint32_t)k;
-            }
-
-            // -------------------------------------------------------------- 3. eligibility + extension
-            // afterwards tok[i] = (len-1) << 16 | LUT byte offset of the token  (len-1 = 0 for a literal)
-            pin(best); pin(ow);
-            PHASE_FENCE();
-            const uint32_t nrem_m2 = nrem - 2u;                       // (wraps when nrem < 2: then nothing is eligible)
-            const uint32_t p4_run = 4u * min(p_run, 1024u);           // 4*p saturated: only p < CWINDOW <= 256 matters
-            uint32_t tok[RUN];
-            static_for<0, RUN>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                const uint32_t d4 = best[i];
-                // R3: 1 <= p <= N-5;  R4: d <= min(CWINDOW, p)
-                const bool ok = (d4 <= cw4) & (d4 <= p4_run + (uint32_t)(4 * i)) & (nrem >= (uint32_t)(i + 5));   // '&': no short-circuit branches
-                // distance for the gather; for "no match" any in-range value will do (the result is discarded)
-                const uint32_t d = (NCH == 1) ? ((d4 & 0xFCu) >> 2) : (ok ? (d4 >> 2) : 1u);
-                // R5: common prefix of x[p+3..p+10] and x[p-d+3..p-d+10]
-                const uint32_t q = lds_run + (uint32_t)(i + 3) - d;   // byte offset of the candidate's 4th byte
-                const uint32_t qd = q >> 2, qs = q & 3u;
-                const uint32_t a0 = lds.in[qd], a1 = lds.in[qd + 1], a2 = lds.in[qd + 2];
-                const uint32_t clo = alignbyte(a1, a0, qs), chi = alignbyte(a2, a1, qs);
-                constexpr int o = i + 3;
-                uint32_t olo, ohi;
-                if constexpr ((o & 3) == 0) { olo = ow[o >> 2]; ohi = ow[(o >> 2) + 1]; }
-                else { olo = alignbyte(ow[(o >> 2) + 1], ow[o >> 2], o & 3); ohi = alignbyte(ow[(o >> 2) + 2], ow[(o >> 2) + 1], o & 3); }
-                // equal low BITS of the two 8-byte windows (ffbl(0) = 0xFFFFFFFF = "no difference in this half")
-                const uint32_t zhi = min(ffbl(chi ^ ohi), 32u) + 32u;
-                const uint32_t zb = min(ffbl(clo ^ olo), zhi);
-                // m = min(3 + equal bytes, Kmax, N-2-p): a match never covers the last two bytes
-                const uint32_t mlen = umin3(3u + (zb >> 3), kmax, nrem_m2 - (uint32_t)i);
-                // literal byte -> LUT offset 4*byte
-                constexpr int bsh = 8 * (i & 3);
-                uint32_t lit;
-                if constexpr (bsh == 0) lit = (ow[i >> 2] << 2) & 0x3FCu;
-                else lit = (ow[i >> 2] >> (bsh - 2)) & 0x3FCu;
-                uint32_t mt;
-                if (NCH == 1) {
-                    // (len-1)<<16 | base + ((len-3)*32 + d-1)*4 = mlen*65664 + d4 + const, as two shift-adds:
-                    // hipcc folds the C form into a quarter-rate v_mul_lo_u32
-                    uint32_t t1;
-                    asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(t1) : "v"(mlen), "v"(d4 + (LUT_MATCH_BYTE - 65924u)));
-                    asm("v_lshl_add_u32 %0, %1, 16, %2" : "=v"(mt) : "v"(mlen), "v"(t1));
-                }
-                else mt = (mlen << 16) + d4 + (LUT_MATCH_BYTE - 65540u);                     // (len-1)<<16 | base + (d-1)*4
-                tok[i] = ok ? mt : lit;
-                if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(tok); pin(ow); PHASE_FENCE(); }
-            });
-
-            pin(tok);
-            PHASE_FENCE();
-            // backward pass: E[i] = exit skip if a token starts at local index i; nibbles of P hold E[i+1..i+10]
-            uint64_t P = 0x9876543210ull;
-#pragma unroll
-            for (int i = RUN - 1; i >= 0; i--) {
-                const uint32_t sh = (tok[i] >> 16) * 4u;              // 4 * (len-1)
-                const uint32_t e = (uint32_t)(P >> sh) & 15u;
-                P = (P << 4) | e;
-            }
-
+        const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);       // dword index of the run in lds.in
+        uint32_t best[RUN], tok[RUN];
+        match_search<NCH>(lds.in, run_dw, best);                                                   // 2. R3/R4
+        {
+            uint32_t ow[12];
+            load_own(lds.in, run_dw, ow);
+            make_tokens<NCH, FULLWIN>(lds.in, HALO + lane * RUN, ow, best, cw4, kmax, 4u * min(p_run, 32u * NCH), nrem, tok);   // 3. R5
+        }
+        pin(tok);
+        PHASE_FENCE();
+        const uint64_t P = run_transfer(tok);                                                      // 4. greedy parse of the run
             // transfer function of the whole tile: lanes 0..9 each push one entry skip through the 64 runs
             {
                 const uint32_t plo = (uint32_t)P, phi = (uint32_t)(P >> 32);
@@ -477,239 +335,38 @@ __global__ __launch_bounds__(64) void k_stream_offsets_blocks(StreamArgs a) {
 
 // ------------------------------------------------------------------------------------------------ pass C
 template <int NCH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 5 : 4, NCH == 1 ? 5 : 4))) void k_stream_tile(StreamArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? HDLZ_W1 : 4, NCH == 1 ? HDLZ_W1 : 4))) void k_stream_tile(StreamArgs a) {
     HDLZ_STREAM_PROLOGUE()
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         HDLZ_TILE_COORDS(t)
         uint32_t skip_in = a.skip[t];
         const uint32_t base_bits = 0;                                // the tile's bits are built from local bit 0
 
-        // ---- stage tile t: [t0 - 256, t0 + 2048 + 16) straight from HBM (no carried halo: tiles are independent)
-        __syncthreads();
-        {
-            const uint32_t nchunk = (HALO + TILE + LOOKAHEAD) / 16;          // 145 16-byte chunks
-            for (uint32_t c = lane; c < nchunk; c += 64) {
-                const int64_t p = (int64_t)t0 - HALO + (int64_t)c * 16;       // first position of the chunk
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (p >= 0 && p < (int64_t)n) {
-                    if (aligned16) {
-                        v = *reinterpret_cast<const uint4*>(src + p);
-                    } else {
-                        const uint32_t* q = reinterpret_cast<const uint32_t*>(src + p - mis);
-                        const uint32_t nd = (uint32_t)(((int64_t)n - p + mis + 3) >> 2);
-                        uint32_t d0 = q[0];
-                        uint32_t d1 = nd > 1 ? q[1] : 0, d2 = nd > 2 ? q[2] : 0, d3 = nd > 3 ? q[3] : 0, d4 = nd > 4 ? q[4] : 0;
-                        v.x = alignbyte(d1, d0, mis); v.y = alignbyte(d2, d1, mis);
-                        v.z = alignbyte(d3, d2, mis); v.w = alignbyte(d4, d3, mis);
-                    }
-                    const uint32_t valid = (uint32_t)((int64_t)n - p < 16 ? (int64_t)n - p : 16);
-                    if (valid < 16u) {
-                        uint32_t* vv = reinterpret_cast<uint32_t*>(&v);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const uint32_t lo = 4u * k;
-                            vv[k] &= valid <= lo ? 0u : (valid >= lo + 4u ? 0xFFFFFFFFu : ((1u << (8u * (valid - lo))) - 1u));
-                        }
-                    }
-                }
-                *reinterpret_cast<uint4*>(lin8 + c * 16u) = v;
-            }
-        }
+        stage_tile(lin8, src, t0, n, aligned16, mis, lane);
         for (uint32_t w = lane; w < OUT_WORDS; w += 64) lds.out[w] = 0u;
         __syncthreads();
         const uint32_t p_run = t0 + lane * RUN;
-        const uint32_t lds_run = HALO + lane * RUN;
         const uint32_t nrem = n - min(p_run, n);
-            // -------------------------------------------------------------- 2. match search
-            const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);   // dword index of the run in lds.in
-            uint32_t ow[12];                                          // own 32 bytes + 16 look-ahead
-            {
-                const uint4 v0 = *reinterpret_cast<const uint4*>(&lds.in[run_dw]);
-                const uint4 v1 = *reinterpret_cast<const uint4*>(&lds.in[run_dw + 4]);
-                const uint4 v2 = *reinterpret_cast<const uint4*>(&lds.in[run_dw + 8]);
-                ow[0] = v0.x; ow[1] = v0.y; ow[2] = v0.z; ow[3] = v0.w;
-                ow[4] = v1.x; ow[5] = v1.y; ow[6] = v1.z; ow[7] = v1.w;
-                ow[8] = v2.x; ow[9] = v2.y; ow[10] = v2.z; ow[11] = v2.w;
-            }
-            uint32_t ko[RUN];
-            static_for<0, RUN>([&](auto I) { constexpr int i = decltype(I)::value; ko[i] = key3<i>(ow, (uint32_t)(4 * (i + 32))); });
-
-            pin(ko); pin(ow);
-            PHASE_FENCE();
-            uint32_t best[RUN];                                       // 4 * nearest distance, huge = none
-#pragma unroll
-            for (int i = 0; i < RUN; i++) best[i] = 0xFFFFFFFFu;
-
-#pragma unroll 1
-            for (int k = NCH - 1; k >= 0; k--) {                      // far chunks first, nearer ones overwrite
-                uint32_t cd[17];                                      // 64 candidate positions + 2 bytes
-                const uint32_t cdw = run_dw - 8u * (uint32_t)(k + 1);
-                {
-                    const uint4 c0 = *reinterpret_cast<const uint4*>(&lds.in[cdw]);
-                    const uint4 c1 = *reinterpret_cast<const uint4*>(&lds.in[cdw + 4]);
-                    cd[0] = c0.x; cd[1] = c0.y; cd[2] = c0.z; cd[3] = c0.w;
-                    cd[4] = c1.x; cd[5] = c1.y; cd[6] = c1.z; cd[7] = c1.w;
-                    if (NCH == 1) {
-                        cd[8] = ow[0];                                // candidate 31 needs the first own bytes
-#pragma unroll
-                        for (int j = 9; j < 17; j++) cd[j] = 0;      // unused: own keys double as candidates
-                    } else {
-                        const uint4 c2 = *reinterpret_cast<const uint4*>(&lds.in[cdw + 8]);
-                        const uint4 c3 = *reinterpret_cast<const uint4*>(&lds.in[cdw + 12]);
-                        cd[8] = c2.x; cd[9] = c2.y; cd[10] = c2.z; cd[11] = c2.w;
-                        cd[12] = c3.x; cd[13] = c3.y; cd[14] = c3.z; cd[15] = c3.w;
-                        cd[16] = lds.in[cdw + 16];
-                    }
-                }
-                uint32_t m[RUN];
-#pragma unroll
-                for (int i = 0; i < RUN; i++) m[i] = 0xFFFFFFFFu;
-                // candidate-major order: two candidate keys live at a time, 32 running minima
-                static_for<0, 63>([&](auto J) {
-                    constexpr int j = decltype(J)::value;             // handles candidates j and j+1 (j even)
-                    if constexpr ((j & 1) == 0) {
-                        uint32_t kc0, kc1;
-                        if constexpr (NCH == 1 && j >= 32) {          // own position j-32 IS candidate j (same tag 4j)
-                            // pin in place: without it the scheduler precomputes all ~500 own-vs-own differences
-                            asm volatile("" : "+v"(ko[j - 32]), "+v"(ko[j - 31]));
-                            kc0 = ko[j - 32];
-                            kc1 = ko[j - 31];
-                        } else {
-                            kc0 = key3<j>(cd, (uint32_t)(4 * j));
-                            kc1 = key3<j + 1>(cd, (uint32_t)(4 * (j + 1)));
-                        }
-                        // own index i pairs with candidates j in [i, i+31]
-                        static_for<0, RUN>([&](auto I) {
-                            constexpr int i = decltype(I)::value;
-                            constexpr bool use0 = (j >= i) && (j <= i + 31);
-                            constexpr bool use1 = (j + 1 >= i) && (j + 1 <= i + 31);
-                            if constexpr (use0 && use1) m[i] = umin3(m[i], ko[i] - kc0, ko[i] - kc1);
-                            else if constexpr (use0) m[i] = min(m[i], ko[i] - kc0);
-                            else if constexpr (use1) m[i] = min(m[i], ko[i] - kc1);
-                        });
-                        if constexpr ((j & 7) == 6) { pin(m); PHASE_FENCE(); }
-                    }
-                });
-#pragma unroll
-                for (int i = 0; i < RUN; i++)
-                    if (m[i] < 256u) best[i] = m[i] + 128u * (uint32_t)k;
-            }
-
-            // -------------------------------------------------------------- 3. eligibility + extension
-            // afterwards tok[i] = (len-1) << 16 | LUT byte offset of the token  (len-1 = 0 for a literal)
-            pin(best); pin(ow);
-            PHASE_FENCE();
-            const uint32_t nrem_m2 = nrem - 2u;                       // (wraps when nrem < 2: then nothing is eligible)
-            const uint32_t p4_run = 4u * min(p_run, 1024u);           // 4*p saturated: only p < CWINDOW <= 256 matters
-            uint32_t tok[RUN];
-            static_for<0, RUN>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                const uint32_t d4 = best[i];
-                // R3: 1 <= p <= N-5;  R4: d <= min(CWINDOW, p)
-                const bool ok = (d4 <= cw4) & (d4 <= p4_run + (uint32_t)(4 * i)) & (nrem >= (uint32_t)(i + 5));   // '&': no short-circuit branches
-                // distance for the gather; for "no match" any in-range value will do (the result is discarded)
-                const uint32_t d = (NCH == 1) ? ((d4 & 0xFCu) >> 2) : (ok ? (d4 >> 2) : 1u);
-                // R5: common prefix of x[p+3..p+10] and x[p-d+3..p-d+10]
-                const uint32_t q = lds_run + (uint32_t)(i + 3) - d;   // byte offset of the candidate's 4th byte
-                const uint32_t qd = q >> 2, qs = q & 3u;
-                const uint32_t a0 = lds.in[qd], a1 = lds.in[qd + 1], a2 = lds.in[qd + 2];
-                const uint32_t clo = alignbyte(a1, a0, qs), chi = alignbyte(a2, a1, qs);
-                constexpr int o = i + 3;
-                uint32_t olo, ohi;
-                if constexpr ((o & 3) == 0) { olo = ow[o >> 2]; ohi = ow[(o >> 2) + 1]; }
-                else { olo = alignbyte(ow[(o >> 2) + 1], ow[o >> 2], o & 3); ohi = alignbyte(ow[(o >> 2) + 2], ow[(o >> 2) + 1], o & 3); }
-                // equal low BITS of the two 8-byte windows (ffbl(0) = 0xFFFFFFFF = "no difference in this half")
-                const uint32_t zhi = min(ffbl(chi ^ ohi), 32u) + 32u;
-                const uint32_t zb = min(ffbl(clo ^ olo), zhi);
-                // m = min(3 + equal bytes, Kmax, N-2-p): a match never covers the last two bytes
-                const uint32_t mlen = umin3(3u + (zb >> 3), kmax, nrem_m2 - (uint32_t)i);
-                // literal byte -> LUT offset 4*byte
-                constexpr int bsh = 8 * (i & 3);
-                uint32_t lit;
-                if constexpr (bsh == 0) lit = (ow[i >> 2] << 2) & 0x3FCu;
-                else lit = (ow[i >> 2] >> (bsh - 2)) & 0x3FCu;
-                uint32_t mt;
-                if (NCH == 1) {
-                    // (len-1)<<16 | base + ((len-3)*32 + d-1)*4 = mlen*65664 + d4 + const, as two shift-adds:
-                    // hipcc folds the C form into a quarter-rate v_mul_lo_u32
-                    uint32_t t1;
-                    asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(t1) : "v"(mlen), "v"(d4 + (LUT_MATCH_BYTE - 65924u)));
-                    asm("v_lshl_add_u32 %0, %1, 16, %2" : "=v"(mt) : "v"(mlen), "v"(t1));
-                }
-                else mt = (mlen << 16) + d4 + (LUT_MATCH_BYTE - 65540u);                     // (len-1)<<16 | base + (d-1)*4
-                tok[i] = ok ? mt : lit;
-                if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(tok); pin(ow); PHASE_FENCE(); }
-            });
-
-            pin(tok); pin(ow);
-            PHASE_FENCE();
-            // backward pass: E[i] = exit skip if a token starts at local index i; nibbles of P hold E[i+1..i+10]
-            uint64_t P = 0x9876543210ull;
-#pragma unroll
-            for (int i = RUN - 1; i >= 0; i--) {
-                const uint32_t sh = (tok[i] >> 16) * 4u;              // 4 * (len-1)
-                const uint32_t e = (uint32_t)(P >> sh) & 15u;
-                P = (P << 4) | e;
-            }
-            // now nibble s of P = exit skip for entry skip s.  Compose across the wave (serial, scalar).
-            uint32_t myskip;
-            {
-                const uint32_t plo = (uint32_t)P, phi = (uint32_t)(P >> 32);
-                uint32_t s = skip_in;
-                uint64_t sv[4] = {0, 0, 0, 0};     // entry skips of all 64 lanes, one nibble each (scalar regs)
-                // 4 segments of 16 lanes; the scheduling barriers keep the compiler from hoisting all 128
-                // readlanes to the top (that needed ~260 SGPR spills = v_writelane/v_readlane traffic)
-                static_for<0, 4>([&](auto G) {
-                    constexpr int g = decltype(G)::value;
-                    uint64_t acc = 0;
-#pragma unroll
-                    for (int l = 0; l < 16; l++) {
-                        acc |= (uint64_t)s << (4 * l);
-                        // NB: readlane returns a signed int -- cast before widening or bit 31 smears into the high half
-                        const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, g * 16 + l) << 32) |
-                                           (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)plo, g * 16 + l);
-                        s = (uint32_t)(f >> (4u * s)) & 15u;
-                    }
-                    sv[g] = acc;
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                skip_in = s;
-                const uint32_t g = lane >> 4;
-                const uint64_t mine = g == 0 ? sv[0] : g == 1 ? sv[1] : g == 2 ? sv[2] : sv[3];
-                myskip = (uint32_t)(mine >> (4u * (lane & 15u))) & 15u;
-            }
-
-            pin(tok); asm volatile("" : "+v"(myskip));
-            PHASE_FENCE();
-            // -------------------------------------------------------------- 5. token bits
-            // pass A: LUT entry (code | nbits << 27) of every token start, 0 elsewhere
-            uint32_t code[RUN];
-            uint32_t lane_bits = 0;
-            {
-                uint32_t c = myskip;
-                static_for<0, RUN>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    const uint32_t e = *reinterpret_cast<const uint32_t*>(lut8 + (tok[i] & 0xFFFFu));
-                    const bool start = (c == 0u);
-                    const uint32_t lenm1 = tok[i] >> 16;
-                    c = start ? lenm1 : (c - 1u);
-                    uint32_t ee = e;
-                    if constexpr (NCH != 1)                               // wide windows: [dist] LUT + computed length code
-                        ee |= lenm1 ? (__builtin_bitreverse32(lenm1 - 1u) >> 25) : 0u;
-                    code[i] = start ? ee : 0u;
-                    lane_bits += code[i] >> NB_SHIFT;
-                    if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(code); asm volatile("" : "+v"(c), "+v"(lane_bits)); PHASE_FENCE(); }
-                });
-            }
-
+        const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);       // dword index of the run in lds.in
+        uint32_t best[RUN], tok[RUN], code[RUN];
+        uint32_t sa, sc;                                             // Adler partials of the run
+        match_search<NCH>(lds.in, run_dw, best);                                                   // 2. R3/R4
+        {
+            uint32_t ow[12];
+            load_own(lds.in, run_dw, ow);
+            adler_run(ow, sa, sc);
+            make_tokens<NCH, FULLWIN>(lds.in, HALO + lane * RUN, ow, best, cw4, kmax, 4u * min(p_run, 32u * NCH), nrem, tok);   // 3. R5
+        }
+        pin(tok);
+        PHASE_FENCE();
+        const uint64_t P = run_transfer(tok);                                                      // 4. greedy parse of the run
+        uint32_t myskip = chain_skips(P, lane, skip_in);
+        pin(tok); asm volatile("" : "+v"(myskip));
+        PHASE_FENCE();
+        uint32_t lane_bits = token_codes<NCH, false>(lut8, tok, myskip, 0u, code);                 // 5. R6/R7
             pin(code);
             PHASE_FENCE();
-            uint32_t incl = lane_bits;
-#pragma unroll
-            for (int ofs = 1; ofs < 64; ofs <<= 1) {
-                const uint32_t o = __shfl_up(incl, ofs, 64);
-                if (lane >= (uint32_t)ofs) incl += o;
-            }
+            uint32_t incl = wave_scan_incl(lane_bits, lane);
             const uint32_t tile_bits_all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             // positions >= N of the last tile were parsed as one 8-bit literal each (see hdlz_compress.hip); their
             // bits sit behind the real end and are cut off by k_stream_place, which only takes bits[t] bits
@@ -718,13 +375,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 5
             const uint32_t tile_bits = tile_bits_all - 8u * ninv;
             {
                 // bits and Adler partials of the tile
-                uint32_t sa = 0, sc = 0;
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    sa = __builtin_amdgcn_sad_u8(ow[k], 0u, sa);
-                    const uint32_t wts = (uint32_t)(4 * k) | ((uint32_t)(4 * k + 1) << 8) | ((uint32_t)(4 * k + 2) << 16) | ((uint32_t)(4 * k + 3) << 24);
-                    sc = __builtin_amdgcn_udot4(ow[k], wts, sc, false);
-                }
                 uint32_t wsum = ((nrem % ADLER_MOD) * sa) % ADLER_MOD + ADLER_MOD * 8u - (sc % ADLER_MOD);   // < 10 * 65521
 #pragma unroll
                 for (int ofs = 32; ofs > 0; ofs >>= 1) {
@@ -736,20 +386,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 5
             }
             pin(code); asm volatile("" : "+v"(incl), "+v"(lane_bits));
             PHASE_FENCE();
-            // pass B: OR every token into the LDS bit buffer at its own bit offset
-            {
-                uint32_t bp = base_bits + incl - lane_bits;
-#pragma unroll
-                for (int i = 0; i < RUN; i++) {
-                    const uint64_t v = (uint64_t)(code[i] & CODE_MASK) << (bp & 31u);
-                    uint32_t* w = reinterpret_cast<uint32_t*>(out8 + ((bp >> 3) & ~3u));
-                    __hip_atomic_fetch_or(w, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_or(w + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    bp += code[i] >> NB_SHIFT;
-                    if ((i & 3) == 3) { asm volatile("" : "+v"(bp)); PHASE_FENCE(); }
-                }
-            }
-
+            scatter_codes(out8, code, base_bits + incl - lane_bits);                               // bit writer
 
             __syncthreads();
             // the tile's bit string goes to its slot of the scratch buffer; k_stream_place shifts it to its final position
@@ -884,137 +521,16 @@ __global__ __launch_bounds__(64) void k_stream_tails(StreamArgs a) {
         }
     }
     __syncthreads();
-            // -------------------------------------------------------------- 2. match search
-            uint32_t ow[12];                                          // own 32 bytes + 16 look-ahead
-            {
-                const uint4 v0 = *reinterpret_cast<const uint4*>(&lds.in[run_dw]);
-                const uint4 v1 = *reinterpret_cast<const uint4*>(&lds.in[run_dw + 4]);
-                const uint4 v2 = *reinterpret_cast<const uint4*>(&lds.in[run_dw + 8]);
-                ow[0] = v0.x; ow[1] = v0.y; ow[2] = v0.z; ow[3] = v0.w;
-                ow[4] = v1.x; ow[5] = v1.y; ow[6] = v1.z; ow[7] = v1.w;
-                ow[8] = v2.x; ow[9] = v2.y; ow[10] = v2.z; ow[11] = v2.w;
-            }
-            uint32_t ko[RUN];
-            static_for<0, RUN>([&](auto I) { constexpr int i = decltype(I)::value; ko[i] = key3<i>(ow, (uint32_t)(4 * (i + 32))); });
-
-            pin(ko); pin(ow);
-            PHASE_FENCE();
-            uint32_t best[RUN];                                       // 4 * nearest distance, huge = none
-#pragma unroll
-            for (int i = 0; i < RUN; i++) best[i] = 0xFFFFFFFFu;
-
-#pragma unroll 1
-            for (int k = NCH - 1; k >= 0; k--) {                      // far chunks first, nearer ones overwrite
-                uint32_t cd[17];                                      // 64 candidate positions + 2 bytes
-                const uint32_t cdw = run_dw - 8u * (uint32_t)(k + 1);
-                {
-                    const uint4 c0 = *reinterpret_cast<const uint4*>(&lds.in[cdw]);
-                    const uint4 c1 = *reinterpret_cast<const uint4*>(&lds.in[cdw + 4]);
-                    cd[0] = c0.x; cd[1] = c0.y; cd[2] = c0.z; cd[3] = c0.w;
-                    cd[4] = c1.x; cd[5] = c1.y; cd[6] = c1.z; cd[7] = c1.w;
-                    if (NCH == 1) {
-                        cd[8] = ow[0];                                // candidate 31 needs the first own bytes
-#pragma unroll
-                        for (int j = 9; j < 17; j++) cd[j] = 0;      // unused: own keys double as candidates
-                    } else {
-                        const uint4 c2 = *reinterpret_cast<const uint4*>(&lds.in[cdw + 8]);
-                        const uint4 c3 = *reinterpret_cast<const uint4*>(&lds.in[cdw + 12]);
-                        cd[8] = c2.x; cd[9] = c2.y; cd[10] = c2.z; cd[11] = c2.w;
-                        cd[12] = c3.x; cd[13] = c3.y; cd[14] = c3.z; cd[15] = c3.w;
-                        cd[16] = lds.in[cdw + 16];
-                    }
-                }
-                uint32_t m[RUN];
-#pragma unroll
-                for (int i = 0; i < RUN; i++) m[i] = 0xFFFFFFFFu;
-                // candidate-major order: two candidate keys live at a time, 32 running minima
-                static_for<0, 63>([&](auto J) {
-                    constexpr int j = decltype(J)::value;             // handles candidates j and j+1 (j even)
-                    if constexpr ((j & 1) == 0) {
-                        uint32_t kc0, kc1;
-                        if constexpr (NCH == 1 && j >= 32) {          // own position j-32 IS candidate j (same tag 4j)
-                            // pin in place: without it the scheduler precomputes all ~500 own-vs-own differences
-                            asm volatile("" : "+v"(ko[j - 32]), "+v"(ko[j - 31]));
-                            kc0 = ko[j - 32];
-                            kc1 = ko[j - 31];
-                        } else {
-                            kc0 = key3<j>(cd, (uint32_t)(4 * j));
-                            kc1 = key3<j + 1>(cd, (uint32_t)(4 * (j + 1)));
-                        }
-                        // own index i pairs with candidates j in [i, i+31]
-                        static_for<0, RUN>([&](auto I) {
-                            constexpr int i = decltype(I)::value;
-                            constexpr bool use0 = (j >= i) && (j <= i + 31);
-                            constexpr bool use1 = (j + 1 >= i) && (j + 1 <= i + 31);
-                            if constexpr (use0 && use1) m[i] = umin3(m[i], ko[i] - kc0, ko[i] - kc1);
-                            else if constexpr (use0) m[i] = min(m[i], ko[i] - kc0);
-                            else if constexpr (use1) m[i] = min(m[i], ko[i] - kc1);
-                        });
-                        if constexpr ((j & 7) == 6) { pin(m); PHASE_FENCE(); }
-                    }
-                });
-#pragma unroll
-                for (int i = 0; i < RUN; i++)
-                    if (m[i] < 256u) best[i] = m[i] + 128u * (uint32_t)k;
-            }
-
-            // -------------------------------------------------------------- 3. eligibility + extension
-            // afterwards tok[i] = (len-1) << 16 | LUT byte offset of the token  (len-1 = 0 for a literal)
-            pin(best); pin(ow);
-            PHASE_FENCE();
-            const uint32_t nrem_m2 = nrem - 2u;                       // (wraps when nrem < 2: then nothing is eligible)
-            const uint32_t p4_run = 4u * min(p_run, 1024u);           // 4*p saturated: only p < CWINDOW <= 256 matters
-            uint32_t tok[RUN];
-            static_for<0, RUN>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                const uint32_t d4 = best[i];
-                // R3: 1 <= p <= N-5;  R4: d <= min(CWINDOW, p)
-                const bool ok = (d4 <= cw4) & (d4 <= p4_run + (uint32_t)(4 * i)) & (nrem >= (uint32_t)(i + 5));   // '&': no short-circuit branches
-                // distance for the gather; for "no match" any in-range value will do (the result is discarded)
-                const uint32_t d = (NCH == 1) ? ((d4 & 0xFCu) >> 2) : (ok ? (d4 >> 2) : 1u);
-                // R5: common prefix of x[p+3..p+10] and x[p-d+3..p-d+10]
-                const uint32_t q = lds_run + (uint32_t)(i + 3) - d;   // byte offset of the candidate's 4th byte
-                const uint32_t qd = q >> 2, qs = q & 3u;
-                const uint32_t a0 = lds.in[qd], a1 = lds.in[qd + 1], a2 = lds.in[qd + 2];
-                const uint32_t clo = alignbyte(a1, a0, qs), chi = alignbyte(a2, a1, qs);
-                constexpr int o = i + 3;
-                uint32_t olo, ohi;
-                if constexpr ((o & 3) == 0) { olo = ow[o >> 2]; ohi = ow[(o >> 2) + 1]; }
-                else { olo = alignbyte(ow[(o >> 2) + 1], ow[o >> 2], o & 3); ohi = alignbyte(ow[(o >> 2) + 2], ow[(o >> 2) + 1], o & 3); }
-                // equal low BITS of the two 8-byte windows (ffbl(0) = 0xFFFFFFFF = "no difference in this half")
-                const uint32_t zhi = min(ffbl(chi ^ ohi), 32u) + 32u;
-                const uint32_t zb = min(ffbl(clo ^ olo), zhi);
-                // m = min(3 + equal bytes, Kmax, N-2-p): a match never covers the last two bytes
-                const uint32_t mlen = umin3(3u + (zb >> 3), kmax, nrem_m2 - (uint32_t)i);
-                // literal byte -> LUT offset 4*byte
-                constexpr int bsh = 8 * (i & 3);
-                uint32_t lit;
-                if constexpr (bsh == 0) lit = (ow[i >> 2] << 2) & 0x3FCu;
-                else lit = (ow[i >> 2] >> (bsh - 2)) & 0x3FCu;
-                uint32_t mt;
-                if (NCH == 1) {
-                    // (len-1)<<16 | base + ((len-3)*32 + d-1)*4 = mlen*65664 + d4 + const, as two shift-adds:
-                    // hipcc folds the C form into a quarter-rate v_mul_lo_u32
-                    uint32_t t1;
-                    asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(t1) : "v"(mlen), "v"(d4 + (LUT_MATCH_BYTE - 65924u)));
-                    asm("v_lshl_add_u32 %0, %1, 16, %2" : "=v"(mt) : "v"(mlen), "v"(t1));
-                }
-                else mt = (mlen << 16) + d4 + (LUT_MATCH_BYTE - 65540u);                     // (len-1)<<16 | base + (d-1)*4
-                tok[i] = ok ? mt : lit;
-                if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(tok); pin(ow); PHASE_FENCE(); }
-            });
-
-            pin(tok);
-            PHASE_FENCE();
-            // backward pass: E[i] = exit skip if a token starts at local index i; nibbles of P hold E[i+1..i+10]
-            uint64_t P = 0x9876543210ull;
-#pragma unroll
-            for (int i = RUN - 1; i >= 0; i--) {
-                const uint32_t sh = (tok[i] >> 16) * 4u;              // 4 * (len-1)
-                const uint32_t e = (uint32_t)(P >> sh) & 15u;
-                P = (P << 4) | e;
-            }
-
+    uint32_t best[RUN], tok[RUN];
+    match_search<NCH>(lds.in, run_dw, best);                                                       // 2. R3/R4
+    {
+        uint32_t ow[12];
+        load_own(lds.in, run_dw, ow);
+        make_tokens<NCH, FULLWIN>(lds.in, lds_run, ow, best, cw4, kmax, 4u * min(p_run, 32u * NCH), nrem, tok);   // 3. R5
+    }
+    pin(tok);
+    PHASE_FENCE();
+    const uint64_t P = run_transfer(tok);                                                          // 4. greedy parse of the run
     // constant?  (nibbles 0..9 of P = exit skip for entry skip 0..9 over these 32 positions)
     {
         const uint64_t P40 = P & 0xFFFFFFFFFFull;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
         }
     }
     const uint8_t* __restrict__ z = a.in + off;
-    uint8_t* __restrict__ out = a.out + sid * a.out_pitch;
+    uint8_t* out = a.out + sid * a.out_pitch;     // (not __restrict__: the chunk flush stores the same bytes through a.out)
     uint8_t* ring8 = reinterpret_cast<uint8_t*>(lds.ring[wave]);
     const uint32_t cap = a.out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00u : (uint32_t)a.out_pitch;   // o + 258 never wraps
     // obsize != 0: reference-exact OBSIZE build -- the stored LEN register is LOBSIZE bits wide
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
     const uint32_t obsize = a.obsize ? a.obsize : 32768u;
     const uint32_t len_mask = a.obsize ? ((1u << (31u - (uint32_t)__builtin_clz(a.obsize))) - 1u) : 0xFFFFu;
     const bool assume_fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) != 0;
+    const uint32_t oneblock = (a.flags & HDLZ_INFLATE_ONEBLOCK) ? 1u : 0u;       // deflate.py:678,:1542,:1617
     const bool out16 = ((reinterpret_cast<uintptr_t>(a.out) | a.out_pitch) & 15u) == 0;
     const int32_t isize = (int32_t)zn - 1;            // deflate.py:605
 
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
                 HDLZ_REFILL();
                 if (need_header) {
                     // HEADER (deflate.py:677-732)
-                    final_ = (uint32_t)bb & 1u;
+                    final_ = ((uint32_t)bb & 1u) | oneblock;
                     const uint32_t hm = assume_fixed ? 1u : ((uint32_t)(bb >> 1) & 3u);
                     if (hm == 3u) { HDLZ_FAIL(HDLZ_E_BAD_BTYPE); break; }
                     if (hm == 2u) { HDLZ_FAIL(HDLZ_E_DYNAMIC_UNSUPPORTED); break; }

@@ -14,7 +14,7 @@
 // The reference's table layout (10-bit instant table + incremental-mask retry) is FPGA-specific; a
 // canonical count/offset decoder returns the same symbols for every valid code.  Invalid code
 // descriptions are HDLZ_E_BAD_TREE (zlib's acceptance rules: over-subscribed sets rejected, incomplete
-// sets only with a single code).
+// sets only with a single code -- or, for the distance code, with none at all).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         for (;;) {
             REFILL();
             // HEADER (deflate.py:677-732)
-            const uint32_t final_ = (uint32_t)bb & 1u;
+            const uint32_t final_ = ((uint32_t)bb & 1u) | ((a.flags & HDLZ_INFLATE_ONEBLOCK) ? 1u : 0u);   // ONEBLOCK: deflate.py:678,:1542,:1617
             const uint32_t hm = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) ? 1u : ((uint32_t)(bb >> 1) & 3u);   // DYNAMIC=False build: deflate.py:724-732
             if (hm == 3u) FAIL(HDLZ_E_BAD_BTYPE);
             if (hm == 0u) {
@@ -333,7 +333,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 {
                     const int l1 = L.left[1], l2 = L.left[2];
                     if (l1 < 0 || (l1 > 0 && (int)nlen - (int)L.cnt[1][0] != 1)) FAIL(HDLZ_E_BAD_TREE);
-                    if (l2 < 0 || (l2 > 0 && (int)ndist - (int)L.cnt[2][0] != 1)) FAIL(HDLZ_E_BAD_TREE);
+                    // an EMPTY distance set (a block of literals only) is legal, RFC1951 3.2.7 -- zlib's inflate_table (max == 0)
+                    // and puff accept it; a distance symbol met later then finds no code (dlen > 15 -> BAD_SYMBOL)
+                    if (l2 < 0 || (l2 > 0 && (int)ndist - (int)L.cnt[2][0] > 1)) FAIL(HDLZ_E_BAD_TREE);
                 }
                 if ((int32_t)(BITPOS() >> 3) > isize - 3) FAIL(HDLZ_E_NO_EOF);
             }

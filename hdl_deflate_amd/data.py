@@ -63,6 +63,9 @@ def make_blocks(nblocks, n, device, seed=0, families=(1, 2, 3, 4), first_block=0
     g = torch.Generator(device=device)
     out = torch.empty((nblocks, n), dtype=torch.uint8, device=device)
     nf = len(families)
+    # the text families build int64 [rows, n] intermediates: bound a chunk to 2^25 elements (16384 rows of 2 KiB -- the
+    # default -- or 512 rows of 64 KiB).  Block contents depend on the chunk grid: shards must start on a chunk multiple.
+    chunk = max(nf, min(chunk, (1 << 25) // max(n, 1)))
     for c0 in range(0, nblocks, chunk):
         c1 = min(nblocks, c0 + chunk)
         for fi, f in enumerate(families):

@@ -1,10 +1,23 @@
 """Batch engine: thin Python over the C-ABI (include/hdlz.h).  torch is used for device memory and
 streams only.  All tensors live on the GPU; nothing here computes on the CPU."""
+import functools
+
 import torch
 
 from . import _lib
-from .constants import OK, pitch_for
+from .constants import OK, LMAX, pitch_for
 from .errors import Error
+
+
+def _on_device(fn):
+    """run an Engine method with the engine's GPU current: the C-ABI launches on the CURRENT HIP device and on torch's
+    current stream of that device, so an engine built for cuda:1 must not enqueue on cuda:0 because the caller forgot
+    torch.cuda.set_device"""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **kw)
+    return wrapper
 
 
 class Engine(object):
@@ -30,6 +43,7 @@ class Engine(object):
 
     def _prep(self, d_in, in_off, in_len, nblocks):
         assert d_in.is_cuda and d_in.dtype == torch.uint8 and d_in.is_contiguous()
+        assert d_in.device == self.device, "tensor on %s, engine on %s" % (d_in.device, self.device)
         if in_off is not None:
             assert in_off.is_cuda and in_off.dtype == torch.int64 and in_off.is_contiguous()
             nb = in_off.numel() - 1
@@ -41,10 +55,13 @@ class Engine(object):
         return None, in_len, in_len, nblocks
 
     # -- STARTC for a batch
+    @_on_device
     def compress_batch(self, d_in, in_off=None, in_len=None, nblocks=None, cwindow=32, maxmatch=10,
                        out=None, out_pitch=None, max_len=None):
-        """d_in: uint8 [B, pitch] (fixed-size blocks) or flat uint8 with in_off int64[B+1].
-        Returns (out uint8[B, out_pitch], out_len int32[B], status int32[B])."""
+        """d_in: uint8 [B, pitch] (fixed-size blocks) or flat uint8 with in_off int64[B+1] (ascending).
+        Returns (out uint8[B, out_pitch], out_len int32[B], status int32[B]); per-block failures are statuses, never
+        exceptions.  Ragged batches: pass `max_len` (an upper bound on the block lengths) or `out_pitch` -- without
+        either the bound is computed from in_off with ONE host sync per call."""
         off_ptr, pitch, ilen, nb = self._prep(d_in, in_off, in_len, nblocks)
         if out_pitch is None:
             if max_len is None:
@@ -57,7 +74,8 @@ class Engine(object):
         out_len = torch.empty(nb, dtype=torch.int32, device=d_in.device)
         status = torch.empty(nb, dtype=torch.int32, device=d_in.device)
         if in_off is None and ilen >= self.LARGE_BLOCK and pitch % 16 == 0 and nb <= self.MANY_WAVES and \
-                self.lib.hdlz_streams_work_bytes(ilen, nb) != 0:
+                out_pitch >= (self.lib.hdlz_out_bound(ilen) + 3) // 4 * 4 and self.lib.hdlz_streams_work_bytes(ilen, nb) != 0:
+            # (a too small out_pitch stays on the batch path, which reports E_OUT_CAPACITY per block instead of failing the call)
             # few large blocks: one wave per block (hdlz_compress_batch) would leave the GPU idle (a 1 MiB block is 5.5 ms
             # on a wave); all tiles of all blocks go through the stream passes together instead (same bytes)
             work = torch.empty((self.lib.hdlz_streams_work_bytes(ilen, nb) + 7) // 8, dtype=torch.int64, device=d_in.device)
@@ -77,6 +95,7 @@ class Engine(object):
     LARGE_BLOCK, MANY_WAVES = 1 << 16, 1200   # compress_batch: up to this many blocks of at least this size -> stream passes
                                               # (a wave does ~180 MB/s, the stream passes ~250 GB/s: crossover ~1400 blocks)
 
+    @_on_device
     def compress_stream(self, d_in, n, cwindow=32, maxmatch=10, out=None, work=None):
         """d_in: flat uint8 device tensor, readable up to n rounded up to 16.
         Returns (out uint8[cap], out_len int32[1], status int32[1])."""
@@ -96,6 +115,7 @@ class Engine(object):
         return out, out_len, status
 
     # -- STARTD for a batch
+    @_on_device
     def inflate_batch(self, d_in, in_off=None, in_len=None, nblocks=None, out_pitch=None, flags=0, obsize=0,
                       out=None):
         off_ptr, pitch, ilen, nb = self._prep(d_in, in_off, in_len, nblocks)
@@ -111,16 +131,19 @@ class Engine(object):
         return out, out_len, status
 
     # -- archive compaction
+    @_on_device
     def compact(self, rows, lens, offsets=None, archive=None):
         """rows uint8[B, pitch], lens int32[B] -> (archive uint8[total], offsets int64[B]).
         `offsets` (exclusive scan, e.g. global offsets after the multi-GPU length all-gather) and `archive`
         may be supplied; otherwise they are computed / allocated here (one host sync for the size)."""
         assert rows.is_cuda and rows.dtype == torch.uint8 and rows.dim() == 2 and rows.is_contiguous()
+        assert rows.device == self.device and lens.is_cuda and lens.dtype == torch.int32 and lens.numel() == rows.shape[0]
         B, pitch = rows.shape
         lens = lens.contiguous()
         if offsets is None:
             l64 = lens.to(torch.int64)
             offsets = torch.cumsum(l64, 0) - l64
+        assert offsets.is_cuda and offsets.dtype == torch.int64 and offsets.numel() == B, "offsets must be int64 [B] on the GPU"
         offsets = offsets.contiguous()
         if archive is None:
             total = int((offsets[-1] + lens[-1]).item()) if B else 0
@@ -131,6 +154,7 @@ class Engine(object):
         return archive, offsets
 
     # -- single-stream conveniences used by the port adapter (one START = one block)
+    @_on_device
     def compress_bytes(self, data, cwindow=32, maxmatch=10):
         """-> (status, bytes)"""
         n = len(data)
@@ -146,14 +170,17 @@ class Engine(object):
         st = int(st.item())
         return st, bytes(out[0, :int(ol.item())].cpu().numpy().tobytes())
 
+    @_on_device
     def inflate_bytes(self, z, out_cap=None, flags=0, obsize=0):
+        """-> (status, bytes).  Default capacity: deflate expands at most 1032:1 (a 258-byte match costs 2 bits), so
+        1032 n + 258 bytes hold any stream, capped at the reference's 2^LMAX counter range (deflate.py:73-76)."""
         n = len(z)
         pad = (n + 15) // 16 * 16 + 16
         host = torch.zeros(pad, dtype=torch.uint8)
         if n:
             host[:n] = torch.frombuffer(bytearray(z), dtype=torch.uint8)
         d = host.to(self.device).view(1, pad)
-        cap = out_cap if out_cap is not None else max(1 << 16, 260 * n)
+        cap = out_cap if out_cap is not None else min(1 << LMAX, max(1 << 16, 1032 * n + 258))
         cap = (cap + 15) // 16 * 16
         out, ol, st = self.inflate_batch(d, in_len=n, out_pitch=cap, flags=flags, obsize=obsize)
         st = int(st.item())

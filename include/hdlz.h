@@ -58,6 +58,9 @@ enum {
 
 /* inflate flags */
 #define HDLZ_INFLATE_ASSUME_FIXED 1u /* DYNAMIC=False build: every block is decoded as BTYPE=1 (deflate.py:724-732) */
+/* ONEBLOCK=True build (deflate.py:40-41; forced by LOWLUT, :43-49): BFINAL is never read (deflate.py:678) and the stream
+ * ends at the end of its FIRST block -- EOB (deflate.py:1542) or the last stored byte (:1617) -- whatever follows */
+#define HDLZ_INFLATE_ONEBLOCK 8u
 /* mapping hints (results are identical): by default batches of at most HDLZ_INFLATE_WAVE_THRESHOLD streams are decoded
  * one wave per stream, larger ones one lane per stream with a wave-per-stream second pass for dynamic-tree streams */
 #define HDLZ_INFLATE_LANE_PER_STREAM 2u

@@ -47,13 +47,19 @@ def _patch(lines, lineno, expect, new):
 _cache = {}
 
 
-def load_reference(cwindow=32, match10=True, fast=True, dynamic=True, obsize=512):
-    """exec deflate.py (by path) with patched constants; returns its namespace."""
-    key = (cwindow, match10, fast, dynamic, obsize)
+def load_reference(cwindow=32, match10=True, fast=True, dynamic=True, obsize=512, oneblock=False, lowlut=False):
+    """exec deflate.py (by path) with patched constants; returns its namespace.
+    lowlut=True is the reference's LOWLUT build (deflate.py:21-22, :43-49: inflate only, DYNAMIC=False, ONEBLOCK=True,
+    LMAX=16)."""
+    key = (cwindow, match10, fast, dynamic, obsize, oneblock, lowlut)
     if key in _cache:
         return _cache[key]
     with open(os.path.join(REF, "deflate.py")) as f:
         lines = f.readlines()
+    if lowlut:
+        _patch(lines, 22, "LOWLUT = False", "LOWLUT = True")
+        _patch(lines, 26, "COMPRESS = True", "COMPRESS = False")
+    _patch(lines, 41, "ONEBLOCK = False", "ONEBLOCK = %s" % bool(oneblock or lowlut))
     _patch(lines, 32, "DYNAMIC = True", "DYNAMIC = %s" % bool(dynamic))
     _patch(lines, 35, "MATCH10 = True", "MATCH10 = %s" % bool(match10))
     _patch(lines, 38, "FAST = True", "FAST = %s" % bool(fast))
@@ -62,7 +68,8 @@ def load_reference(cwindow=32, match10=True, fast=True, dynamic=True, obsize=512
     _patch(lines, 62, "OBSIZE = 512", "OBSIZE = %d" % obsize)
     ns = {"__name__": "deflate", "print": lambda *a, **k: None}
     exec(compile("".join(lines), os.path.join(REF, "deflate.py"), "exec"), ns)
-    assert ns["CWINDOW"] == cwindow and ns["MATCH10"] == bool(match10)
+    assert ns["CWINDOW"] == cwindow and (lowlut or ns["MATCH10"] == bool(match10))
+    assert ns["ONEBLOCK"] == bool(oneblock or lowlut) and ns["LMAX"] == (16 if lowlut else 24)
     _cache[key] = ns
     return ns
 

@@ -35,6 +35,7 @@
 #define HDLZ_E_BAD_TREE 10     /* dynamic block header describes an impossible Huffman code */
 
 #define HDLZ_INFLATE_ASSUME_FIXED 1u /* DYNAMIC=False build: BTYPE ignored (deflate.py:724-732) */
+#define HDLZ_INFLATE_ONEBLOCK 8u     /* ONEBLOCK=True build (deflate.py:40-41,:678,:1542,:1617) */
 
 /* RFC1951 tables, as in deflate.py:100-110 (regenerated from the RFC, not pasted). */
 static const uint16_t copy_length[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51,
@@ -341,6 +342,8 @@ int hdlz_oracle_inflate(const uint8_t* z, size_t zn, unsigned flags, uint32_t ob
     for (;;) {
         /* HEADER (deflate.py:677-732) */
         final = (int)get4(&r, 0, 1);
+        if (flags & HDLZ_INFLATE_ONEBLOCK) final = 1; /* ONEBLOCK build: BFINAL is not read (deflate.py:678), the first
+                                                        * EOB (:1542) / end of the first stored block (:1617) ends the stream */
         unsigned hm = (flags & HDLZ_INFLATE_ASSUME_FIXED) ? 1u : get4(&r, 1, 2);
         if (hm == 3) return HDLZ_E_BAD_BTYPE;
         if (hm == 0) {
@@ -407,7 +410,8 @@ int hdlz_oracle_inflate(const uint8_t* z, size_t zn, unsigned flags, uint32_t ob
             int err = canon_build(&lencode, lengths, nlen);
             if (err < 0 || (err > 0 && nlen - lencode.count[0] != 1)) return HDLZ_E_BAD_TREE;
             err = canon_build(&distcode, lengths + nlen, ndist);
-            if (err < 0 || (err > 0 && ndist - distcode.count[0] != 1)) return HDLZ_E_BAD_TREE;
+            /* an empty distance set (literals only) is legal (RFC1951 3.2.7; zlib inflate_table max == 0, puff) */
+            if (err < 0 || (err > 0 && ndist - distcode.count[0] > 1)) return HDLZ_E_BAD_TREE;
             if (r.di > isize - 3) return HDLZ_E_NO_EOF; /* header ran into the trailer / past the end */
         }
         /* NEXT / INFLATE loop */

@@ -13,6 +13,7 @@ OK, E_SHORT_INPUT, E_OUT_CAPACITY, E_BAD_BTYPE, E_BAD_DISTANCE, E_NO_EOF, E_DYNA
     E_BAD_SYMBOL, E_BAD_PARAM = range(9)
 E_HIP, E_BAD_TREE = 9, 10
 INFLATE_ASSUME_FIXED = 1
+INFLATE_ONEBLOCK = 8
 
 
 def build(force=False):
@@ -72,7 +73,7 @@ def compress(data, cwindow=32, maxmatch=10):
 def inflate(z, flags=0, obsize=0, out_cap=None):
     """-> (status, bytes)"""
     z = bytes(z)
-    cap = out_cap if out_cap is not None else max(1 << 16, 260 * len(z))
+    cap = out_cap if out_cap is not None else min(1 << 24, max(1 << 16, 1032 * len(z) + 258))   # deflate expands <= 1032:1
     out = ctypes.create_string_buffer(cap)
     ol = ctypes.c_size_t(0)
     rc = lib().hdlz_oracle_inflate(z, len(z), flags, obsize, out, cap, ctypes.byref(ol))

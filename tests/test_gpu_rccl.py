@@ -1,0 +1,106 @@
+"""GPU (-m gpu): the N>1 path on real hardware -- RCCL (torch.distributed backend "nccl") initialised with however
+many devices are visible, the HIP compress path on every rank's contiguous shard, the all-gather of the uint32
+output lengths, checked against the oracle; plus bench.py's sharded entry (BASELINE configs[4]
+shape, reduced) launched exactly as the driver launches it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, nblocks, n, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        import hdl_deflate_amd
+        from hdl_deflate_amd.data import make_blocks
+        from hdl_deflate_amd.shard import LengthGather, shard_range, archive_offsets
+        eng = hdl_deflate_amd.Engine(dev)
+        b0, b1 = shard_range(nblocks, rank, world)
+        d_in = make_blocks(b1 - b0, n, dev, seed=3, first_block=b0, chunk=4)
+        out, ol, st = eng.compress_batch(d_in)
+        lg = LengthGather(nblocks, dev)
+        all_len = lg.gather(ol).clone()
+        again = lg.gather(ol)                                   # buffers are reused: a second step gives the same
+        offs, total = archive_offsets(all_len)
+        torch.cuda.synchronize()
+        assert int((st != 0).sum()) == 0 and torch.equal(all_len, again)
+        assert torch.equal(all_len[b0:b1], ol)
+        q.put((rank, b0, d_in.cpu().numpy(), out.cpu().numpy(), all_len.cpu().numpy(), offs.cpu().numpy(), total))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_length_allgather_over_visible_devices(oracle):
+    import torch
+    import torch.multiprocessing as mp
+    world = torch.cuda.device_count()
+    assert world >= 1
+    nblocks, n = 16 * world + (3 if world > 1 else 0), 4096     # uneven shards whenever there is more than one rank
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_rank_main, args=(r, world, port, nblocks, n, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in ps), key=lambda t: t[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    want = []
+    for rank, b0, h_in, h_out, all_len, offs, total in res:
+        for k in range(h_in.shape[0]):
+            rc, ref = oracle.compress(h_in[k].tobytes(), 32, 10)
+            assert rc == 0 and h_out[k, :all_len[b0 + k]].tobytes() == ref, (rank, k)
+            want.append(len(ref))
+    for rank, b0, h_in, h_out, all_len, offs, total in res:      # every rank holds the whole job's lengths + offsets
+        assert all_len.tolist() == want
+        assert offs.tolist() == list(np.cumsum([0] + want[:-1])) and total == sum(want)
+
+
+def _run_bench(world, env_extra, args):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", str(world)] + args
+    p = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_sharded_entry_cfg5_shape():
+    """bench.py --gpus N as the driver launches it (torch.distributed.run, one rank per GPU): the configs[4] shape,
+    reduced to 2048 blocks; with a single visible device the same entry runs as two ranks sharing the GPU over gloo
+    (the collective is then not RCCL -- the RCCL leg is the test above)"""
+    import torch
+    ndev = torch.cuda.device_count()
+    args = ["--cfg5-blocks", "2048", "--steps", "2", "--warmup", "1"]
+    if ndev > 1:
+        r = _run_bench(ndev, {}, args)
+    else:
+        r = _run_bench(2, {"HDLZ_BENCH_BACKEND": "gloo"}, args)
+    assert r["scaling"] == "strong" and r["n_gpus"] == max(ndev, 2) and r["value"] > 0
+    assert r["config"]["blocks_total"] == 2048 and r["config"]["block_bytes"] == 65536
+    assert 0.3 < r["compression_ratio_out_over_in"] < 0.8 and r["roofline"]["frac"] > 0

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from hdl_deflate_amd.shard import shard_range, gather_lengths, archive_offsets, gather_archive
+from hdl_deflate_amd.shard import shard_range, gather_lengths, archive_offsets, gather_archive, LengthGather
 
 
 def test_shard_range_covers_everything():
@@ -32,6 +32,8 @@ def _worker(rank, world, port, nblocks, q):
         blocks = [family_bytes(1 + b % 4, 300 + (b % 5), seed=b, counter0=16 * b) for b in range(b0, b1)]
         lens = torch.tensor([len(O.compress(x)[1]) for x in blocks], dtype=torch.int32)
         all_len = gather_lengths(lens, nblocks)
+        lg = LengthGather(nblocks, "cpu")                 # the reusable form bench.py holds: same answer, twice
+        assert lg.gather(lens).tolist() == all_len.tolist() and lg.gather(lens).tolist() == all_len.tolist()
         offs, total = archive_offsets(all_len)
         # payload gather of the per-rank archives (8(f) rank 2): concatenation = the global archive
         mine = torch.frombuffer(bytearray(b"".join(O.compress(x)[1] for x in blocks)), dtype=torch.uint8)
@@ -42,11 +44,16 @@ def _worker(rank, world, port, nblocks, q):
 
 
 def test_length_allgather_world2():
+    _run_world2(11)                  # uneven shards: 6 + 5 (padded gather)
+    _run_world2(12)                  # equal shards: gathered straight into the result (the BASELINE configs[4] shape)
+
+
+def _run_world2(nblocks):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    nblocks, world = 11, 2           # uneven shards: 6 + 5
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ps = [ctx.Process(target=_worker, args=(r, world, port, nblocks, q)) for r in range(world)]
