@@ -5,7 +5,7 @@ Only the hot path of tomtor/HDL-deflate is here: STARTC (fixed-Huffman LZ77 comp
 include/hdlz.h), plus the host-side mirror of the reference's port interface (port.py).
 There is NO CPU fallback: every compute entry point raises if the HIP library or a GPU is missing.
 """
-from .errors import Error, HdlzStatusError                         # noqa: F401
+from .errors import Error, HdlzStatusError, HdlzRangeError                         # noqa: F401
 from .constants import (IDLE, WRITE, READ, STARTC, STARTD, OK, E_SHORT_INPUT, E_OUT_CAPACITY,   # noqa: F401
                         E_BAD_BTYPE, E_BAD_DISTANCE, E_NO_EOF, E_DYNAMIC_UNSUPPORTED, E_BAD_SYMBOL,
                         E_BAD_PARAM, E_HIP, E_BAD_TREE, INFLATE_ASSUME_FIXED, INFLATE_LANE_PER_STREAM, INFLATE_WAVE_PER_STREAM, INFLATE_ONEBLOCK,

@@ -7,7 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HDLZ_LIB") or os.path.join(_HERE, "lib", "libhdlz.so")   # HDLZ_LIB: A/B builds
 EXPORTS = ("hdlz_version", "hdlz_status_string", "hdlz_last_error", "hdlz_device_count", "hdlz_out_bound",
            "hdlz_compress_batch", "hdlz_inflate_batch", "hdlz_compact_batch",
-           "hdlz_stream_work_bytes", "hdlz_compress_stream", "hdlz_streams_work_bytes", "hdlz_compress_streams")
+           "hdlz_stream_work_bytes", "hdlz_compress_stream", "hdlz_streams_work_bytes", "hdlz_compress_streams",
+           "hdlz_compress_chunk", "hdlz_inflate_chunk")
 _lib = None
 
 
@@ -45,5 +46,9 @@ def load():
     L.hdlz_streams_work_bytes.argtypes = [ctypes.c_size_t, u64]
     L.hdlz_compress_streams.restype = ci
     L.hdlz_compress_streams.argtypes = [vp, u64, u32, u64, ci, ci, vp, u64, vp, vp, vp, ctypes.c_size_t, vp]
+    L.hdlz_compress_chunk.restype = ci
+    L.hdlz_compress_chunk.argtypes = [vp, u32, u32, ci, ci, ci, vp, u64, vp, vp]
+    L.hdlz_inflate_chunk.restype = ci
+    L.hdlz_inflate_chunk.argtypes = [vp, u32, ci, u32, u32, vp, u64, u32, vp, vp]
     _lib = L
     return L

@@ -181,4 +181,33 @@ int hdlz_compress_streams(const uint8_t* d_in, uint64_t in_pitch, uint32_t in_le
     return HDLZ_OK;
 }
 
+int hdlz_compress_chunk(const uint8_t* d_in, uint32_t in_len, uint32_t q_end, int final, int cwindow, int maxmatch,
+                        uint8_t* d_out, uint64_t out_cap, void* d_state, void* stream) {
+    if (cwindow < 1 || cwindow > 256) return fail_param("cwindow must be in [1,256]");
+    if (maxmatch != 5 && maxmatch != 10) return fail_param("maxmatch must be 5 (MATCH10=False) or 10 (MATCH10=True)");
+    if (!d_in || !d_out || !d_state) return fail_param("null device pointer");
+    if (in_len >= 0x80000000u) return fail_param("in_len too large");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 3u) || (reinterpret_cast<uintptr_t>(d_state) & 3u)) return fail_param("d_out / d_state must be 4-byte aligned");
+    int rc = check_device();
+    if (rc != HDLZ_OK) return rc;
+    hipError_t e = hdlz::launch_compress_chunk(d_in, in_len, q_end, final, cwindow, maxmatch, d_out, out_cap, d_state,
+                                               static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "launch k_compress_chunk");
+    return HDLZ_OK;
+}
+
+int hdlz_inflate_chunk(const uint8_t* d_in, uint32_t in_len, int final, uint32_t flags, uint32_t obsize, uint8_t* d_out,
+                       uint64_t out_cap, uint32_t out_limit, void* d_state, void* stream) {
+    if (flags & ~(HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_ONEBLOCK)) return fail_param("unknown flag");
+    if (!d_in || !d_out || !d_state) return fail_param("null device pointer");
+    if (in_len >= 0x10000000u) return fail_param("in_len too large (streams are limited to 256 MiB - 1)");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 3u) || (reinterpret_cast<uintptr_t>(d_state) & 3u)) return fail_param("d_out / d_state must be 4-byte aligned");
+    int rc = check_device();
+    if (rc != HDLZ_OK) return rc;
+    hipError_t e = hdlz::launch_inflate_chunk(d_in, in_len, final, flags, obsize, d_out, out_cap, out_limit, d_state,
+                                              static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "launch k_inflate_dyn<stream>");
+    return HDLZ_OK;
+}
+
 }  // extern "C"

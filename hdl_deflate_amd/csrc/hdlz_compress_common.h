@@ -392,4 +392,18 @@ __device__ __forceinline__ uint4 load_chunk16(const uint8_t* __restrict__ src, u
 }
 
 
+// ---- stage the tile that starts at position t0: [t0 - 256, t0 + 2048 + 16) straight from HBM (no carried halo: tiles are independent)
+__device__ __forceinline__ void stage_tile(uint8_t* lin8, const uint8_t* __restrict__ src, uint32_t t0, uint32_t n, bool aligned16,
+                                           uint32_t mis, uint32_t lane) {
+    __syncthreads();
+    const uint32_t nchunk = (HALO + TILE + LOOKAHEAD) / 16;          // 145 16-byte chunks
+    for (uint32_t c = lane; c < nchunk; c += 64) {
+        const int64_t p = (int64_t)t0 - HALO + (int64_t)c * 16;       // first position of the chunk
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (p >= 0 && p < (int64_t)n) v = load_chunk16(src, (uint32_t)p, n, aligned16, mis);
+        *reinterpret_cast<uint4*>(lin8 + c * 16u) = v;
+    }
+}
+
+
 }  // namespace hdlz

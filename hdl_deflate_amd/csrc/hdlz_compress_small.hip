@@ -69,7 +69,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             a.status[blk] = nb < 5u ? HDLZ_E_SHORT_INPUT : HDLZ_E_BAD_PARAM;
         }
         const uint32_t nrem = lane_ok ? nb - min(p_run, nb) : 0u; // positions of the block from this run on
-        const uint32_t nrem_m2 = nrem - 2u;
         // -------------------------------------------------------------- 1. stage: every lane loads its own run
         __syncthreads();
         {

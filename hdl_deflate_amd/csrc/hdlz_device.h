@@ -57,6 +57,11 @@ size_t stream_work_bytes(uint32_t n, uint32_t nblocks);
 hipError_t launch_compress_streams(const uint8_t* in, uint64_t in_pitch, uint32_t n, uint32_t nblocks, int cwindow, int maxmatch,
                                    uint8_t* out, uint64_t out_pitch, uint32_t* out_len, uint32_t* status, void* work,
                                    hipStream_t stream);
+typedef hdlz_cstate ChunkState;     // resumable compress session (include/hdlz.h)
+hipError_t launch_compress_chunk(const uint8_t* in, uint32_t n, uint32_t q_end, int final_, int cwindow, int maxmatch, uint8_t* out,
+                                 uint64_t out_cap, void* state, hipStream_t stream);
+hipError_t launch_inflate_chunk(const uint8_t* in, uint32_t in_len, int final_, uint32_t flags, uint32_t obsize, uint8_t* out,
+                                uint64_t out_cap, uint32_t out_limit, void* state, hipStream_t stream);
 hipError_t launch_compact(const uint8_t* rows, uint64_t pitch, const uint32_t* len, const uint64_t* off,
                           uint64_t nblocks, uint8_t* archive, hipStream_t stream);
 

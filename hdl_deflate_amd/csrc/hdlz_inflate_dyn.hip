@@ -25,6 +25,8 @@ constexpr uint32_t DRING = 2048;    // history ring bytes (power of two)
 constexpr uint32_t DCHUNK = 64;
 constexpr uint32_t IWIN = 512;      // compressed-input window staged in LDS (bytes)
 constexpr uint32_t DYN_ALL = 0x80000000u;   // internal flag bit: this kernel is the only pass, every stream is its
+constexpr uint32_t DYN_FINAL = 0x40000000u; // internal flag bit (STREAM): in_len is the final stream length
+constexpr uint32_t DYN_HDR_BYTES = 700;     // a dynamic block header is at most 14 + 19*3 + 316*(7+7) bits = 562 bytes
 constexpr uint32_t WCAP = 448;       // output bytes committed per decode window (< 512: see the ring argument at the commit)
 
 struct __attribute__((aligned(16))) DynLds {
@@ -146,11 +148,16 @@ __device__ __forceinline__ void xwalk(const XCode& X, uint32_t bits15, uint32_t&
     const uint32_t base = sel & 0xFFFFu, idx = (sel >> 16) & 0x1FFu;
     symi = idx + ((V - base) >> (15u - min(len, 15u)));
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_inflate_dyn(InflateArgs a) {
+// STREAM = the resumable form for ONE stream that arrives in pieces (hdlz_inflate_chunk): the decoder
+// state lives in a device-resident hdlz_istate between the calls; a call decodes until the stream ends, the input known so
+// far runs out (the reference's `di >= isize - 4 and not i_mode == IDLE` stall, deflate.py:1529-1530) or the output limit
+// is reached (its `do >= i_raddr + OBSIZE` hold, deflate.py:1531-1534, :1597-1599), always stopping BETWEEN two tokens.
+template <bool STREAM>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_inflate_dyn(InflateArgs a, hdlz_istate* ist, uint32_t out_limit) {
     __shared__ DynLds L;
     const uint32_t lane = threadIdx.x;
     for (uint64_t sid = blockIdx.x; sid < a.nstreams; sid += gridDim.x) {
-        if (!(a.flags & DYN_ALL) && a.status[sid] != HDLZ_E_DYNAMIC_UNSUPPORTED) continue;   // pass 1 finished this stream
+        if (!STREAM && !(a.flags & DYN_ALL) && a.status[sid] != HDLZ_E_DYNAMIC_UNSUPPORTED) continue;   // pass 1 finished this stream
         uint64_t off;
         uint32_t zn;
         if (a.in_off) {
@@ -160,13 +167,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             off = sid * a.in_pitch;
             zn = a.in_len;
         }
+        const bool sfinal = !STREAM || (a.flags & DYN_FINAL) != 0;      // the whole stream is here: the reference's end-of-input checks apply
+        uint32_t need = 0;                                              // STREAM: why this call stops (1 = input, 2 = output room)
+        if (STREAM) {
+            if (ist->done || ist->status != HDLZ_OK) return;            // a finished or failed session stays as it is
+            if (!sfinal && zn < 16u) {                                  // nothing decodable yet
+                if (lane == 0) { ist->need = 1; }
+                return;
+            }
+        }
         if (zn < 5u) {                              // R0/D0: the reference never starts (only reachable when this kernel is the first pass)
+            if (STREAM) { if (lane == 0) { ist->status = HDLZ_E_SHORT_INPUT; ist->out_pos = 0; } return; }
             if (lane == 0) { a.out_len[sid] = 0; a.status[sid] = HDLZ_E_SHORT_INPUT; }
             continue;
         }
         const uint8_t* __restrict__ z = a.in + off;
         uint8_t* __restrict__ out = a.out + sid * a.out_pitch;
-        const uint32_t cap = a.out_pitch > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a.out_pitch;
+        const uint32_t cap0 = a.out_pitch > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a.out_pitch;
+        const uint32_t cap = STREAM ? (out_limit < cap0 ? out_limit : cap0) : cap0;      // STREAM: reaching it is a stop, not an error
+        const uint32_t inbits = 8u * zn;                                                 // (zn < 2^28)
         const uint32_t obsize = a.obsize ? a.obsize : 32768u;
         const uint32_t len_mask = a.obsize ? ((1u << (31u - (uint32_t)__builtin_clz(a.obsize))) - 1u) : 0xFFFFu;
         const int32_t isize = (int32_t)zn - 1;
@@ -175,6 +194,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         uint32_t o = 0;                     // bytes produced
         uint64_t bb = 0;
         uint32_t bc = 0, ip = 2;            // D0: zlib header skipped unvalidated
+        uint32_t save_bit = 16, save_phase = 0, save_srem = 0;          // STREAM: where and how the next call resumes
         // a serial decoder must not pay a global-load latency per 4 input bytes: the compressed stream is
         // staged through an LDS window, filled cooperatively (coalesced) whenever the reader runs off its end
         uint32_t iwbase = ip - IWIN;        // forces a fill at the first refill
@@ -217,26 +237,64 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         // hand an absolute bit position back to the scalar bit reader
 #define RESYNC(bitp) do { ip = (bitp) >> 3; bb = 0; bc = 0; iwbase = ip - IWIN; REFILL(); TAKE((bitp) & 7u); } while (0)
 
+        // ---- STREAM: pick the session up where the previous call parked it
+        uint32_t r_phase = 0, r_final = 0, r_hm = 0, r_srem = 0, r_nlen = 0, r_ndist = 0;
+        if (STREAM && ist->started) {
+            o = ist->out_pos; r_phase = ist->phase; r_final = ist->final_; r_hm = ist->hm; r_srem = ist->srem;
+            r_nlen = ist->nlen; r_ndist = ist->ndist;
+            save_bit = ist->bitpos; save_phase = r_phase; save_srem = r_srem;
+            // the history ring is re-primed from the output produced so far
+            const uint32_t h0 = o > DRING ? o - DRING : 0u;
+            for (uint32_t k = h0 + lane; k < o; k += 64u) L.ring[k & (DRING - 1u)] = out[k];
+            if (r_phase == 1u && r_hm == 2u)
+                for (uint32_t k = lane; k < 320u; k += 64u) L.lengths[k] = ist->lengths[k];
+            __syncthreads();
+            RESYNC(save_bit);
+        }
         for (;;) {
+            uint32_t final_, hm;
+            uint32_t blk_bit = 0;
+            bool resumed = false;
+            if (STREAM && r_phase != 0u) {          // inside a block: no header to read
+                final_ = r_final; hm = r_hm; resumed = true;
+            } else {
             REFILL();
+            blk_bit = BITPOS();
+            if (STREAM && !sfinal && blk_bit + 64u > inbits) { save_bit = blk_bit; save_phase = 0; need = 1; goto done; }
             // HEADER (deflate.py:677-732)
-            const uint32_t final_ = ((uint32_t)bb & 1u) | ((a.flags & HDLZ_INFLATE_ONEBLOCK) ? 1u : 0u);   // ONEBLOCK: deflate.py:678,:1542,:1617
-            const uint32_t hm = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) ? 1u : ((uint32_t)(bb >> 1) & 3u);   // DYNAMIC=False build: deflate.py:724-732
+            final_ = ((uint32_t)bb & 1u) | ((a.flags & HDLZ_INFLATE_ONEBLOCK) ? 1u : 0u);   // ONEBLOCK: deflate.py:678,:1542,:1617
+            hm = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) ? 1u : ((uint32_t)(bb >> 1) & 3u);   // DYNAMIC=False build: deflate.py:724-732
+            }
             if (hm == 3u) FAIL(HDLZ_E_BAD_BTYPE);
             if (hm == 0u) {
                 // stored (deflate.py:709-717, COPY :1603-1626)
-                const uint32_t dio = BITPOS() & 7u;
-                uint32_t skip = 8u - dio;
-                if (skip <= 2u) skip = 16u - dio;
-                const uint32_t length = (uint32_t)(bb >> skip) & 0xFFFFu & len_mask;
-                TAKE(skip + 16u);
-                REFILL();
-                TAKE(16u);                                   // NLEN unchecked (D2)
-                const uint32_t p0 = BITPOS() >> 3;            // first data byte (bit reader is byte aligned here)
+                uint32_t length, p0;
+                if (STREAM && resumed) {                      // the rest of a stored block the previous call could not finish
+                    length = r_srem; p0 = save_bit >> 3;
+                } else {
+                    const uint32_t dio = BITPOS() & 7u;
+                    uint32_t skip = 8u - dio;
+                    if (skip <= 2u) skip = 16u - dio;
+                    length = (uint32_t)(bb >> skip) & 0xFFFFu & len_mask;
+                    TAKE(skip + 16u);
+                    REFILL();
+                    TAKE(16u);                                // NLEN unchecked (D2)
+                    p0 = BITPOS() >> 3;                       // first data byte (bit reader is byte aligned here)
+                }
                 // the reference checks, byte by byte and in this order: input left (deflate.py:1600), then room
                 const uint32_t i_noeof = (int32_t)p0 >= isize ? 0u : (uint32_t)isize - p0;
                 const uint32_t i_cap = cap - o;
-                if (length > (i_noeof < i_cap ? i_noeof : i_cap)) FAIL(i_noeof <= i_cap ? HDLZ_E_NO_EOF : HDLZ_E_OUT_CAPACITY);
+                const uint32_t whole = length;
+                if (STREAM) {
+                    // input known so far: the reference's COPY holds while di >= isize - 2 (deflate.py:1600)
+                    const uint32_t i_in = sfinal ? i_noeof : (zn >= p0 + 2u ? zn - 2u - p0 : 0u);
+                    const uint32_t lim = i_in < i_cap ? i_in : i_cap;
+                    if (length > lim) {
+                        if (i_in <= i_cap) { if (sfinal) FAIL(HDLZ_E_NO_EOF); need = 1; }
+                        else need = 2;
+                        length = lim;                         // copy what can be copied, park the rest
+                    }
+                } else if (length > (i_noeof < i_cap ? i_noeof : i_cap)) FAIL(i_noeof <= i_cap ? HDLZ_E_NO_EOF : HDLZ_E_OUT_CAPACITY);
                 {
                     // bytes of the current, still unflushed line live only in the ring: push them out first
                     const uint32_t c0 = o & ~(DCHUNK - 1u);
@@ -249,13 +307,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
                 o += length;
+                if (STREAM) {
+                    if (need == 0u && !sfinal && p0 + length + 2u > zn) need = 1;           // is the block properly followed?  not known yet
+                    if (need != 0u) {
+                        save_bit = 8u * (p0 + length); save_phase = 2; save_srem = whole - length;
+                        r_final = final_; r_hm = 0;
+                        goto done;
+                    }
+                    r_phase = 0;
+                }
                 if ((int32_t)(p0 + length) >= isize) FAIL(HDLZ_E_NO_EOF);      // deflate.py:1617-1626 with the COPY hold
                 ip = p0 + length; bb = 0; bc = 0;                              // resynchronise the bit reader
                 iwbase = ip - IWIN;                                            // ... and refill the window there
                 if (final_) break;
                 continue;
             }
-            TAKE(3u);
+            if (!(STREAM && resumed)) {
+                // STREAM: a dynamic header is only parsed when it is here as a whole
+                if (STREAM && !sfinal && hm == 2u && blk_bit + 8u * DYN_HDR_BYTES > inbits) { save_bit = blk_bit; save_phase = 0; need = 1; goto done; }
+                TAKE(3u);
+            }
+            uint32_t nlen = r_nlen, ndist = r_ndist;
             if (hm == 1u) {
                 // fixed code lengths (deflate.py:1066-1073)
                 for (uint32_t s = lane; s < 288u; s += 64u) L.lengths[s] = (uint8_t)(s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8);
@@ -264,11 +336,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 canon_build(L, 1, L.lengths, L.lsym, 288, lane);
                 canon_build(L, 2, L.lengths + 288, L.dsym, 32, lane);
                 __syncthreads();
+            } else if (STREAM && resumed) {
+                // the code lengths of the block came back with the state: rebuild the two codes
+                canon_build(L, 1, L.lengths, L.lsym, (int)nlen, lane);
+                canon_build(L, 2, L.lengths + nlen, L.dsym, (int)ndist, lane);
+                __syncthreads();
             } else {
                 // BL (deflate.py:1090-1114)
                 REFILL();
-                const uint32_t nlen = ((uint32_t)bb & 31u) + 257u;
-                const uint32_t ndist = ((uint32_t)(bb >> 5) & 31u) + 1u;
+                nlen = ((uint32_t)bb & 31u) + 257u;
+                ndist = ((uint32_t)(bb >> 5) & 31u) + 1u;
                 const uint32_t ncode = ((uint32_t)(bb >> 10) & 15u) + 4u;
                 TAKE(14u);
                 if (nlen > 286u || ndist > 30u) FAIL(HDLZ_E_BAD_TREE);
@@ -337,8 +414,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     // and puff accept it; a distance symbol met later then finds no code (dlen > 15 -> BAD_SYMBOL)
                     if (l2 < 0 || (l2 > 0 && (int)ndist - (int)L.cnt[2][0] > 1)) FAIL(HDLZ_E_BAD_TREE);
                 }
-                if ((int32_t)(BITPOS() >> 3) > isize - 3) FAIL(HDLZ_E_NO_EOF);
+                if (sfinal && (int32_t)(BITPOS() >> 3) > isize - 3) FAIL(HDLZ_E_NO_EOF);
+                if (STREAM) {                                        // the block's code lengths travel with the session
+                    for (uint32_t k = lane; k < 320u; k += 64u) ist->lengths[k] = L.lengths[k];
+                    if (lane == 0) { ist->nlen = nlen; ist->ndist = ndist; }
+                }
             }
+            if (STREAM) { r_final = final_; r_hm = hm; r_nlen = nlen; r_ndist = ndist; r_phase = 0; }
             {
                 XCode XL, XD;
                 build_x(XL, L.cnt[1]);
@@ -403,19 +485,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     const uint32_t outlen = (inchain && plain) ? (lit ? 1u : tlen) : 0u;
                     const uint32_t pos = o + excl;
                     // ---- the reference's checks, per token, in its order (deflate.py:1409-1445, :1519-1591, :1447-1517, :1600)
-                    constexpr uint32_t ST_EOB = 100, ST_CUT = 101;
+                    constexpr uint32_t ST_EOB = 100, ST_CUT = 101, ST_NEEDIN = 102, ST_NEEDOUT = 103;
                     uint32_t st = 0;
-                    if (!valid) st = HDLZ_E_BAD_SYMBOL;
+                    // STREAM, more input to come: a token is only decoded when its 64 bits are here; the end-of-input checks
+                    // (deflate.py:1535-1539, :1600) are the final call's business -- and hold for every token decoded earlier
+                    if (STREAM && !sfinal && bitpos + 64u > inbits) st = ST_NEEDIN;
+                    else if (!valid) st = HDLZ_E_BAD_SYMBOL;
                     else if (hm == 1u && sym == 287u) st = HDLZ_E_BAD_SYMBOL;                        // zero leaf, deflate.py:212,:1437-1439
-                    else if ((int32_t)((bitpos + len) >> 3) > isize - 3) st = HDLZ_E_NO_EOF;         // deflate.py:1535-1539
+                    else if (sfinal && (int32_t)((bitpos + len) >> 3) > isize - 3) st = HDLZ_E_NO_EOF;         // deflate.py:1535-1539
                     else if (eobt) st = ST_EOB;
-                    else if (lit) { if (pos >= cap) st = HDLZ_E_OUT_CAPACITY; }
+                    else if (lit) { if (pos >= cap) st = STREAM ? ST_NEEDOUT : (uint32_t)HDLZ_E_OUT_CAPACITY; }
                     else if (token >= 29u) st = HDLZ_E_BAD_SYMBOL;
                     else if (dlen > 15u) st = HDLZ_E_BAD_SYMBOL;
                     else if (ds >= 30u) st = HDLZ_E_BAD_DISTANCE;
                     else if (distance > pos || distance > obsize) st = HDLZ_E_BAD_DISTANCE;          // deflate.py:1506-1508, D8
-                    else if ((int32_t)((bitpos + total) >> 3) >= isize - 2) st = HDLZ_E_NO_EOF;      // COPY hold, :1600
-                    else if ((uint64_t)pos + tlen > cap) st = HDLZ_E_OUT_CAPACITY;
+                    else if (sfinal && (int32_t)((bitpos + total) >> 3) >= isize - 2) st = HDLZ_E_NO_EOF;      // COPY hold, :1600
+                    else if ((uint64_t)pos + tlen > cap) st = STREAM ? ST_NEEDOUT : (uint32_t)HDLZ_E_OUT_CAPACITY;
                     if (st == 0u && excl + outlen > WCAP) st = ST_CUT;                               // rest of the chain: next window
                     const uint64_t special = __ballot(inchain && st != 0u);
                     uint64_t commit = chain;
@@ -427,6 +512,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         commit = chain & ((1ull << f) - 1ull);
                         consumed = f;
                         if (stf == ST_EOB) { consumed = f + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f); eob = true; }
+                        if (STREAM && (stf == ST_NEEDIN || stf == ST_NEEDOUT)) need = stf == ST_NEEDIN ? 1u : 2u;
                         o_new = o + (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)f);
                     } else {
                         o_new = o + acc;                            // (no stop inside the window: acc covers the whole chain)
@@ -460,6 +546,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     flush_lines(o, o_new);
                     o = o_new;
                     bp += consumed;
+                    if (STREAM && need != 0u) { save_bit = bp; save_phase = 1; goto done; }   // parked between two tokens
                 }
                 RESYNC(bp);                                         // back to the scalar bit reader (block headers)
             }
@@ -470,6 +557,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (status == HDLZ_OK) {
             const uint32_t c0 = o & ~(DCHUNK - 1u);
             if (c0 + lane < o) out[c0 + lane] = L.ring[(c0 + lane) & (DRING - 1u)];
+        }
+        if (STREAM) {
+            if (lane == 0) {
+                ist->started = 1; ist->status = status; ist->need = status == HDLZ_OK ? need : 0u;
+                ist->done = (status == HDLZ_OK && need == 0u) ? 1u : 0u;
+                ist->out_pos = status == HDLZ_OK ? o : 0u;
+                ist->bitpos = save_bit; ist->phase = save_phase; ist->srem = save_srem;
+                ist->final_ = r_final; ist->hm = r_hm; ist->nlen = r_nlen; ist->ndist = r_ndist;
+            }
+            return;
         }
         if (lane == 0) {
             a.out_len[sid] = status == HDLZ_OK ? o : 0u;
@@ -490,7 +587,16 @@ hipError_t launch_inflate_dyn(const InflateArgs& a0, hipStream_t stream, bool al
     InflateArgs a = a0;
     if (all) a.flags |= DYN_ALL;
     uint64_t g = a.nstreams < 65536u ? a.nstreams : 65536u;
-    hipLaunchKernelGGL(k_inflate_dyn, dim3((unsigned)g), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(k_inflate_dyn<false>, dim3((unsigned)g), dim3(64), 0, stream, a, (hdlz_istate*)nullptr, 0u);
+    return hipGetLastError();
+}
+
+// one call of a resumable session (hdlz_inflate_chunk): the stream bytes known so far, the session state, the output limit
+hipError_t launch_inflate_chunk(const uint8_t* in, uint32_t in_len, int final_, uint32_t flags, uint32_t obsize, uint8_t* out,
+                                uint64_t out_cap, uint32_t out_limit, void* state, hipStream_t stream) {
+    InflateArgs a{in, nullptr, 0, in_len, 1, (flags & (HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_ONEBLOCK)) | DYN_ALL | (final_ ? DYN_FINAL : 0u),
+                  obsize, out, out_cap, nullptr, nullptr};
+    hipLaunchKernelGGL(k_inflate_dyn<true>, dim3(1), dim3(64), 0, stream, a, static_cast<hdlz_istate*>(state), out_limit);
     return hipGetLastError();
 }
 

@@ -153,6 +153,13 @@ class Engine(object):
         self._check(rc, "hdlz_compact_batch")
         return archive, offsets
 
+    # -- streaming sessions (hdlz_compress_chunk / hdlz_inflate_chunk): the port adapter's streaming mode
+    def compress_session(self, cwindow=32, maxmatch=10):
+        return CompressSession(self, cwindow, maxmatch)
+
+    def inflate_session(self, flags=0, obsize=0):
+        return InflateSession(self, flags, obsize)
+
     # -- single-stream conveniences used by the port adapter (one START = one block)
     @_on_device
     def compress_bytes(self, data, cwindow=32, maxmatch=10):
@@ -185,3 +192,113 @@ class Engine(object):
         out, ol, st = self.inflate_batch(d, in_len=n, out_pitch=cap, flags=flags, obsize=obsize)
         st = int(st.item())
         return st, bytes(out[0, :int(ol.item())].cpu().numpy().tobytes())
+
+
+class _Session(object):
+    """device-resident buffers of one streaming session: the input seen so far (linear, grows), the output (linear, grows)
+    and the kernel's state words; see hdlz_compress_chunk / hdlz_inflate_chunk in include/hdlz.h"""
+
+    def __init__(self, engine, state_words, in_cap=1 << 12, out_cap=1 << 13):
+        self.eng, self.lib, self.dev = engine, engine.lib, engine.device
+        with torch.cuda.device(self.dev):
+            self.d_in = torch.zeros(in_cap, dtype=torch.uint8, device=self.dev)
+            self.d_out = torch.zeros(out_cap, dtype=torch.uint8, device=self.dev)
+            self.d_state = torch.zeros(state_words, dtype=torch.int32, device=self.dev)
+        self.n = 0                    # input bytes on the device
+
+    def write(self, data):
+        """append input bytes (host -> device)"""
+        k = len(data)
+        if not k:
+            return
+        with torch.cuda.device(self.dev):
+            if self.n + k + 64 > self.d_in.numel():
+                grown = torch.zeros(max(2 * self.d_in.numel(), self.n + k + 4096), dtype=torch.uint8, device=self.dev)
+                grown[:self.n] = self.d_in[:self.n]
+                self.d_in = grown
+            self.d_in[self.n:self.n + k] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(self.dev)
+        self.n += k
+
+    def _need_out(self, cap):
+        if cap > self.d_out.numel():
+            with torch.cuda.device(self.dev):
+                grown = torch.zeros(max(2 * self.d_out.numel(), cap), dtype=torch.uint8, device=self.dev)
+                grown[:self.d_out.numel()] = self.d_out
+                self.d_out = grown
+
+    def _state(self):
+        return self.d_state.cpu().tolist()           # (the sync point of a step)
+
+    def output(self, a, b):
+        """output bytes [a, b) (must be below what the last step reported as produced)"""
+        return bytes(self.d_out[a:b].cpu().numpy().tobytes()) if b > a else b""
+
+
+class CompressSession(_Session):
+    """STARTC for a stream that arrives in pieces: write() bytes as they come, step() encodes what can be encoded (the
+    reference's rule: a position needs ten known bytes behind it, deflate.py:768-770, unless the input has ended).  Output
+    is ONE zlib stream, bit-identical to compress_batch on the whole input."""
+
+    def __init__(self, engine, cwindow=32, maxmatch=10):
+        super().__init__(engine, 16)
+        self.cwindow, self.maxmatch = cwindow, maxmatch
+        self.pos = 0                  # positions [0, pos) are encoded
+        self.out_len = 0              # complete output bytes readable
+        self.done = False
+
+    def encodable(self, final=False):
+        """positions step() could encode now (a multiple of 32 unless final)"""
+        if final:
+            return self.n - self.pos
+        return max(0, (self.n - 11 - self.pos) // 32 * 32)
+
+    def step(self, final=False, max_positions=None):
+        """encode up to max_positions (rounded down to a multiple of 32) of the pending positions; with final=True and no
+        cap left over, finish the stream.  Returns the status code (OK also when there was nothing to do)."""
+        if self.done:
+            return OK
+        from .constants import E_SHORT_INPUT
+        nonfinal = max(0, (self.n - 11 - self.pos) // 32 * 32)
+        cap = None if max_positions is None else max_positions // 32 * 32
+        if final and self.n < 5:
+            return E_SHORT_INPUT                              # R0: the reference never starts
+        if final and (max_positions is None or self.n - self.pos <= max_positions):
+            k, fin = self.n - self.pos, True
+        else:
+            k, fin = (nonfinal if cap is None else min(nonfinal, cap)), False
+        if k <= 0:
+            return OK
+        q_end = self.pos + k
+        self._need_out(self.lib.hdlz_out_bound(self.n + 64) + 4096)
+        with torch.cuda.device(self.dev):
+            rc = self.lib.hdlz_compress_chunk(self.d_in.data_ptr(), self.n, q_end, 1 if fin else 0, self.cwindow, self.maxmatch,
+                                              self.d_out.data_ptr(), self.d_out.numel(), self.d_state.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream)
+        self.eng._check(rc, "hdlz_compress_chunk")
+        st = self._state()
+        self.pos, self.done, self.out_len = st[0], bool(st[8]), st[9]
+        return st[10]
+
+
+class InflateSession(_Session):
+    """STARTD for a stream that arrives in pieces and whose output is drained through a bounded window: step() decodes until
+    the stream ends, the input known so far runs out (need == 1) or out_limit bytes are produced (need == 2)."""
+
+    def __init__(self, engine, flags=0, obsize=0, out_cap=1 << 16):
+        super().__init__(engine, 16 + 80, out_cap=out_cap)
+        self.flags, self.obsize = flags, obsize
+        self.out_pos, self.done, self.need = 0, False, 1
+
+    def step(self, final=False, out_limit=None):
+        if self.done:
+            return OK
+        limit = (1 << LMAX) if out_limit is None else out_limit
+        self._need_out(min(limit, 1 << LMAX) + 64)
+        with torch.cuda.device(self.dev):
+            rc = self.lib.hdlz_inflate_chunk(self.d_in.data_ptr(), self.n, 1 if final else 0, self.flags, self.obsize,
+                                             self.d_out.data_ptr(), self.d_out.numel(), min(limit, 0xFFFFFFFF),
+                                             self.d_state.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        self.eng._check(rc, "hdlz_inflate_chunk")
+        st = self._state()
+        self.out_pos, self.done, self.need = st[1], bool(st[9]), st[11]
+        return st[10]

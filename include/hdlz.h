@@ -142,6 +142,70 @@ int hdlz_compress_stream(const uint8_t* d_in, uint32_t in_len, int cwindow, int 
                          uint64_t out_cap, uint32_t* d_out_len, uint32_t* d_status, void* d_work,
                          size_t work_bytes, void* stream);
 
+/* ---- STARTC for a stream that arrives in pieces (the streaming mode of the port) ------------------
+ * The reference compresses WHILE the caller is still WRITE-ing (test_deflate.py:197-286): position di is encoded as soon as
+ * ten more bytes are known (`di >= isize - 10 and i_mode != IDLE` stalls, deflate.py:768-770) and output becomes readable as
+ * it is produced (put / do_flush, deflate.py:535-567).  hdlz_compress_chunk is that mode for a device-resident stream: any
+ * number of calls produce ONE zlib stream / ONE deflate block, bit-identical to hdlz_compress_batch over the whole input.
+ *   d_state   64-byte device-resident session (hdlz_cstate), ZEROED by the caller before the first call of a stream
+ *   d_in      the stream from its first byte on (the pointer may change between calls, the bytes [0, in_len) may not),
+ *             in_len = the bytes known so far
+ *   q_end     this call encodes the positions [state.pos, q_end).  Not final: q_end <= in_len - 11 (the reference's stall
+ *             margin: every encoded position then has its whole look-ahead, whatever the final length will be) and
+ *             q_end - state.pos a positive multiple of 32.  Final: q_end == in_len = the stream length (>= 5, else
+ *             HDLZ_E_SHORT_INPUT); writes EOB, padding, Adler-32 and sets done.
+ *   d_out     the whole output stream, linear, 4-byte aligned; out_cap >= hdlz_out_bound(final length) + 2400
+ * After a call state.out_len complete output bytes are readable at d_out (the final call: the stream length, R9).
+ * Violations are reported in state.status (HDLZ_E_BAD_PARAM / _OUT_CAPACITY / _SHORT_INPUT); a failed or finished session
+ * ignores further calls.  One wave per call: the port adapter's path, not a throughput path. */
+typedef struct hdlz_cstate {
+    uint32_t pos;          /* positions [0, pos) are encoded */
+    uint32_t skip;         /* positions from pos on that the last match already covers (greedy-parse state) */
+    uint32_t out_words;    /* complete 32-bit words already in d_out */
+    uint32_t base_bits;    /* valid bits of carry_word */
+    uint32_t carry_word;   /* the partial output word (put's ob1/doo, deflate.py:535-560) */
+    uint32_t adler_a;      /* sum x_p mod 65521 */
+    uint32_t adler_c;      /* sum p * x_p mod 65521 */
+    uint32_t started;
+    uint32_t done;         /* the trailer is written; out_len is the length of the zlib stream */
+    uint32_t out_len;      /* complete output bytes readable so far */
+    uint32_t status;       /* HDLZ_OK or HDLZ_E_* */
+    uint32_t reserved[5];
+} hdlz_cstate;
+int hdlz_compress_chunk(const uint8_t* d_in, uint32_t in_len, uint32_t q_end, int final, int cwindow, int maxmatch,
+                        uint8_t* d_out, uint64_t out_cap, void* d_state, void* stream);
+
+/* ---- STARTD for a stream that arrives in pieces -----------------------------------------------------------------------
+ * The reference inflates while input is still being written and while the caller drains oram: it stalls on input
+ * (`di >= isize - 4 and not i_mode == IDLE`, deflate.py:1529-1530; COPY: :1600-1602) and on output room
+ * (`do >= i_raddr + OBSIZE`, deflate.py:1531-1534, :1597-1599).  hdlz_inflate_chunk is that mode: the decoder state lives in
+ * a device-resident hdlz_istate (ZEROED by the caller before the first call) and every call decodes until
+ *   - the stream ends                      -> state.done = 1, state.out_pos = the output length
+ *   - the input known so far runs out      -> state.need = 1  (call again with more bytes / final = 1)
+ *   - out_limit output bytes are reached   -> state.need = 2  (call again with a larger limit: the reader has advanced)
+ *   - the stream is bad                    -> state.status = HDLZ_E_* (the codes of hdlz_inflate_batch)
+ * always stopping BETWEEN two tokens, so the bytes [0, state.out_pos) of d_out are final after every call.
+ *   d_in / in_len  the stream from its first byte on, in_len = bytes known so far (the pointer may change between calls,
+ *                  the bytes may not); final != 0: in_len is the stream length and the reference's end-of-input checks apply
+ *   flags          HDLZ_INFLATE_ASSUME_FIXED / HDLZ_INFLATE_ONEBLOCK;  obsize as in hdlz_inflate_batch
+ *   d_out/out_cap  the whole output, linear (back-references read it);  out_limit: produce at most this many bytes in total
+ * Results are identical to hdlz_inflate_batch on the complete stream.  One wave per call (the port adapter's path). */
+typedef struct hdlz_istate {
+    uint32_t bitpos;       /* next stream bit to decode */
+    uint32_t out_pos;      /* output bytes produced (final, readable) */
+    uint32_t phase;        /* 0 at a block header, 1 inside a Huffman block, 2 inside a stored block */
+    uint32_t final_;       /* BFINAL of the current block */
+    uint32_t hm;           /* BTYPE of the current block */
+    uint32_t srem;         /* stored block: bytes still to copy */
+    uint32_t nlen, ndist;  /* dynamic block: HLIT + 257, HDIST + 1 */
+    uint32_t started, done, status;
+    uint32_t need;         /* 0, 1 = more input, 2 = more output room */
+    uint32_t reserved[4];
+    uint8_t lengths[320];  /* dynamic block: the code lengths (the decode tables are rebuilt from them on resume) */
+} hdlz_istate;
+int hdlz_inflate_chunk(const uint8_t* d_in, uint32_t in_len, int final, uint32_t flags, uint32_t obsize, uint8_t* d_out,
+                       uint64_t out_cap, uint32_t out_limit, void* d_state, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -527,3 +527,94 @@ def test_port_adapter_on_gpu_modes(engine):
     g = load_golden("port_modes.json")
     for rec in g["modes"]:
         run_mode_flow(rec, engine)
+
+
+def test_inflate_oneblock_lowlut_builds_and_empty_distance_code(engine):
+    """ONEBLOCK / LOWLUT reference builds (variants_vectors.json, oracle/gen_golden_r2.py) through both decoders; a dynamic
+    block with an empty distance code (RFC1951 3.2.7) is accepted like zlib accepts it"""
+    from conftest import empty_distance_stream
+    g = load_golden("variants_vectors.json")
+    for v in g["oneblock"]:
+        flags = (1 if ("DYNAMIC=False" in v["build"] or "LOWLUT" in v["build"]) else 0) | 8
+        for mapping in MAPPINGS:
+            st, out = engine.inflate_bytes(bytes.fromhex(v["z_hex"]), flags=flags | mapping, obsize=512)
+            assert st == 0 and out.hex() == v["out_hex"], (v["build"], v["name"], mapping)
+    z = empty_distance_stream()
+    for mapping in MAPPINGS:
+        st, out = engine.inflate_bytes(z, flags=mapping)
+        assert st == 0 and out == b"aaaaa" == zlib.decompress(z)
+
+
+def test_inflate_bytes_high_ratio_streams(engine):
+    """deflate expands up to 1032:1 -- the default capacity of inflate_bytes / the port must hold such streams"""
+    from test_port_protocol import make_dut, stream_leg
+    from hdl_deflate_amd import STARTD
+    for data in (b"Hello World! 1 " * 20000, bytes(1 << 20)):
+        z = zlib.compress(data, 9)
+        assert len(data) > 260 * len(z) and len(data) > (1 << 16)
+        st, out = engine.inflate_bytes(z)
+        assert st == 0 and out == data
+    z = zlib.compress(bytes(200000), 9)
+    dut, s = make_dut(engine)
+    res, total = stream_leg(dut, s, z, STARTD)
+    assert total == 200000 and res == bytes(200000)
+
+
+def test_port_streaming_mode_on_gpu(engine):
+    """SURVEY 8(f) rank 3 on the HIP engine: the streaming port (bounded circular iram / oram, a resumable kernel call per
+    filled window, the OBSIZE hold) under the reference's harness with a slow reader / slow writer -- replay of the
+    trajectories recorded from the executed reference -- and through the six reference test modes"""
+    from test_port_protocol import run_backpressure_fixture, run_streaming_mode_flows, make_dut, stream_leg
+    from hdl_deflate_amd import STARTC, STARTD, HdlzRangeError
+    g = load_golden("variants_vectors.json")
+    for v in g["backpressure"]:
+        stats = run_backpressure_fixture(v, engine)
+        assert stats["cycles"] > 0
+    run_streaming_mode_flows(engine)
+    # a stream much longer than both rings, dynamic trees, tiny OBSIZE: every byte still arrives, in order
+    data = DYN_TEXT * 30
+    z = zlib.compress(data, 6)
+    dut, s = make_dut(engine, streaming=True, stream_obsize=512, ibsize=64, window=32)
+    res, total = stream_leg(dut, s, z, STARTD, read_every=2)
+    assert res == data and dut.launches > 20
+    with pytest.raises(ValueError):                          # a 258-byte copy never fits a smaller output buffer (deflate.py:1597)
+        dut, s = make_dut(engine, streaming=True, stream_obsize=64)
+        stream_leg(dut, s, z, STARTD)
+    dut, s = make_dut(engine, streaming=True, stream_obsize=128, ibsize=128, cwindow=32)
+    res, total = stream_leg(dut, s, data, STARTC, write_every=2)
+    assert zlib.decompress(res) == data and res == engine.compress_bytes(data)[1]
+    # LMAX = 16 (LOWLUT build): 65 535 bytes pass, one more does not fit the counters
+    for v in g["lmax16"]:
+        dut, s = make_dut(engine, lmax=16, inflate_flags=1 | 8, streaming=True)
+        if v["error"] is None:
+            res, total = stream_leg(dut, s, bytes.fromhex(v["z_hex"]), STARTD)
+            assert total == 65535
+        else:
+            with pytest.raises(HdlzRangeError):
+                stream_leg(dut, s, bytes.fromhex(v["z_hex"]), STARTD)
+
+
+def test_block_chaining_beyond_lmax(engine):
+    """inputs longer than the reference's 2^LMAX counters are chained block by block -- one complete
+    zlib stream per block, every block inside the counter range -- and inflate back to the input"""
+    import torch
+    from hdl_deflate_amd.chain import compress_chained, inflate_chained, plan_blocks, MAX_BLOCK
+    from hdl_deflate_amd.data import make_blocks
+    assert plan_blocks(100, 64) == [(0, 64), (64, 36)] and plan_blocks(130, 64) == [(0, 64), (64, 48), (112, 18)]
+    assert MAX_BLOCK % 16 == 0 and 6 + (9 * MAX_BLOCK + 17) // 8 < (1 << 24)
+    n = (40 << 20) + 3                                       # 2.5 x the 16 MiB a single START can address, tail of 3 bytes
+    flat = torch.cat([make_blocks(20480, 2048, "cuda", seed=5).view(-1), torch.tensor([7, 8, 9], dtype=torch.uint8, device="cuda")])
+    assert flat.numel() == n
+    archive, offsets, lens = compress_chained(engine, flat, block=8 << 20)
+    torch.cuda.synchronize()
+    off = offsets.tolist()
+    assert len(off) == 7 and off[-1] == archive.numel()      # 4 full blocks + 2 end pieces (the 3-byte tail was avoided)
+    host, ha = flat.cpu().numpy().tobytes(), archive.cpu().numpy().tobytes()
+    pos = 0
+    for b in range(6):
+        piece = zlib.decompress(ha[off[b]:off[b + 1]])       # every piece is a complete stock-zlib-readable stream
+        assert piece == host[pos:pos + len(piece)] and 5 <= len(piece) <= (8 << 20) and off[b + 1] - off[b] < (1 << 24)
+        pos += len(piece)
+    assert pos == n
+    back = inflate_chained(engine, archive, offsets, block=8 << 20)
+    assert torch.equal(back, flat)

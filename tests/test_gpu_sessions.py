@@ -1,0 +1,110 @@
+"""GPU (-m gpu): the resumable kernels behind the port's streaming mode (hdlz_compress_chunk / hdlz_inflate_chunk,
+SURVEY.md 8(f) rank 3): a stream fed in arbitrary pieces, with arbitrary caps on the work per call, must give exactly the
+bytes of the one-shot path -- which the other GPU tests pin to the oracle and the golden vectors."""
+import random
+import zlib
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _feed_compress(engine, data, r, cw, mm, piece_max, cap_choices):
+    s = engine.compress_session(cwindow=cw, maxmatch=mm)
+    i, seen = 0, 0
+    while i < len(data):
+        k = r.randint(1, piece_max)
+        s.write(data[i:i + k])
+        i += k
+        st = s.step(max_positions=r.choice(cap_choices))
+        assert st == 0 and s.out_len >= seen and not s.done
+        seen = s.out_len
+    while not s.done:
+        st = s.step(final=True, max_positions=r.choice(cap_choices))
+        assert st == 0
+    return s.output(0, s.out_len)
+
+
+def test_compress_session_equals_one_shot(engine, oracle):
+    from hdl_deflate_amd.data import family_bytes
+    r = random.Random(77)
+    cases = [(family_bytes(1, 5000), 32, 10), (family_bytes(2, 9000, seed=3), 32, 10), (family_bytes(3, 3000, seed=4), 32, 5),
+             (family_bytes(4, 7001, seed=5), 64, 10), (bytes(6000), 32, 10), (b"abcdefghij" * 700, 256, 10),
+             (family_bytes(2, 70000, seed=9), 32, 10), (b"xyz" * 11, 32, 10), (b"12345", 32, 10)]
+    for data, cw, mm in cases:
+        rc, ref = oracle.compress(data, cw, mm)
+        assert rc == 0
+        for piece_max, caps in ((97, (None,)), (700, (32, 64, 352, None)), (5000, (None, 2048, 4096))):
+            got = _feed_compress(engine, data, r, cw, mm, piece_max, caps)
+            assert got == ref, (len(data), cw, mm, piece_max)
+    # every complete byte reported after a step is final: a prefix of the one-shot result
+    data = family_bytes(1, 20000)
+    rc, ref = oracle.compress(data)
+    s = engine.compress_session()
+    for i in range(0, len(data), 1000):
+        s.write(data[i:i + 1000])
+        assert s.step() == 0
+        assert s.output(0, s.out_len) == ref[:s.out_len]
+    assert s.step(final=True) == 0 and s.done and s.output(0, s.out_len) == ref
+
+
+def test_compress_session_short_input(engine):
+    s = engine.compress_session()
+    s.write(b"abcd")
+    assert s.step() == 0 and s.step(final=True) == 1            # HDLZ_E_SHORT_INPUT: the reference never starts
+
+
+def _feed_inflate(engine, z, r, piece_max, window, flags=0, obsize=0):
+    """feed in pieces; the reader lags: the output limit grows by random amounts (the OBSIZE hold)"""
+    s = engine.inflate_session(flags=flags, obsize=obsize)
+    i, limit, guard = 0, window, 0
+    while not s.done:
+        guard += 1
+        assert guard < 100000
+        if i < len(z):
+            k = r.randint(1, piece_max)
+            s.write(z[i:i + k])
+            i += k
+        st = s.step(final=(i >= len(z)), out_limit=limit)
+        if st != 0:
+            return st, b""
+        assert s.out_pos <= limit
+        if s.need == 2 or r.random() < 0.3:
+            limit += r.randint(1, window)                           # the reader advanced
+    return 0, s.output(0, s.out_pos)
+
+
+def test_inflate_session_equals_one_shot(engine, oracle):
+    from hdl_deflate_amd.data import family_bytes
+    r = random.Random(78)
+    plain = [family_bytes(1, 6000), family_bytes(2, 5000, seed=2), family_bytes(3, 3000, seed=3), family_bytes(4, 9000, seed=4),
+             bytes(40000), b"Hello World! 1 " * 3000, family_bytes(2, 200000, seed=6)]
+    streams = []
+    for d in plain:
+        streams.append(zlib.compress(d, 6))                                        # dynamic trees
+        co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        streams.append(co.compress(d) + co.flush())                                 # fixed
+        streams.append(zlib.compress(d, 0))                                         # stored blocks
+        co = zlib.compressobj(9)
+        streams.append(co.compress(d[:len(d) // 3]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(d[len(d) // 3:]) + co.flush())
+    rc, own = oracle.compress(plain[0])
+    streams.append(own)
+    for z in streams:
+        rc, ref = oracle.inflate(z)
+        assert rc == 0 and ref == zlib.decompress(z)
+        for piece_max, window in ((50, 512), (700, 600), (100000, 32768)):
+            st, got = _feed_inflate(engine, z, r, piece_max, window)
+            assert st == 0 and got == ref, (len(z), piece_max, window)
+    # damaged / truncated streams: same status as the one-shot oracle, however the stream is cut into pieces
+    z = zlib.compress(plain[1], 6)
+    for bad in (z[:-3], z[:len(z) // 2], z[:2] + bytes([z[2] | 6]) + z[3:], z[:40] + bytes(20) + z[60:]):
+        rc, _ = oracle.inflate(bad)
+        st, got = _feed_inflate(engine, bad, r, 300, 4096)
+        assert st == rc, (rc, st)
+    # ONEBLOCK / ASSUME_FIXED builds go through the same session
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+    z = co.compress(plain[0][:2000]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(plain[0][2000:]) + co.flush()
+    st, got = _feed_inflate(engine, z, r, 200, 512, flags=8)
+    assert st == 0 and got == plain[0][:2000]
+    st, got = _feed_inflate(engine, z[:-1], r, 200, 512, flags=1 | 8)
+    assert st == 0 and got == plain[0][:2000]

@@ -223,3 +223,39 @@ def test_batch_driver_threads(oracle):
     assert (l1 == l4).all() and (out1 == out4).all() and (s1 == 0).all()
     for b, blk in enumerate(blocks):
         assert zlib.decompress(out1[b, :l1[b]].tobytes()) == blk
+
+
+def _variant_flags(oracle, build):
+    """variants_vectors.json build label -> inflate flags: DYNAMIC=False and LOWLUT builds ignore BTYPE, ONEBLOCK / LOWLUT
+    builds stop at the end of the first block (deflate.py:40-49)"""
+    f = 0
+    if "DYNAMIC=False" in build or "LOWLUT=True" in build:
+        f |= oracle.INFLATE_ASSUME_FIXED
+    if "ONEBLOCK=True" in build or "LOWLUT=True" in build:
+        f |= oracle.INFLATE_ONEBLOCK
+    return f
+
+
+def test_oneblock_and_lowlut_builds(oracle):
+    """ONEBLOCK=True / LOWLUT=True reference builds (oracle/gen_golden_r2.py): the stream ends with its first block"""
+    g = load_golden("variants_vectors.json")
+    assert len(g["oneblock"]) >= 12
+    for v in g["oneblock"]:
+        rc, out = oracle.inflate(bytes.fromhex(v["z_hex"]), flags=_variant_flags(oracle, v["build"]), obsize=512)
+        assert v["error"] is None and rc == 0 and out.hex() == v["out_hex"], (v["build"], v["name"])
+    # without the flag the same streams decode all their blocks
+    v = [x for x in g["oneblock"] if x["name"] == "fixed_two_blocks"][0]
+    rc, out = oracle.inflate(bytes.fromhex(v["z_hex"]), obsize=512)
+    assert rc == 0 and len(out) == 700 and out[:300].hex() == v["out_hex"]
+    for v in g["lmax16"]:                      # the decoder itself has no 16-bit limit: that is the port's (test_port_protocol.py)
+        rc, out = oracle.inflate(bytes.fromhex(v["z_hex"]), flags=_variant_flags(oracle, v["build"]), obsize=512, out_cap=1 << 17)
+        assert rc == 0 and len(out) == v["n"]
+
+
+def test_empty_distance_code_is_legal(oracle):
+    """a dynamic block whose HDIST lengths are all zero holds literals only (RFC1951 3.2.7; zlib and puff accept it)"""
+    from conftest import empty_distance_stream
+    z = empty_distance_stream()
+    assert zlib.decompress(z) == b"aaaaa"                     # stock zlib accepts it
+    rc, out = oracle.inflate(z)
+    assert rc == 0 and out == b"aaaaa"
