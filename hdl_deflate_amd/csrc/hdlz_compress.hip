@@ -85,7 +85,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
         uint32_t base_bits = 19;    // R1: 78 9C + bits 1,1,0
         uint32_t carry_word = 0x78u | (0x9Cu << 8) | (0x3u << 16);
         uint32_t skip_in = 0;       // positions at the tile start covered by the previous tile's last match
-        uint32_t ad_a = 0, ad_w = 0;   // per-lane Adler partials (sum x, sum (N-p) x mod 65521)
+        // per-lane Adler partials: ad_a = sum x (plain: reduced once per GiB and at the end), ad_w = sum (N-p) x mod 65521 with
+        // ONE modulo per tile -- the weight N - p_run is carried mod 65521 from tile to tile instead of being reduced every time
+        uint32_t ad_a = 0, ad_w = 0;
+        uint32_t wm = (n - min(lane * (uint32_t)RUN, n)) % ADLER_MOD;
 
         for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
             // -------------------------------------------------------------- 1. stage the tile
@@ -121,13 +124,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
                 {                                                                                  // 6. Adler partials
                     uint32_t sa, sc;
                     adler_run(ow, sa, sc);
-                    // sum (N - p) x_p over the run = (N - p_run) * sa - sc ; bytes at p >= N are zero
-                    const uint32_t wgt = nrem % ADLER_MOD;
-                    ad_a = (ad_a + sa) % ADLER_MOD;
-                    ad_w = (ad_w + (wgt * sa) % ADLER_MOD + ADLER_MOD * 8u - (sc % ADLER_MOD)) % ADLER_MOD;
+                    // sum (N - p) x_p over the run = (N - p_run) * sa - sc ; bytes at p >= N are zero (then the weight does not matter);
+                    // wm * sa <= 65520 * 8160, sc <= 252960 < 4 * 65521: the sum stays below 2^31
+                    ad_a += sa;
+                    ad_w = (ad_w + __umul24(wm, sa) + (4u * ADLER_MOD - sc)) % ADLER_MOD;
+                    wm = wm >= (uint32_t)(TILE % ADLER_MOD) ? wm - (uint32_t)(TILE % ADLER_MOD) : wm + (ADLER_MOD - (uint32_t)(TILE % ADLER_MOD));
+                    if (((t0 >> 11) & 0x3FFFFu) == 0x3FFFFu) ad_a %= ADLER_MOD;      // (every 2^18 tiles: ad_a grows by <= 8160 per tile)
+                    asm volatile("" : "+v"(ad_a), "+v"(ad_w), "+v"(wm));              // computed HERE, while the bytes are in registers
                 }
                 HDLZ_MARK("extend");
-                make_tokens<NCH, FULLWIN>(lds.in, HALO + lane * RUN, ow, best, cw4, kmax, 4u * min(p_run, 32u * NCH), nrem, tok);   // 3. R5
+                make_tokens<NCH, FULLWIN, true>(lds.in, HALO + lane * RUN, ow, best, cw4, kmax, 4u * min(p_run, 32u * NCH), nrem, tok, (int32_t)(n - t0));   // 3. R5
             }
             pin(tok);
             PHASE_FENCE();
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
                         lds.out[w] = (w == ew) ? (lds.out[w] & ((1u << rb) - 1u)) : 0u;
                 }
                 // R8: EOB = 7 zero bits, zero pad to a byte, Adler-32 big-endian (s2 then s1)
-                uint32_t s1 = ad_a, s2 = ad_w;
+                uint32_t s1 = ad_a % ADLER_MOD, s2 = ad_w;
 #pragma unroll
                 for (int ofs = 32; ofs > 0; ofs >>= 1) {
                     s1 += __shfl_xor(s1, ofs, 64);

@@ -205,13 +205,22 @@ __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw
 //   FULLWIN  cwindow == 32 * NCH: every distance the search can return is inside the window (no cw4 compare)
 // Measured and dropped (profiles/r02_tokens_ab.txt): the candidate's 8 bytes from ONE unaligned ds_read_b64 -- 8 VALU
 // instructions fewer per position, but gfx950's LDS splits unaligned 64-bit reads: LDS busy 57 -> 82 %, 1 % slower.
-template <int NCH, bool FULLWIN>
+//   SCALAR_TAIL: the lane runs are consecutive pieces of ONE block and tile_rem = positions of the block from the tile's first
+//            position on: R3's "p <= N-5" then holds for a PREFIX of the lanes, so it is evaluated on the scalar unit --
+//            at most two different lane masks per tile -- and and-ed into the compare's lane mask (else: per lane, from nrem)
+template <int NCH, bool FULLWIN, bool SCALAR_TAIL = false>
 __device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run, uint32_t (&ow)[12], uint32_t (&best)[RUN],
-                                            uint32_t cw4, uint32_t kmax, uint32_t p4_run, uint32_t nrem, uint32_t (&tok)[RUN]) {
+                                            uint32_t cw4, uint32_t kmax, uint32_t p4_run, uint32_t nrem, uint32_t (&tok)[RUN],
+                                            int32_t tile_rem = 0) {
     pin(best); pin(ow);
     PHASE_FENCE();
     const uint32_t nrem_m5 = nrem - 5u;                       // (wraps when nrem < 5: then nothing is eligible)
     const uint32_t kmax_m3 = kmax - 3u;
+    // lanes l with tile_rem - 32 l >= i + 5  <=>  l < cnt_i,  cnt_i = ((tile_rem - 5 - i) >> 5) + 1: two values over i = 0..31
+    const int32_t rem5 = tile_rem - 5;
+    const uint32_t thr = rem5 >= 0 ? ((uint32_t)rem5 & 31u) : 0u;                        // i <= thr: the larger count
+    const int32_t cnt_hi = rem5 >= 0 ? (rem5 >> 5) + 1 : 0, cnt_lo = rem5 >= 0 ? (rem5 >> 5) : 0;
+    const uint64_t m_hi = cnt_hi >= 64 ? ~0ull : ((1ull << cnt_hi) - 1ull), m_lo = cnt_lo >= 64 ? ~0ull : ((1ull << cnt_lo) - 1ull);
     // token word of a match of length len = l3 + 3 at distance d:  (len-1) << 16 | LUT offset
     //   CWINDOW <= 32: LUT [len-3][d-1] -> l3 * (65536 + 128) + 4d + K;   wider: LUT [d-1] -> l3 * 65536 + 4d + K
     const uint32_t tok_k = (2u << 16) + LUT_MATCH_BYTE - 4u;
@@ -220,10 +229,12 @@ __device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run
         constexpr int i = decltype(I)::value;
         const uint32_t d4 = best[i];
         // R3: 1 <= p <= N-5;  R4: d <= min(CWINDOW, p)   ('&': no short-circuit branches)
-        bool ok = (d4 <= p4_run + (uint32_t)(4 * i)) & (nrem >= (uint32_t)(i + 5));
-        if constexpr (!FULLWIN) ok = ok & (d4 <= cw4);
+        uint64_t okm = __builtin_amdgcn_ballot_w64(d4 <= p4_run + (uint32_t)(4 * i));      // (the compare's own lane mask)
+        if constexpr (!FULLWIN) okm &= __builtin_amdgcn_ballot_w64(d4 <= cw4);
+        if constexpr (SCALAR_TAIL) okm &= ((uint32_t)i <= thr ? m_hi : m_lo);
+        else okm &= __builtin_amdgcn_ballot_w64(nrem >= (uint32_t)(i + 5));
         // distance for the gather; for "no match" any in-range value will do (the result is discarded)
-        const uint32_t d = (NCH == 1) ? ((d4 & 0xFCu) >> 2) : (ok ? (d4 >> 2) : 1u);
+        const uint32_t d = (NCH == 1) ? ((d4 & 0xFCu) >> 2) : (d4 <= cw4 ? (d4 >> 2) : 1u);
         // R5: common prefix of x[p+3..p+10] and x[p-d+3..p-d+10]
         const uint32_t q = lds_run + (uint32_t)(i + 3) - d;   // byte offset of the candidate's 4th byte
         const uint32_t qd = q >> 2;
@@ -236,7 +247,9 @@ __device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run
         // equal low BITS of the two 8-byte windows.  Only 7 bytes can matter (len <= 10): a sentinel in the top bit of
         // the eighth bounds the count at 63 (-> 7 bytes) and keeps ffbl away from its "no bit set" value
         const uint32_t zhi = ffbl((chi ^ ohi) | 0x80000000u) | 32u;
-        const uint32_t zb = min(ffbl(clo ^ olo), zhi);           // ffbl(0) = 0xFFFFFFFF: "no difference in the low half"
+        uint32_t zlo;                                            // v_ffbl_b32(0) = 0xFFFFFFFF: "no difference in the low half"
+        asm("v_ffbl_b32 %0, %1" : "=v"(zlo) : "v"(clo ^ olo));   // (asm: hipcc turns ffs()-1 + min into a compare and a select)
+        const uint32_t zb = min(zlo, zhi);
         // len - 3 = min(equal bytes, Kmax - 3, N-2-p - 3): a match never covers the last two bytes
         const uint32_t l3 = umin3(zb >> 3, kmax_m3, nrem_m5 - (uint32_t)i);
         // literal byte -> LUT offset 4*byte
@@ -246,8 +259,8 @@ __device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run
         else lit = (ow[i >> 2] >> (bsh - 2)) & 0x3FCu;
         uint32_t mt;     // l3 * tok_mul + d4 + tok_k  (hipcc folds the C form into a quarter-rate v_mul_lo_u32)
         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(mt) : "v"(l3), "s"(tok_mul), "v"(d4 + tok_k));
-        tok[i] = ok ? mt : lit;
-        if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(tok); pin(ow); PHASE_FENCE(); }
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(tok[i]) : "v"(lit), "v"(mt), "s"(okm));      // tok = ok ? mt : lit
+        if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(tok); PHASE_FENCE(); }
     });
 }
 
