@@ -37,8 +37,10 @@
 namespace hdlz {
 
 // NCH = ceil(cwindow / 32): 1, 2 or 8 chunks of 32 candidate distances; FULLWIN: cwindow == 32 * NCH (the reference's
-// own windows 32 and 256, and 64), which spares the per-position window compare
-template <int NCH, bool FULLWIN>
+// own windows 32 and 256, and 64), which spares the per-position window compare; ONE_TILE: every block of the batch fits one
+// wave-tile (N <= 2048: BASELINE configs[1]'s block size and the reference's own IBSIZE scale) -- no tile loop, no halo
+// carried from a previous tile, no carried bit / Adler state
+template <int NCH, bool FULLWIN, bool ONE_TILE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? HDLZ_W1 : 4, NCH == 1 ? HDLZ_W1 : 4))) void k_compress(CompressArgs a) {
     __shared__ WaveLds lds;
     const uint32_t lane = threadIdx.x;
@@ -74,6 +76,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
             if (lane == 0) { a.out_len[blk] = 0; a.status[blk] = HDLZ_E_SHORT_INPUT; }
             continue;
         }
+        if (ONE_TILE && n > (uint32_t)TILE) {       // (the caller's bound on the block lengths was wrong)
+            if (lane == 0) { a.out_len[blk] = 0; a.status[blk] = HDLZ_E_BAD_PARAM; }
+            continue;
+        }
         if ((uint64_t)out_bound(n) > a.out_pitch) {
             if (lane == 0) { a.out_len[blk] = 0; a.status[blk] = HDLZ_E_OUT_CAPACITY; }
             continue;
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
         uint32_t ad_a = 0, ad_w = 0;
         uint32_t wm = (n - min(lane * (uint32_t)RUN, n)) % ADLER_MOD;
 
-        for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
+        for (uint32_t t0 = 0; t0 < n; t0 += TILE) {       // (ONE_TILE: one iteration; left as a loop -- hipcc spills when it is peeled)
             // -------------------------------------------------------------- 1. stage the tile
             HDLZ_MARK("stage");
             uint32_t keep = 0;
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
             __syncthreads();
 
             // -------------------------------------------------------------- 7. flush
-            const bool last = (t0 + TILE >= n);
+            const bool last = ONE_TILE || (t0 + TILE >= n);
             if (!last) {
                 const uint32_t end_bits = base_bits + tile_bits_all;
                 const uint32_t full = end_bits >> 5;
@@ -207,12 +213,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
     }
 }
 
-template __global__ void k_compress<1, true>(CompressArgs);
-template __global__ void k_compress<1, false>(CompressArgs);
-template __global__ void k_compress<2, true>(CompressArgs);
-template __global__ void k_compress<2, false>(CompressArgs);
-template __global__ void k_compress<8, true>(CompressArgs);
-template __global__ void k_compress<8, false>(CompressArgs);
+template __global__ void k_compress<1, true, true>(CompressArgs);
+template __global__ void k_compress<1, false, true>(CompressArgs);
+template __global__ void k_compress<1, true, false>(CompressArgs);
+template __global__ void k_compress<1, false, false>(CompressArgs);
+template __global__ void k_compress<2, true, false>(CompressArgs);
+template __global__ void k_compress<2, false, false>(CompressArgs);
+template __global__ void k_compress<8, true, false>(CompressArgs);
+template __global__ void k_compress<8, false, false>(CompressArgs);
 
 hipError_t launch_compress(const CompressArgs& a, hipStream_t stream) {
     if (a.nblocks == 0) return hipSuccess;
@@ -236,12 +244,16 @@ hipError_t launch_compress(const CompressArgs& a, hipStream_t stream) {
     uint64_t g = (uint64_t)ncu * 64u;
     if (g > a.nblocks) g = a.nblocks;
     const dim3 grid((unsigned)g), block(64);
-    if (a.cwindow == 32) hipLaunchKernelGGL((k_compress<1, true>), grid, block, 0, stream, a);
-    else if (a.cwindow < 32) hipLaunchKernelGGL((k_compress<1, false>), grid, block, 0, stream, a);
-    else if (a.cwindow == 64) hipLaunchKernelGGL((k_compress<2, true>), grid, block, 0, stream, a);
-    else if (a.cwindow < 64) hipLaunchKernelGGL((k_compress<2, false>), grid, block, 0, stream, a);
-    else if (a.cwindow == 256) hipLaunchKernelGGL((k_compress<8, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_compress<8, false>), grid, block, 0, stream, a);
+    // every block within one wave-tile (fixed size, or a ragged batch whose caller states such a bound in in_len)
+    const bool one_tile = a.in_len >= 5u && a.in_len <= (uint32_t)TILE;
+    if (a.cwindow == 32 && one_tile) hipLaunchKernelGGL((k_compress<1, true, true>), grid, block, 0, stream, a);
+    else if (a.cwindow < 32 && one_tile) hipLaunchKernelGGL((k_compress<1, false, true>), grid, block, 0, stream, a);
+    else if (a.cwindow == 32) hipLaunchKernelGGL((k_compress<1, true, false>), grid, block, 0, stream, a);
+    else if (a.cwindow < 32) hipLaunchKernelGGL((k_compress<1, false, false>), grid, block, 0, stream, a);
+    else if (a.cwindow == 64) hipLaunchKernelGGL((k_compress<2, true, false>), grid, block, 0, stream, a);
+    else if (a.cwindow < 64) hipLaunchKernelGGL((k_compress<2, false, false>), grid, block, 0, stream, a);
+    else if (a.cwindow == 256) hipLaunchKernelGGL((k_compress<8, true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_compress<8, false, false>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
 

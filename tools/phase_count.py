@@ -12,7 +12,7 @@ import sys
 FAST = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_mov_b32", "v_min_u16",
         "v_add_co_u32", "v_not_b32")
 defs = [a for a in sys.argv[1:] if a.startswith("-D")]
-kern = "k_compressILi1ELb1E"
+kern = "k_compressILi1ELb1ELb1E"
 for i, a in enumerate(sys.argv):
     if a == "--kernel":
         kern = sys.argv[i + 1]
