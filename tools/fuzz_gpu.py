@@ -124,6 +124,43 @@ def main():
                 if not ((hs2 == rs2).all() and (hl2 == rl2).all() and ((hb2 == ro2) | ~mask2).all()):
                     print("STREAMS MISMATCH it=%d seed=%d nbk=%d n=%d cw=%d mm=%d kind=%d" % (it, a.seed, nbk, nbytes_, cw, mm, kind))
                     return 1
+        # now and then: a slice of the data through the RESUMABLE kernels (hdlz_compress_chunk / hdlz_inflate_chunk), fed in
+        # random pieces with random caps on the work per call -- must equal the one-shot oracle
+        if it % 3 == 1 and total >= 5:
+            sl_n = int(min(total, rng.integers(5, 60000)))
+            piece = flat[mis:mis + sl_n].tobytes()
+            rc, ref = O.compress(piece, cw, mm)
+            cs = eng.compress_session(cwindow=cw, maxmatch=mm)
+            i = 0
+            while i < sl_n:
+                k = int(rng.integers(1, 4000))
+                cs.write(piece[i:i + k])
+                i += k
+                cs.step(max_positions=int(rng.choice([32, 96, 1024, 1 << 20])))
+            guard = 0
+            while not cs.done and guard < 100000:
+                guard += 1
+                if cs.step(final=True, max_positions=int(rng.choice([64, 2048, 1 << 20]))) != 0:
+                    break
+            if not cs.done or cs.output(0, cs.out_len) != ref:
+                print("CHUNK-COMPRESS MISMATCH it=%d seed=%d n=%d cw=%d mm=%d" % (it, a.seed, sl_n, cw, mm))
+                return 1
+            z = zlib.compress(piece, int(rng.integers(0, 10))) if rng.random() < 0.7 else ref
+            isn = eng.inflate_session()
+            i, limit, guard = 0, 600, 0
+            while not isn.done and guard < 200000:
+                guard += 1
+                if i < len(z):
+                    k = int(rng.integers(1, 3000))
+                    isn.write(z[i:i + k])
+                    i += k
+                if isn.step(final=(i >= len(z)), out_limit=limit) != 0:
+                    break
+                if isn.need == 2 or rng.random() < 0.3:
+                    limit += int(rng.integers(1, 5000))
+            if not isn.done or isn.output(0, isn.out_pos) != piece:
+                print("CHUNK-INFLATE MISMATCH it=%d seed=%d n=%d zlen=%d" % (it, a.seed, sl_n, len(z)))
+                return 1
         blocks += B
         nbytes += total
     print("fuzz OK: %d batches, %d blocks, %.1f MiB, seed %d" % (it, blocks, nbytes / 2 ** 20, a.seed))
