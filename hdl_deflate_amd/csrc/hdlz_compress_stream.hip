@@ -98,21 +98,21 @@ __global__ __launch_bounds__(64) void k_stream_xfer(StreamArgs a) {
         pin(tok);
         PHASE_FENCE();
         const uint64_t P = run_transfer(tok);                                                      // 4. greedy parse of the run
-            // transfer function of the whole tile: lanes 0..9 each push one entry skip through the 64 runs
-            {
-                const uint32_t plo = (uint32_t)P, phi = (uint32_t)(P >> 32);
-                uint32_t s = lane < 10u ? lane : 0u;
+        // transfer function of the whole tile: lanes 0..9 each push one entry skip through the 64 runs
+        {
+            const uint32_t plo = (uint32_t)P, phi = (uint32_t)(P >> 32);
+            uint32_t s = lane < 10u ? lane : 0u;
 #pragma unroll 4
-                for (int l = 0; l < 64; l++) {
-                    const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, l) << 32) |
-                                       (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)plo, l);
-                    s = (uint32_t)(f >> (4u * s)) & 15u;
-                }
-                uint64_t T = 0;
-#pragma unroll
-                for (int k = 0; k < 10; k++) T |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)s, k) << (4 * k);
-                if (lane == 0) a.xfer[t] = T;
+            for (int l = 0; l < 64; l++) {
+                const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, l) << 32) |
+                                   (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)plo, l);
+                s = (uint32_t)(f >> (4u * s)) & 15u;
             }
+            uint64_t T = 0;
+#pragma unroll
+            for (int k = 0; k < 10; k++) T |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)s, k) << (4 * k);
+            if (lane == 0) a.xfer[t] = T;
+        }
     }
 }
 
@@ -351,37 +351,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
         pin(tok); asm volatile("" : "+v"(myskip));
         PHASE_FENCE();
         uint32_t lane_bits = token_codes<NCH, false>(lut8, tok, myskip, 0u, code);                 // 5. R6/R7
-            pin(code);
-            PHASE_FENCE();
-            uint32_t incl = wave_scan_incl(lane_bits, lane);
-            const uint32_t tile_bits_all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            // positions >= N of the last tile were parsed as one 8-bit literal each (see hdlz_compress.hip); their
-            // bits sit behind the real end and are cut off by k_stream_place, which only takes bits[t] bits
-            const bool last = (t0 + (uint32_t)TILE >= n);
-            const uint32_t ninv = last ? t0 + (uint32_t)TILE - n : 0u;
-            const uint32_t tile_bits = tile_bits_all - 8u * ninv;
-            {
-                // bits and Adler partials of the tile
-                uint32_t wsum = ((nrem % ADLER_MOD) * sa) % ADLER_MOD + ADLER_MOD * 8u - (sc % ADLER_MOD);   // < 10 * 65521
+        pin(code);
+        PHASE_FENCE();
+        uint32_t incl = wave_scan_incl(lane_bits, lane);
+        const uint32_t tile_bits_all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        // positions >= N of the last tile were parsed as one 8-bit literal each (see hdlz_compress.hip); their
+        // bits sit behind the real end and are cut off by k_stream_place, which only takes bits[t] bits
+        const bool last = (t0 + (uint32_t)TILE >= n);
+        const uint32_t ninv = last ? t0 + (uint32_t)TILE - n : 0u;
+        const uint32_t tile_bits = tile_bits_all - 8u * ninv;
+        {
+            // bits and Adler partials of the tile
+            uint32_t wsum = ((nrem % ADLER_MOD) * sa) % ADLER_MOD + ADLER_MOD * 8u - (sc % ADLER_MOD);   // < 10 * 65521
 #pragma unroll
-                for (int ofs = 32; ofs > 0; ofs >>= 1) {
-                    sa += __shfl_xor(sa, ofs, 64);
-                    wsum += __shfl_xor(wsum, ofs, 64);
-                }
-                // (per-tile partials: 256 same-address atomics per chunk sum serialised in L2 and doubled this pass)
-                if (lane == 0) { a.bits[t] = tile_bits; a.ad[t] = make_uint2(sa, wsum % ADLER_MOD); }
+            for (int ofs = 32; ofs > 0; ofs >>= 1) {
+                sa += __shfl_xor(sa, ofs, 64);
+                wsum += __shfl_xor(wsum, ofs, 64);
             }
-            pin(code); asm volatile("" : "+v"(incl), "+v"(lane_bits));
-            PHASE_FENCE();
-            scatter_codes(out8, code, base_bits + incl - lane_bits);                               // bit writer
+            // (per-tile partials: 256 same-address atomics per chunk sum serialised in L2 and doubled this pass)
+            if (lane == 0) { a.bits[t] = tile_bits; a.ad[t] = make_uint2(sa, wsum % ADLER_MOD); }
+        }
+        pin(code); asm volatile("" : "+v"(incl), "+v"(lane_bits));
+        PHASE_FENCE();
+        scatter_codes(out8, code, base_bits + incl - lane_bits);                               // bit writer
 
-            __syncthreads();
-            // the tile's bit string goes to its slot of the scratch buffer; k_stream_place shifts it to its final position
-            {
-                uint32_t* __restrict__ slot = a.tmp + (size_t)t * OUT_WORDS;
-                const uint32_t nw = (tile_bits_all + 31u) >> 5;
-                for (uint32_t w = lane; w < nw; w += 64) slot[w] = lds.out[w];
-            }
+        __syncthreads();
+        // the tile's bit string goes to its slot of the scratch buffer; k_stream_place shifts it to its final position
+        {
+            uint32_t* __restrict__ slot = a.tmp + (size_t)t * OUT_WORDS;
+            const uint32_t nw = (tile_bits_all + 31u) >> 5;
+            for (uint32_t w = lane; w < nw; w += 64) slot[w] = lds.out[w];
+        }
     }
 }
 

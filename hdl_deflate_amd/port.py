@@ -38,8 +38,8 @@ Protocol facts honoured in both modes:
   * o_done rises only when all output is readable; final o_oprogress = output length (deflate.py:814);
   * where the reference raises myhdl.Error (or hangs: N < 5), cycle() raises hdl_deflate_amd.Error.
 """
-from .constants import (IDLE, WRITE, READ, STARTC, STARTD, OK, CWINDOW, MAXMATCH, LMAX, STATUS_NAMES)
-from .errors import Error, HdlzStatusError, HdlzRangeError
+from .constants import IDLE, WRITE, STARTC, STARTD, OK, CWINDOW, MAXMATCH, LMAX
+from .errors import HdlzStatusError, HdlzRangeError
 
 
 class Sig(object):
