@@ -92,7 +92,8 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
                        uint32_t* d_out_len, uint32_t* d_status, void* stream) {
     if (nstreams > 0x7FFFFFFFull * 32) return fail_param("nstreams too large for one launch");
     if (nstreams && (!d_in || !d_out || !d_out_len || !d_status)) return fail_param("null device pointer");
-    if (flags & ~(HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_ONEBLOCK))
+    if (flags & ~(HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_ONEBLOCK |
+                  HDLZ_INFLATE_TOKEN_ROUNDS | HDLZ_INFLATE_BYTE_LOCKSTEP))
         return fail_param("unknown flag");
     // the kernels keep stream lengths and bit positions in 32 bits (8 * length must not wrap)
     if (!d_in_off && in_len >= 0x10000000u) return fail_param("in_len too large (streams are limited to 256 MiB - 1)");
@@ -114,7 +115,7 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
         if (e != hipSuccess) return fail_hip(e, "launch k_inflate_dyn");
         return HDLZ_OK;
     }
-    hipError_t e = hdlz::launch_inflate(a, st);
+    hipError_t e = (flags & HDLZ_INFLATE_TOKEN_ROUNDS) ? hdlz::launch_inflate_tok(a, st) : hdlz::launch_inflate(a, st);
     if (e != hipSuccess) return fail_hip(e, "launch k_inflate");
     // second pass, same stream: streams in which pass 1 met a dynamic-tree block (status 6) are redone
     // by one wave each; everything else is left untouched

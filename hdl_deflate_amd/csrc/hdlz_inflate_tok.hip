@@ -1,0 +1,435 @@
+// hdlz_inflate_tok.hip -- STARTD for a batch of independent zlib streams, one LANE per stream, one TOKEN per round.
+//
+// Same contract and same reference lines as hdlz_inflate.hip (/root/reference/deflate.py:635-732 IDLE/HEADER, :1402-1445 NEXT,
+// :1519-1591 INFLATE, :1593-1659 COPY, :517-533 get4/adv); rule names D0..D8 are SURVEY.md 8(a)'s.  k_inflate (round 1) runs its 64
+// streams in lockstep ONE OUTPUT BYTE per iteration, which keeps the output offset wave-uniform -- but every iteration pays the
+// whole token decode (~50 VALU + ~40 SALU instructions) although only the lanes standing at a token boundary need it: with
+// ~6 bytes per token the decode is paid six times.  Here a ROUND decodes one token in every lane, then a short loop moves the
+// bytes: up to four per lane and iteration (the literal, or the next four bytes of the copy), so the decode is paid once per token
+// and a byte of a copy costs ~8 VALU instructions.  What changes with it:
+//   * every lane has its own output position.  The ring stays lane-interleaved (dword w of lane l at dword index w*64 + l: each
+//     lane owns a bank, whatever the positions are) and is 128 bytes per lane; four bytes are written at once, unmasked -- the
+//     bytes behind the new end are not-yet-produced positions whose old content (history > 120 back) is never read again;
+//   * a lane's 64-byte line is flushed when complete, by the lane itself (16 conflict-free ds_read_b32 + 4 x 16-byte stores: a full
+//     64-byte sector per lane); flushes are batched: they run when a quarter of the wave is ready or one lane is about to overrun;
+//   * near history (distance <= 120) is read from the ring, far history from the stream's own flushed output, four bytes at a time;
+//   * input arrives through 16-byte LDS-DMA slots per lane (hdlz_inflate.hip explains the ordering rule).
+// Status codes and the ORDER of the reference's checks are those of k_inflate / the oracle: the slow path is the same code.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hdlz_device.h"
+
+namespace hdlz {
+namespace tok {
+
+#ifndef HDLZ_TOK_RING
+#define HDLZ_TOK_RING 128
+#endif
+constexpr uint32_t RINGB = HDLZ_TOK_RING;     // ring bytes per stream (128 or 64)
+constexpr uint32_t RING_DW = RINGB / 4;
+constexpr uint32_t NEAR = RINGB - 12;         // distances up to this are served from the ring: NEAR + 3 (dword alignment of the
+                                              // source) + 8 (the unmasked write ahead of the end) < RINGB
+constexpr uint32_t CHUNK = RINGB >= 128u ? 64u : RINGB / 2u;   // bytes per flush
+constexpr uint32_t URGENT = RINGB - 36;       // a lane with this many unflushed bytes forces a flush (+3 per move, +8 written ahead,
+                                              // and the far prefetch reads 16 bytes from o - dist on: they must be flushed)
+constexpr uint32_t WAVES = 4;
+constexpr uint32_t SLOT_DW = 4;               // input dwords fetched per lane and refill
+#ifndef HDLZ_TOK_MOVES
+#define HDLZ_TOK_MOVES 2
+#endif
+constexpr uint32_t MOVES = HDLZ_TOK_MOVES;    // move iterations (4 bytes per lane each) per round
+
+struct __attribute__((aligned(16))) Lds {
+    uint32_t ring[WAVES][RING_DW * 64];   // per wave: [dword][lane]
+    uint32_t inq[WAVES][64 * SLOT_DW];    // per lane: SLOT_DW stream dwords from byte `sbase` on (LDS-DMA)
+    uint32_t lit[512];
+    uint32_t dst[32];
+};
+
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+
+__device__ __forceinline__ uint32_t rev(uint32_t v, uint32_t nbits) { return __builtin_bitreverse32(v) >> (32u - nbits); }
+
+__device__ __forceinline__ uint32_t load32(const uint8_t* __restrict__ z, uint32_t ip, uint32_t zn) {
+    if (ip + 4u <= zn) return *reinterpret_cast<const u32_unaligned*>(z + ip);
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 4u; k++)
+        if (ip + k < zn) v |= (uint32_t)z[ip + k] << (8u * k);
+    return v;
+}
+
+__device__ __forceinline__ void lds_dma_load16(const uint8_t* gptr, uint32_t lds_base) {
+    uint32_t save;      // LDS address = M0 + lane * 16 (see tools/ubench/lds_dma.hip); M0 is saved and restored
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(save) : "v"(gptr), "s"(lds_base) : "memory");
+}
+
+// RFC1951 tables in closed form (deflate.py:100-110)
+__device__ __forceinline__ void length_info(uint32_t token, uint32_t& base, uint32_t& eb) {
+    if (token < 8u) { base = 3u + token; eb = 0; }
+    else if (token == 28u) { base = 258u; eb = 0; }
+    else { eb = (token >> 2) - 1u; base = 3u + ((4u + (token & 3u)) << eb); }
+}
+__device__ __forceinline__ void dist_info(uint32_t dc, uint32_t& base, uint32_t& eb) {
+    if (dc < 4u) { base = 1u + dc; eb = 0; }
+    else { eb = (dc >> 1) - 1u; base = 1u + ((2u + (dc & 1u)) << eb); }
+}
+// the widened stat_leaves (deflate.py:151-216): nbits[3:0] | sym[12:4] | type[14:13] | lbase[24:16] | leb[27:25]
+enum { T_LIT = 0, T_LEN = 1, T_EOB = 2, T_BAD = 3 };
+__device__ __forceinline__ uint32_t lit_entry(uint32_t c) {
+    uint32_t sym, nb;
+    const uint32_t r7 = rev(c & 127u, 7), r8 = rev(c & 255u, 8), r9 = rev(c, 9);
+    if (r7 < 24u) { sym = 256u + r7; nb = 7; }
+    else if (r8 >= 0x30u && r8 < 0xC0u) { sym = r8 - 0x30u; nb = 8; }
+    else if (r8 >= 0xC0u && r8 < 0xC8u) { sym = 280u + (r8 - 0xC0u); nb = 8; }
+    else { sym = r9 - 256u; nb = 9; }
+    uint32_t type = sym < 256u ? T_LIT : sym == 256u ? T_EOB : sym <= 285u ? T_LEN : T_BAD;
+    uint32_t lbase = 0, leb = 0;
+    if (type == T_LEN) length_info(sym - 257u, lbase, leb);
+    if (sym == 287u) nb = 0;                                 // the reference's zero leaf at index 483 (deflate.py:212)
+    return nb | (sym << 4) | (type << 13) | (lbase << 16) | (leb << 25);
+}
+__device__ __forceinline__ uint32_t dst_entry(uint32_t raw5) {
+    const uint32_t dc = rev(raw5, 5);
+    if (dc >= 30u) return 0xFFFFFFFFu;
+    uint32_t dbase, deb;
+    dist_info(dc, dbase, deb);
+    return dbase | (deb << 16);
+}
+
+// byte address of stream position `pos` of lane `lane` inside a wave's ring
+__device__ __forceinline__ uint32_t ring_addr(uint32_t pos, uint32_t lane4) { return ((pos & (RINGB - 4u)) << 6) | lane4 | (pos & 3u); }
+
+__global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
+    __shared__ Lds lds;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t c = threadIdx.x; c < 512u; c += 64u * WAVES) lds.lit[c] = lit_entry(c);
+    if (threadIdx.x < 32u) lds.dst[threadIdx.x] = dst_entry(threadIdx.x);
+    __syncthreads();                 // the only workgroup barrier: the waves are independent from here on
+
+    const uint64_t sid = ((uint64_t)blockIdx.x * WAVES + wave) * 64u + lane;
+    const bool exists = sid < a.nstreams;
+    uint64_t off = 0;
+    uint32_t zn = 0;
+    if (exists) {
+        if (a.in_off) {
+            off = a.in_off[sid];
+            zn = (uint32_t)(a.in_off[sid + 1] - off);
+        } else {
+            off = sid * a.in_pitch;
+            zn = a.in_len;
+        }
+    }
+    const uint8_t* __restrict__ z = a.in + off;
+    uint8_t* out = a.out + sid * a.out_pitch;
+    uint8_t* ring8 = reinterpret_cast<uint8_t*>(lds.ring[wave]);
+    const uint32_t lane4 = lane << 2;
+    const uint32_t cap = a.out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00u : (uint32_t)a.out_pitch;   // o + 258 never wraps
+    const uint32_t obsize = a.obsize ? a.obsize : 32768u;
+    const uint32_t len_mask = a.obsize ? ((1u << (31u - (uint32_t)__builtin_clz(a.obsize))) - 1u) : 0xFFFFu;   // deflate.py:329,:714
+    const bool assume_fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) != 0;
+    const uint32_t oneblock = (a.flags & HDLZ_INFLATE_ONEBLOCK) ? 1u : 0u;
+    const bool out16 = ((reinterpret_cast<uintptr_t>(a.out) | a.out_pitch) & 15u) == 0;
+    const int32_t isize = (int32_t)zn - 1;            // deflate.py:605
+
+    uint32_t status = HDLZ_OK;
+    uint32_t out_len = 0;
+    bool active = exists;
+    if (exists && zn < 5u) { status = HDLZ_E_SHORT_INPUT; active = false; }
+
+    uint64_t bb = 0;            // bit buffer (LSB first)
+    uint32_t bc = 0;            // valid bits in bb
+    uint32_t ip = 2;            // D0: next byte to load; the 2 zlib header bytes are skipped unvalidated
+    uint32_t sbase = 2;         // first stream byte held by this lane's input slot
+    uint32_t o = 0;             // bytes produced by THIS lane
+    uint32_t flushed = 0;       // ... of which in HBM (a multiple of 64)
+    uint32_t pend = 0;          // the valid low bytes of the ring dword that holds position o
+    uint32_t rem = 0, dist = 0; // pending LZ copy
+    uint64_t fb = 0, fpre = 0;  // far copy: 8 source bytes being consumed, and the NEXT 8, requested a round ahead
+    uint32_t fbn = 0;           // bytes left in fb
+    uint32_t litv = 0, litn = 0;// pending literal / stored byte (litn = 0 or 1)
+    uint32_t srem = 0;          // pending stored bytes
+    uint32_t final_ = 0;
+    bool need_header = true;
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    lds_vu32* inq = (lds_vu32*)&lds.inq[wave][0];
+    const uint32_t inq_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(&lds.inq[wave][0]));
+    uint32_t issued = 0;        // wave-uniform: LDS-DMA instructions issued so far
+    uint32_t myissue = 0;       // value of `issued` right after this lane's pending request
+
+#define TOK_REQUEST(asyncv) do {                                                                        \
+        if (sbase + 16u <= zn) lds_dma_load16(z + sbase, inq_base);                                       \
+        else for (uint32_t k_ = 0; k_ < SLOT_DW; k_++) inq[lane * SLOT_DW + k_] = load32(z, sbase + 4u * k_, zn); \
+        myissue = (asyncv);                                                                               \
+    } while (0)
+    // synchronous refill for the slow path
+#define TOK_REFILL() do { if (bc <= 32u) {                                                              \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+        bb |= (uint64_t)inq[lane * SLOT_DW + ((ip - sbase) >> 2)] << bc; bc += 32u; ip += 4u;              \
+        if (ip - sbase >= 16u) {                                                                           \
+            sbase = ip;                                                                                    \
+            for (uint32_t k_ = 0; k_ < SLOT_DW; k_++) inq[lane * SLOT_DW + k_] = load32(z, sbase + 4u * k_, zn); \
+            myissue = issued - 1000u;                                                                      \
+        }                                                                                                  \
+    } } while (0)
+#define TOK_FAIL(code) do { status = (code); out_len = 0; active = false; } while (0)
+#define TOK_BITPOS() (8u * ip - bc)
+    // flush the completed 64-byte lines: batched -- when a quarter of the wave is ready or a lane is about to overrun its ring
+#define TOK_FLUSH() do {                                                                                \
+        const bool ready_ = exists && (o - flushed) >= CHUNK;                                              \
+        const uint64_t rm_ = __ballot(ready_);                                                             \
+        if (rm_ != 0ull && (__popcll(rm_) >= 16 || __ballot(exists && (o - flushed) >= URGENT) != 0ull)) { \
+            if (ready_) {                                                                                  \
+                const uint32_t* rp_ = &lds.ring[wave][((flushed & (RINGB - 1u)) >> 2) * 64u + lane];       \
+                uint8_t* dp_ = out + flushed;                                                              \
+                _Pragma("unroll") for (uint32_t q_ = 0; q_ < CHUNK / 16u; q_++) {                          \
+                    uint4 v_;                                                                              \
+                    v_.x = rp_[(4u * q_) * 64u]; v_.y = rp_[(4u * q_ + 1u) * 64u];                         \
+                    v_.z = rp_[(4u * q_ + 2u) * 64u]; v_.w = rp_[(4u * q_ + 3u) * 64u];                    \
+                    if (out16) *reinterpret_cast<uint4*>(dp_ + 16u * q_) = v_;                             \
+                    else { uint32_t* d32_ = reinterpret_cast<uint32_t*>(dp_ + 16u * q_);                   \
+                           d32_[0] = v_.x; d32_[1] = v_.y; d32_[2] = v_.z; d32_[3] = v_.w; }               \
+                }                                                                                          \
+                flushed += CHUNK;                                                                          \
+            }                                                                                              \
+            /* far copies read these bytes back through L1/L2 */                                           \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                         \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                         \
+        }                                                                                                  \
+    } while (0)
+
+    if (active) { TOK_REQUEST(issued + 1u); }
+    if (__ballot(active && sbase + 16u <= zn) != 0ull) issued += 1u;
+
+    for (;;) {
+        // ------------------------------------------------------------ 0. move the bytes of the tokens decoded in the PREVIOUS round: up to
+        // four per lane and iteration.  (Moving first, decoding after: the far history a token needs was requested when it was
+        // decoded, a whole round ago -- waiting for it right after the decode left 67 % of the wave cycles in s_waitcnt.)
+        // At most MOVES iterations per round: a long copy goes on in the next rounds while the other lanes decode on -- waiting
+        // for the longest copy of the wave in every round left the short tokens idle (measured: 91 VALU per byte instead of ~25)
+        for (uint32_t mvi = 0; mvi < MOVES && __ballot(exists && (litn != 0u || rem != 0u)) != 0ull; mvi++) {
+            const bool mv = exists && (litn != 0u || rem != 0u);
+            if (mv) {
+                uint32_t v = litv, k = 1;
+                if (litn == 0u) {
+                    k = min(rem, 4u);
+                    const uint32_t src = o - dist;
+                    if (dist <= NEAR) {                             // near history: the ring (unflushed bytes live only here)
+                        const uint32_t a0 = ((src & (RINGB - 4u)) << 6) | lane4, a1 = (((src + 4u) & (RINGB - 4u)) << 6) | lane4;
+                        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(ring8 + a0), w1 = *reinterpret_cast<const uint32_t*>(ring8 + a1);
+                        v = __builtin_amdgcn_alignbyte(w1, w0, src);
+                        // an overlapping copy repeats a pattern of `dist` bytes: only its first period is there yet
+                        if (dist < 4u) v = __builtin_amdgcn_perm(v, v, dist == 1u ? 0x00000000u : dist == 2u ? 0x01000100u : 0x00020100u);
+                    } else {
+                        // far history: the stream's own output, flushed long ago (src + 15 < flushed: URGENT), 8 bytes per load,
+                        // the next 8 requested as soon as these are taken
+                        if (fbn == 0u) {
+                            fb = fpre; fbn = 8u;
+                            if (rem > 8u) fpre = *reinterpret_cast<const u64_unaligned*>(out + src + 8u);
+                        }
+                        v = (uint32_t)fb;
+                        fb >>= 32; fbn -= 4u;
+                    }
+                    rem -= k;
+                }
+                litn = 0;
+                // four bytes at position o, unmasked; `pend` holds the valid low bytes of the dword at o
+                const uint32_t s8 = (o & 3u) * 8u;
+                const uint64_t t64 = (uint64_t)v << s8;
+                const uint32_t d0 = (uint32_t)t64 | pend, d1 = (uint32_t)(t64 >> 32);
+                const uint32_t b0 = ((o & (RINGB - 4u)) << 6) | lane4, b1 = (((o + 4u) & (RINGB - 4u)) << 6) | lane4;
+                *reinterpret_cast<uint32_t*>(ring8 + b0) = d0;
+                *reinterpret_cast<uint32_t*>(ring8 + b1) = d1;
+                const uint32_t q1 = (o & 3u) + k;                  // 1..7
+                o += k;
+                const uint32_t nd = q1 >= 4u ? d1 : d0;
+                pend = nd & ((1u << ((q1 & 3u) * 8u)) - 1u);
+            }
+            TOK_FLUSH();
+        }
+        // ------------------------------------------------------------ 0b. input refill (a lane waits only when it opens a new slot)
+        {
+            const bool need = active && bc <= 32u;
+            if (__ballot(need) != 0ull) {
+                const bool fresh = need && ip == sbase;
+                if (__ballot(fresh) != 0ull) {
+                    const uint32_t after = issued - myissue;
+                    if (__ballot(fresh && after < 2u) == 0ull) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if (__ballot(fresh && after < 1u) == 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                bool dma = false, exhausted = false;
+                if (need) {
+                    bb |= (uint64_t)inq[lane * SLOT_DW + ((ip - sbase) >> 2)] << bc; bc += 32u; ip += 4u;
+                    exhausted = ip - sbase >= 16u;
+                }
+                if (__ballot(exhausted) != 0ull) {
+                    if (exhausted) {
+                        sbase = ip;
+                        dma = sbase + 16u <= zn;
+                        TOK_REQUEST(issued + 1u);
+                    }
+                    if (__ballot(dma) != 0ull) issued += 1u;
+                }
+            }
+        }
+        // ------------------------------------------------------------ 1a. fast path: literal / match inside a fixed block
+        bool slow = false;
+        if (active && srem == 0u && rem == 0u) {              // (a lane still copying takes no new token)
+            slow = need_header;
+            const uint32_t e = lds.lit[(uint32_t)bb & 511u];
+            const uint32_t nb = e & 15u, type = (e >> 13) & 3u;
+            const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;
+            uint64_t x = bb >> nb;
+            const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));
+            x >>= leb;
+            const uint32_t de = lds.dst[(uint32_t)x & 31u];
+            const uint32_t deb = (de >> 16) & 15u;
+            const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> 5) & ((1u << deb) - 1u));
+            const uint32_t mbits = nb + leb + 5u + deb;
+            // input guard: after the refill bc >= 33, so every bit of this token lies below byte ip; with ip + 3 <= zn both
+            // reference checks (deflate.py:1535-1539 after the symbol, :1600 before the copy) pass -- the rest goes the slow way
+            const bool in_ok = ip + 3u <= zn;
+            const bool lit_ok = (type == (uint32_t)T_LIT) & in_ok & (o < cap);
+            const bool len_ok = (type == (uint32_t)T_LEN) & in_ok & (de != 0xFFFFFFFFu) & (distance <= o) &
+                                (distance <= obsize) & (o + tlength <= cap);
+            if (!slow && (lit_ok | len_ok)) {
+                const uint32_t used = lit_ok ? nb : mbits;
+                bb >>= used; bc -= used;
+                if (lit_ok) { litv = (e >> 4) & 0xFFu; litn = 1; }
+                else {
+                    rem = tlength; dist = distance; fbn = 0;
+                    if (distance > NEAR) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
+                }
+            } else {
+                slow = true;                                        // EOB, header, invalid data, any failing check
+            }
+        }
+        // ------------------------------------------------------------ 1b. slow path (wave-uniform branch, rare)
+        if (__ballot(slow || (active && srem != 0u)) != 0ull) {
+            while (slow && active && rem == 0u && srem == 0u && litn == 0u) {
+                TOK_REFILL();
+                if (need_header) {
+                    // HEADER (deflate.py:677-732)
+                    final_ = ((uint32_t)bb & 1u) | oneblock;
+                    const uint32_t hm = assume_fixed ? 1u : ((uint32_t)(bb >> 1) & 3u);
+                    if (hm == 3u) { TOK_FAIL(HDLZ_E_BAD_BTYPE); break; }
+                    if (hm == 2u) { TOK_FAIL(HDLZ_E_DYNAMIC_UNSUPPORTED); break; }
+                    need_header = false;
+                    if (hm == 0u) {
+                        // stored (deflate.py:709-717): LEN sits `skip` bits after the header start
+                        const uint32_t dio = TOK_BITPOS() & 7u;
+                        uint32_t skip = 8u - dio;
+                        if (skip <= 2u) skip = 16u - dio;
+                        const uint32_t length = (uint32_t)(bb >> skip) & 0xFFFFu & len_mask;
+                        bb >>= (skip + 16u); bc -= (skip + 16u);          // now at NLEN = the reference's di
+                        TOK_REFILL();
+                        bb >>= 16; bc -= 16u;                             // NLEN unchecked (D2); data follows
+                        srem = length;
+                        if (length == 0u) {
+                            // COPY with nothing to copy (deflate.py:1617-1626)
+                            if ((int32_t)(TOK_BITPOS() >> 3) >= isize) { TOK_FAIL(HDLZ_E_NO_EOF); break; }
+                            if (final_) { out_len = o; active = false; break; }
+                            need_header = true;
+                        }
+                    } else {
+                        bb >>= 3; bc -= 3u;
+                    }
+                    continue;
+                }
+                // NEXT (deflate.py:1409-1445)
+                const uint32_t e = lds.lit[(uint32_t)bb & 511u];
+                const uint32_t nb = e & 15u, code = (e >> 4) & 0x1FFu;
+                if (nb < 1u) { TOK_FAIL(HDLZ_E_BAD_SYMBOL); break; }
+                bb >>= nb; bc -= nb;
+                // INFLATE (deflate.py:1519-1591)
+                if ((int32_t)(TOK_BITPOS() >> 3) > isize - 3) { TOK_FAIL(HDLZ_E_NO_EOF); break; }   // :1535-1539
+                if (code == 256u) {
+                    if (final_) { out_len = o; active = false; break; }   // D6
+                    need_header = true;
+                    continue;
+                }
+                if (code < 256u) {
+                    if (o >= cap) { TOK_FAIL(HDLZ_E_OUT_CAPACITY); break; }
+                    litv = code; litn = 1;
+                    break;
+                }
+                const uint32_t token = code - 257u;
+                if (token >= 29u) { TOK_FAIL(HDLZ_E_BAD_SYMBOL); break; }
+                uint32_t lbase, leb, dbase, deb;
+                length_info(token, lbase, leb);
+                const uint32_t tlength = lbase + ((uint32_t)bb & ((1u << leb) - 1u));
+                bb >>= leb;
+                const uint32_t dc = rev((uint32_t)bb & 31u, 5);
+                bb >>= 5;
+                if (dc >= 30u) { TOK_FAIL(HDLZ_E_BAD_DISTANCE); break; }
+                dist_info(dc, dbase, deb);
+                const uint32_t distance = dbase + ((uint32_t)bb & ((1u << deb) - 1u));
+                bb >>= deb;
+                bc -= leb + 5u + deb;
+                if (distance > o || distance > obsize) { TOK_FAIL(HDLZ_E_BAD_DISTANCE); break; }        // D8
+                if ((int32_t)(TOK_BITPOS() >> 3) >= isize - 2) { TOK_FAIL(HDLZ_E_NO_EOF); break; }      // COPY hold, :1600
+                if ((uint64_t)o + tlength > cap) { TOK_FAIL(HDLZ_E_OUT_CAPACITY); break; }
+                rem = tlength;
+                dist = distance;
+                fbn = 0;
+                if (distance > NEAR) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
+            }
+            // stored COPY (deflate.py:1603-1616): one byte per round (rare: level-0 streams, incompressible blocks)
+            if (active && srem != 0u && litn == 0u && rem == 0u) {
+                TOK_REFILL();
+                if ((int32_t)(TOK_BITPOS() >> 3) >= isize) { TOK_FAIL(HDLZ_E_NO_EOF); }
+                else if (o >= cap) { TOK_FAIL(HDLZ_E_OUT_CAPACITY); }
+                else {
+                    litv = (uint32_t)bb & 0xFFu; litn = 1;
+                    bb >>= 8; bc -= 8u;
+                    srem--;
+                    if (srem == 0u) {                              // the block ends with this byte (deflate.py:1617-1626)
+                        if ((int32_t)(TOK_BITPOS() >> 3) >= isize) { TOK_FAIL(HDLZ_E_NO_EOF); litn = 0; }
+                        else if (final_) { out_len = o + 1u; active = false; }      // (the byte is still emitted below)
+                        else need_header = true;
+                    }
+                }
+            }
+        }
+        if (__ballot(active || rem != 0u || litn != 0u) == 0ull) break;
+    }
+    // the lines completed since the last batch
+    if (exists && (o - flushed) >= CHUNK) {
+        const uint32_t* rp = &lds.ring[wave][((flushed & (RINGB - 1u)) >> 2) * 64u + lane];
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(out + flushed);
+#pragma unroll
+        for (uint32_t q = 0; q < CHUNK / 4u; q++) d32[q] = rp[q * 64u];
+        flushed += CHUNK;
+    }
+#undef TOK_FAIL
+#undef TOK_BITPOS
+#undef TOK_REFILL
+#undef TOK_REQUEST
+#undef TOK_FLUSH
+
+    // no LDS-DMA load may still be in flight when this wave's LDS is handed to another workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- tail: the bytes behind the last flushed line are still only in the ring
+    if (exists && status == HDLZ_OK) {
+        for (uint32_t p = flushed; p < out_len; p++) out[p] = ring8[ring_addr(p, lane4)];
+    }
+    if (exists) {
+        a.out_len[sid] = out_len;
+        a.status[sid] = status;
+    }
+}
+
+}  // namespace tok
+
+hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
+    if (a.nstreams == 0) return hipSuccess;
+    const uint64_t per_wg = 64u * tok::WAVES;
+    const dim3 grid((unsigned)((a.nstreams + per_wg - 1u) / per_wg)), block(64 * tok::WAVES);
+    hipLaunchKernelGGL(tok::k_inflate_tok, grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace hdlz

@@ -66,6 +66,9 @@ enum {
 #define HDLZ_INFLATE_LANE_PER_STREAM 2u
 #define HDLZ_INFLATE_WAVE_PER_STREAM 4u
 #define HDLZ_INFLATE_WAVE_THRESHOLD 49152u
+/* lane-per-stream kernel variant: 16 = one token per round (k_inflate_tok), 32 = one output byte per iteration (k_inflate) */
+#define HDLZ_INFLATE_TOKEN_ROUNDS 16u
+#define HDLZ_INFLATE_BYTE_LOCKSTEP 32u
 
 int hdlz_version(void);
 const char* hdlz_status_string(int status);

@@ -11,7 +11,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-MAPPINGS = (2, 4)       # hdlz_inflate_batch mapping hints: HDLZ_INFLATE_LANE_PER_STREAM, HDLZ_INFLATE_WAVE_PER_STREAM
+MAPPINGS = (2, 4, 2 | 16)   # hdlz_inflate_batch mapping hints: lane per stream (byte lockstep), wave per stream, lane per stream (token rounds)
 
 
 _r = random.Random(8)
