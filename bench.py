@@ -367,8 +367,8 @@ def bench_inflate(a, eng=None, cpu=True):
                       "streams": B, "block_bytes": n},
            "input_MBps": round(z_bytes / (dt / a.steps) / 1e6, 1),
            "compression_ratio_out_over_in": round(z_bytes / u_bytes, 4),
-           "roofline": roofline("k_inflate" if fixed else "k_inflate + k_inflate_dyn", algo, k_ms,
-                                "k_inflate|streams=%d|block=%d" % (B, n))}
+           "roofline": roofline(("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok") + ("" if fixed else " + k_inflate_dyn"), algo, k_ms,
+                                "%s|streams=%d|block=%d" % ("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok", B, n))}
     if cpu and a.cpu_seconds > 0:
         from oracle import oracle as O
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

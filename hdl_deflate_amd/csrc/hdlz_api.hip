@@ -115,7 +115,9 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
         if (e != hipSuccess) return fail_hip(e, "launch k_inflate_dyn");
         return HDLZ_OK;
     }
-    hipError_t e = (flags & HDLZ_INFLATE_TOKEN_ROUNDS) ? hdlz::launch_inflate_tok(a, st) : hdlz::launch_inflate(a, st);
+    // lane per stream: one TOKEN per round (k_inflate_tok, round 2: 362 GB/s on BASELINE configs[3]) unless the caller asks for
+    // round 1's one-byte-per-iteration kernel (k_inflate, 278 GB/s)
+    hipError_t e = (flags & HDLZ_INFLATE_BYTE_LOCKSTEP) ? hdlz::launch_inflate(a, st) : hdlz::launch_inflate_tok(a, st);
     if (e != hipSuccess) return fail_hip(e, "launch k_inflate");
     // second pass, same stream: streams in which pass 1 met a dynamic-tree block (status 6) are redone
     // by one wave each; everything else is left untouched

@@ -14,7 +14,7 @@
 //     64-byte sector per lane); flushes are batched: they run when a quarter of the wave is ready or one lane is about to overrun;
 //   * near history (distance <= 120) is read from the ring, far history from the stream's own flushed output, four bytes at a time;
 //   * input arrives through 16-byte LDS-DMA slots per lane (hdlz_inflate.hip explains the ordering rule).
-// Status codes and the ORDER of the reference's checks are those of k_inflate / the oracle: the slow path is the same code.
+// Status codes and the ORDER of the reference's checks are those of k_inflate: the slow path is the same code.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
@@ -194,9 +194,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
                 }                                                                                          \
                 flushed += CHUNK;                                                                          \
             }                                                                                              \
-            /* far copies read these bytes back through L1/L2 */                                           \
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                         \
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                         \
+            /* (no fence: a far copy reads bytes that THIS lane stored -- program order of one thread; k_inflate's lines are */ \
+            /* stored by other lanes and need the workgroup-scope release / acquire, a full store round trip per flush)     */ \
         }                                                                                                  \
     } while (0)
 

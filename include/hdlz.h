@@ -66,7 +66,8 @@ enum {
 #define HDLZ_INFLATE_LANE_PER_STREAM 2u
 #define HDLZ_INFLATE_WAVE_PER_STREAM 4u
 #define HDLZ_INFLATE_WAVE_THRESHOLD 49152u
-/* lane-per-stream kernel variant: 16 = one token per round (k_inflate_tok), 32 = one output byte per iteration (k_inflate) */
+/* lane-per-stream kernel variant (results are identical): the default and 16 = one token per round (k_inflate_tok),
+ * 32 = one output byte per lockstep iteration (k_inflate, the round-1 kernel) */
 #define HDLZ_INFLATE_TOKEN_ROUNDS 16u
 #define HDLZ_INFLATE_BYTE_LOCKSTEP 32u
 

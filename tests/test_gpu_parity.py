@@ -11,7 +11,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-MAPPINGS = (2, 4, 2 | 16)   # hdlz_inflate_batch mapping hints: lane per stream (byte lockstep), wave per stream, lane per stream (token rounds)
+MAPPINGS = (2, 4, 2 | 32)   # hdlz_inflate_batch mapping hints: lane per stream (token rounds: the default), wave per stream, lane per stream (byte lockstep)
 
 
 _r = random.Random(8)

@@ -70,7 +70,7 @@ def main():
         okb = hs == 0
         if okb.any():
             cap = (int(lens.max()) + 15) // 16 * 16 + 16
-            back, bl, bs = eng.inflate_batch(out, out_pitch=cap, flags=int(rng.choice([0, 2, 4, 18])))   # default / lane / wave mapping
+            back, bl, bs = eng.inflate_batch(out, out_pitch=cap, flags=int(rng.choice([0, 2, 4, 34])))   # default / lane / wave mapping
             torch.cuda.synchronize()
             hb, hbl, hbs = back.cpu().numpy(), bl.cpu().numpy(), bs.cpu().numpy()
             for b in np.nonzero(okb)[0][: 4000]:
@@ -99,7 +99,7 @@ def main():
                 zflat = np.frombuffer(b"".join(zs) + bytes(64), dtype=np.uint8).copy()
                 cap = (int(lens[sel].max()) + 15) // 16 * 16 + 16
                 zb, zl, zst = eng.inflate_batch(torch.from_numpy(zflat).cuda(), in_off=torch.from_numpy(zoff).cuda(), out_pitch=cap,
-                                                   flags=int(rng.choice([0, 2, 4, 18])))
+                                                   flags=int(rng.choice([0, 2, 4, 34])))
                 torch.cuda.synchronize()
                 hb, hbl, hbs = zb.cpu().numpy(), zl.cpu().numpy(), zst.cpu().numpy()
                 for k, b in enumerate(sel):
