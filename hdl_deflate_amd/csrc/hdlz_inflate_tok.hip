@@ -30,12 +30,12 @@ constexpr uint32_t RING_DW = RINGB / 4;
 constexpr uint32_t NEAR = RINGB - 12;         // distances up to this are served from the ring: NEAR + 3 (dword alignment of the
                                               // source) + 8 (the unmasked write ahead of the end) < RINGB
 constexpr uint32_t CHUNK = RINGB >= 128u ? 64u : RINGB / 2u;   // bytes per flush
-constexpr uint32_t URGENT = RINGB - 36;       // a lane with this many unflushed bytes forces a flush (+3 per move, +8 written ahead,
-                                              // and the far prefetch reads 16 bytes from o - dist on: they must be flushed)
+constexpr uint32_t URGENT = RINGB - 44;       // a lane with this many unflushed bytes forces a flush (+3 per move, +8 written ahead,
+                                              // and the far prefetch reads 24 bytes from o - dist on: they must be flushed)
 constexpr uint32_t WAVES = 4;
 constexpr uint32_t SLOT_DW = 4;               // input dwords fetched per lane and refill
 #ifndef HDLZ_TOK_MOVES
-#define HDLZ_TOK_MOVES 2
+#define HDLZ_TOK_MOVES 4
 #endif
 constexpr uint32_t MOVES = HDLZ_TOK_MOVES;    // move iterations (4 bytes per lane each) per round
 
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
     uint32_t flushed = 0;       // ... of which in HBM (a multiple of 64)
     uint32_t pend = 0;          // the valid low bytes of the ring dword that holds position o
     uint32_t rem = 0, dist = 0; // pending LZ copy
-    uint64_t fb = 0, fpre = 0;  // far copy: 8 source bytes being consumed, and the NEXT 8, requested a round ahead
+    uint64_t fb = 0, fpre = 0, fpre2 = 0;  // far copy: 8 source bytes being consumed, and the NEXT 16, requested a round / two chunks ahead
     uint32_t fbn = 0;           // bytes left in fb
     uint32_t litv = 0, litn = 0;// pending literal / stored byte (litn = 0 or 1)
     uint32_t srem = 0;          // pending stored bytes
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
         for (uint32_t mvi = 0; mvi < MOVES && __ballot(exists && (litn != 0u || rem != 0u)) != 0ull; mvi++) {
             const bool mv = exists && (litn != 0u || rem != 0u);
             if (mv) {
-                uint32_t v = litv, k = 1;
+                uint32_t v = litv, k = litn;                       // 1..3 literals, or
                 if (litn == 0u) {
                     k = min(rem, 4u);
                     const uint32_t src = o - dist;
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
                         // far history: the stream's own output, flushed long ago (src + 15 < flushed: URGENT), 8 bytes per load,
                         // the next 8 requested as soon as these are taken
                         if (fbn == 0u) {
-                            fb = fpre; fbn = 8u;
-                            if (rem > 8u) fpre = *reinterpret_cast<const u64_unaligned*>(out + src + 8u);
+                            fb = fpre; fpre = fpre2; fbn = 8u;
+                            if (rem > 16u) fpre2 = *reinterpret_cast<const u64_unaligned*>(out + src + 16u);
                         }
                         v = (uint32_t)fb;
                         fb >>= 32; fbn -= 4u;
@@ -274,36 +274,53 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
                 }
             }
         }
-        // ------------------------------------------------------------ 1a. fast path: literal / match inside a fixed block
+        // ------------------------------------------------------------ 1a. fast path: up to three literals and then a match, inside a
+        // fixed block.  (One token per round made the literal-heavy streams the lanes the whole wave waits for: 362 -> 390 GB/s with
+        // literal triples, more with the match behind them.)
         bool slow = false;
         if (active && srem == 0u && rem == 0u) {              // (a lane still copying takes no new token)
             slow = need_header;
-            const uint32_t e = lds.lit[(uint32_t)bb & 511u];
-            const uint32_t nb = e & 15u, type = (e >> 13) & 3u;
-            const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;
-            uint64_t x = bb >> nb;
-            const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));
-            x >>= leb;
-            const uint32_t de = lds.dst[(uint32_t)x & 31u];
-            const uint32_t deb = (de >> 16) & 15u;
-            const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> 5) & ((1u << deb) - 1u));
-            const uint32_t mbits = nb + leb + 5u + deb;
-            // input guard: after the refill bc >= 33, so every bit of this token lies below byte ip; with ip + 3 <= zn both
-            // reference checks (deflate.py:1535-1539 after the symbol, :1600 before the copy) pass -- the rest goes the slow way
+            // input guard: after the refill bc >= 33, and a token is only taken when at least one buffered bit is left behind it, so
+            // its bit position lies below byte ip; with ip + 3 <= zn both reference checks (deflate.py:1535-1539 after the symbol,
+            // :1600 before the copy) are guaranteed to pass -- anything closer to the end goes the slow way
             const bool in_ok = ip + 3u <= zn;
-            const bool lit_ok = (type == (uint32_t)T_LIT) & in_ok & (o < cap);
-            const bool len_ok = (type == (uint32_t)T_LEN) & in_ok & (de != 0xFFFFFFFFu) & (distance <= o) &
-                                (distance <= obsize) & (o + tlength <= cap);
-            if (!slow && (lit_ok | len_ok)) {
-                const uint32_t used = lit_ok ? nb : mbits;
-                bb >>= used; bc -= used;
-                if (lit_ok) { litv = (e >> 4) & 0xFFu; litn = 1; }
-                else {
+            if (!slow && in_ok) {
+                uint32_t nl = 0;
+#pragma unroll
+                for (uint32_t extra = 0; extra < 3u; extra++) {    // (the third look-up still has 33 - 9 - 9 = 15 valid bits)
+                    const uint32_t e2 = lds.lit[(uint32_t)bb & 511u];
+                    if (nl == extra && ((e2 >> 13) & 3u) == (uint32_t)T_LIT && o + extra < cap) {
+                        litv = extra == 0u ? ((e2 >> 4) & 0xFFu) : (litv | (((e2 >> 4) & 0xFFu) << (8u * extra)));
+                        nl = extra + 1u;
+                        bb >>= (e2 & 15u); bc -= (e2 & 15u);
+                    }
+                }
+                litn = nl;
+                const uint32_t e = lds.lit[(uint32_t)bb & 511u];
+                const uint32_t nb = e & 15u, type = (e >> 13) & 3u;
+                const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;
+                uint64_t x = bb >> nb;
+                const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));
+                x >>= leb;
+                const uint32_t de = lds.dst[(uint32_t)x & 31u];
+                const uint32_t deb = (de >> 16) & 15u;
+                const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> 5) & ((1u << deb) - 1u));
+                const uint32_t mbits = nb + leb + 5u + deb;
+                const uint32_t om = o + nl;                        // where the copy will start
+                const bool len_ok = (type == (uint32_t)T_LEN) & (mbits < bc) & (de != 0xFFFFFFFFu) & (distance <= om) &
+                                    (distance <= obsize) & (om + tlength <= cap);
+                if (len_ok) {
+                    bb >>= mbits; bc -= mbits;
                     rem = tlength; dist = distance; fbn = 0;
-                    if (distance > NEAR) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
+                    if (distance > NEAR) {
+                        fpre = *reinterpret_cast<const u64_unaligned*>(out + (om - distance));
+                        if (tlength > 8u) fpre2 = *reinterpret_cast<const u64_unaligned*>(out + (om - distance) + 8u);
+                    }
+                } else if (nl == 0u) {
+                    slow = true;                                    // EOB, invalid data, any failing check
                 }
             } else {
-                slow = true;                                        // EOB, header, invalid data, any failing check
+                slow = true;                                        // header, end of the input
             }
         }
         // ------------------------------------------------------------ 1b. slow path (wave-uniform branch, rare)
@@ -374,7 +391,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
                 rem = tlength;
                 dist = distance;
                 fbn = 0;
-                if (distance > NEAR) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
+                if (distance > NEAR) {
+                    fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
+                    if (tlength > 8u) fpre2 = *reinterpret_cast<const u64_unaligned*>(out + (o - distance) + 8u);
+                }
             }
             // stored COPY (deflate.py:1603-1616): one byte per round (rare: level-0 streams, incompressible blocks)
             if (active && srem != 0u && litn == 0u && rem == 0u) {
