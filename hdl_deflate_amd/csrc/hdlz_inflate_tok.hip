@@ -27,8 +27,8 @@ namespace tok {
 #endif
 constexpr uint32_t RINGB = HDLZ_TOK_RING;     // ring bytes per stream (128 or 64)
 constexpr uint32_t RING_DW = RINGB / 4;
-constexpr uint32_t NEAR = RINGB - 12;         // distances up to this are served from the ring: NEAR + 3 (dword alignment of the
-                                              // source) + 8 (the unmasked write ahead of the end) < RINGB
+constexpr uint32_t NEAR = RINGB - 16;         // distances up to this are served from the ring: NEAR + 3 (dword alignment of the
+                                              // source) + 12 (the unmasked write ahead of the end) < RINGB
 constexpr uint32_t CHUNK = RINGB >= 128u ? 64u : RINGB / 2u;   // bytes per flush
 constexpr uint32_t URGENT = RINGB - 44;       // a lane with this many unflushed bytes forces a flush (+3 per move, +8 written ahead,
                                               // and the far prefetch reads 24 bytes from o - dist on: they must be flushed)
@@ -147,8 +147,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
     uint32_t flushed = 0;       // ... of which in HBM (a multiple of 64)
     uint32_t pend = 0;          // the valid low bytes of the ring dword that holds position o
     uint32_t rem = 0, dist = 0; // pending LZ copy
-    uint64_t fb = 0, fpre = 0, fpre2 = 0;  // far copy: 8 source bytes being consumed, and the NEXT 16, requested a round / two chunks ahead
-    uint32_t fbn = 0;           // bytes left in fb
+    uint64_t fpre = 0, fpre2 = 0;  // far copy: the next 16 source bytes, requested a round / two moves ahead
     uint32_t litv = 0, litn = 0;// pending literal / stored byte (litn = 0 or 1)
     uint32_t srem = 0;          // pending stored bytes
     uint32_t final_ = 0;
@@ -211,39 +210,39 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
         for (uint32_t mvi = 0; mvi < MOVES && __ballot(exists && (litn != 0u || rem != 0u)) != 0ull; mvi++) {
             const bool mv = exists && (litn != 0u || rem != 0u);
             if (mv) {
-                uint32_t v = litv, k = litn;                       // 1..3 literals, or
+                uint32_t v = litv, vhi = 0, k = litn;              // 1..3 literals, or
                 if (litn == 0u) {
-                    k = min(rem, 4u);
                     const uint32_t src = o - dist;
-                    if (dist <= NEAR) {                             // near history: the ring (unflushed bytes live only here)
+                    if (dist <= NEAR) {                             // near history: the ring (unflushed bytes live only here), 4 bytes
+                        k = min(rem, 4u);
                         const uint32_t a0 = ((src & (RINGB - 4u)) << 6) | lane4, a1 = (((src + 4u) & (RINGB - 4u)) << 6) | lane4;
                         const uint32_t w0 = *reinterpret_cast<const uint32_t*>(ring8 + a0), w1 = *reinterpret_cast<const uint32_t*>(ring8 + a1);
                         v = __builtin_amdgcn_alignbyte(w1, w0, src);
                         // an overlapping copy repeats a pattern of `dist` bytes: only its first period is there yet
                         if (dist < 4u) v = __builtin_amdgcn_perm(v, v, dist == 1u ? 0x00000000u : dist == 2u ? 0x01000100u : 0x00020100u);
                     } else {
-                        // far history: the stream's own output, flushed long ago (src + 15 < flushed: URGENT), 8 bytes per load,
-                        // the next 8 requested as soon as these are taken
-                        if (fbn == 0u) {
-                            fb = fpre; fpre = fpre2; fbn = 8u;
-                            if (rem > 16u) fpre2 = *reinterpret_cast<const u64_unaligned*>(out + src + 16u);
-                        }
-                        v = (uint32_t)fb;
-                        fb >>= 32; fbn -= 4u;
+                        // far history: the stream's own output, flushed long ago (src + 23 < flushed: URGENT), 8 bytes per move; two
+                        // more chunks are in flight, the third is requested as soon as this one is taken
+                        k = min(rem, 8u);
+                        v = (uint32_t)fpre; vhi = (uint32_t)(fpre >> 32);
+                        fpre = fpre2;
+                        if (rem > 16u) fpre2 = *reinterpret_cast<const u64_unaligned*>(out + src + 16u);
                     }
                     rem -= k;
                 }
                 litn = 0;
-                // four bytes at position o, unmasked; `pend` holds the valid low bytes of the dword at o
+                // eight bytes at position o, unmasked; `pend` holds the valid low bytes of the dword at o
                 const uint32_t s8 = (o & 3u) * 8u;
-                const uint64_t t64 = (uint64_t)v << s8;
-                const uint32_t d0 = (uint32_t)t64 | pend, d1 = (uint32_t)(t64 >> 32);
-                const uint32_t b0 = ((o & (RINGB - 4u)) << 6) | lane4, b1 = (((o + 4u) & (RINGB - 4u)) << 6) | lane4;
+                const uint64_t ta = (uint64_t)v << s8, tb = (uint64_t)vhi << s8;
+                const uint32_t d0 = (uint32_t)ta | pend, d1 = (uint32_t)(ta >> 32) | (uint32_t)tb, d2 = (uint32_t)(tb >> 32);
+                const uint32_t b0 = ((o & (RINGB - 4u)) << 6) | lane4, b1 = (((o + 4u) & (RINGB - 4u)) << 6) | lane4,
+                               b2 = (((o + 8u) & (RINGB - 4u)) << 6) | lane4;
                 *reinterpret_cast<uint32_t*>(ring8 + b0) = d0;
                 *reinterpret_cast<uint32_t*>(ring8 + b1) = d1;
-                const uint32_t q1 = (o & 3u) + k;                  // 1..7
+                *reinterpret_cast<uint32_t*>(ring8 + b2) = d2;
+                const uint32_t q1 = (o & 3u) + k;                  // 1..11
                 o += k;
-                const uint32_t nd = q1 >= 4u ? d1 : d0;
+                const uint32_t nd = q1 >= 8u ? d2 : q1 >= 4u ? d1 : d0;
                 pend = nd & ((1u << ((q1 & 3u) * 8u)) - 1u);
             }
             TOK_FLUSH();
@@ -311,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
                                     (distance <= obsize) & (om + tlength <= cap);
                 if (len_ok) {
                     bb >>= mbits; bc -= mbits;
-                    rem = tlength; dist = distance; fbn = 0;
+                    rem = tlength; dist = distance;
                     if (distance > NEAR) {
                         fpre = *reinterpret_cast<const u64_unaligned*>(out + (om - distance));
                         if (tlength > 8u) fpre2 = *reinterpret_cast<const u64_unaligned*>(out + (om - distance) + 8u);
@@ -390,7 +389,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
                 if ((uint64_t)o + tlength > cap) { TOK_FAIL(HDLZ_E_OUT_CAPACITY); break; }
                 rem = tlength;
                 dist = distance;
-                fbn = 0;
                 if (distance > NEAR) {
                     fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
                     if (tlength > 8u) fpre2 = *reinterpret_cast<const u64_unaligned*>(out + (o - distance) + 8u);
