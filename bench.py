@@ -50,6 +50,8 @@ def measured_traffic(key):
 def kname_for(cwindow, n=1 << 16):
     """the kernel symbol hdlz_compress_batch launches for this window / block size (hdlz_compress.hip: launch_compress)"""
     nch = 1 if cwindow <= 32 else 2 if cwindow <= 64 else 8
+    if nch == 1 and 5 <= n <= 1024:
+        return "k_compress_small<false, %s>" % ("true" if cwindow == 32 else "false")      # several small blocks per wave-tile
     return "k_compress<%d, %s, %s>" % (nch, "true" if cwindow == 32 * nch else "false", "true" if (nch == 1 and n <= 2048) else "false")
 
 

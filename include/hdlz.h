@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HDLZ_VERSION 0x000100
+#define HDLZ_VERSION 0x000200   /* round 2: + hdlz_compress_chunk, hdlz_inflate_chunk, HDLZ_INFLATE_ONEBLOCK, kernel-variant hints */
 
 /* command codes of the reference port surface (deflate.py:18) -- used by the adapter */
 enum { HDLZ_IDLE = 0, HDLZ_WRITE = 1, HDLZ_READ = 2, HDLZ_STARTC = 3, HDLZ_STARTD = 4 };
