@@ -108,3 +108,37 @@ def test_inflate_session_equals_one_shot(engine, oracle):
     assert st == 0 and got == plain[0][:2000]
     st, got = _feed_inflate(engine, z[:-1], r, 200, 512, flags=1 | 8)
     assert st == 0 and got == plain[0][:2000]
+
+
+def test_session_edge_cases(engine, oracle):
+    """tiny streams, one-byte feeding, lengths around the look-ahead margin (11) and the lane granularity (32), empty stored
+    blocks, a session reused after it finished, calls that have nothing to do"""
+    r = random.Random(79)
+    for n in list(range(5, 50)) + [63, 64, 65, 75, 76, 77, 2047, 2048, 2049, 2059, 2060, 4096 + 11, 4096 + 43]:
+        data = bytes(r.choice(b"abcab") for _ in range(n))
+        rc, ref = oracle.compress(data)
+        s = engine.compress_session()
+        for i in range(0, n, 7):                      # seven bytes at a time, a step after every piece
+            s.write(data[i:i + 7])
+            assert s.step() == 0 and s.pos % 32 == 0 and s.pos + 11 <= s.n + 0 or s.pos == 0
+        assert s.step(final=True) == 0 and s.done and s.output(0, s.out_len) == ref, n
+        assert s.step(final=True) == 0 and s.out_len == len(ref)          # a finished session stays as it is
+        st, got = _feed_inflate(engine, ref, r, 1, 512)                   # one byte per call
+        assert st == 0 and got == data, n
+    s = engine.compress_session()
+    assert s.step() == 0 and s.step(final=True) == 1                       # nothing written: SHORT_INPUT, no launch
+    # empty stored blocks (Z_FULL_FLUSH markers) between and after data, fed in small pieces
+    co = zlib.compressobj(6)
+    d = bytes(r.choice(b"hello world ") for _ in range(3000))
+    z = co.compress(d[:1000]) + co.flush(zlib.Z_FULL_FLUSH) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(d[1000:]) + co.flush(zlib.Z_SYNC_FLUSH) + co.flush()
+    assert zlib.decompress(z) == d
+    for piece in (1, 3, 50, 5000):
+        st, got = _feed_inflate(engine, z, r, piece, 700)
+        assert st == 0 and got == d, piece
+    # an output limit that never grows: the session reports need == 2 again and again without producing more
+    isn = engine.inflate_session()
+    isn.write(z)
+    assert isn.step(final=True, out_limit=100) == 0 and isn.need == 2 and isn.out_pos <= 100
+    p = isn.out_pos
+    assert isn.step(final=True, out_limit=100) == 0 and isn.need == 2 and isn.out_pos == p and isn.output(0, p) == d[:p]
+    assert isn.step(final=True, out_limit=1 << 20) == 0 and isn.done and isn.output(0, isn.out_pos) == d
