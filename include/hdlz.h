@@ -65,7 +65,7 @@ enum {
  * one wave per stream, larger ones one lane per stream with a wave-per-stream second pass for dynamic-tree streams */
 #define HDLZ_INFLATE_LANE_PER_STREAM 2u
 #define HDLZ_INFLATE_WAVE_PER_STREAM 4u
-#define HDLZ_INFLATE_WAVE_THRESHOLD 49152u
+#define HDLZ_INFLATE_WAVE_THRESHOLD 14336u
 /* lane-per-stream kernel variant (results are identical): the default and 16 = one token per round (k_inflate_tok),
  * 32 = one output byte per lockstep iteration (k_inflate, the round-1 kernel) */
 #define HDLZ_INFLATE_TOKEN_ROUNDS 16u
