@@ -119,10 +119,12 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     // round 1's one-byte-per-iteration kernel (k_inflate, 278 GB/s)
     hipError_t e = (flags & HDLZ_INFLATE_BYTE_LOCKSTEP) ? hdlz::launch_inflate(a, st) : hdlz::launch_inflate_tok(a, st);
     if (e != hipSuccess) return fail_hip(e, "launch k_inflate");
-    // second pass, same stream: streams in which pass 1 met a dynamic-tree block (status 6) are redone
-    // by one wave each; everything else is left untouched
-    e = hdlz::launch_inflate_dyn(a, st, false);
-    if (e != hipSuccess) return fail_hip(e, "launch k_inflate_dyn");
+    // second pass, same stream: streams in which pass 1 met a dynamic-tree block (status 6) are redone, again one lane each
+    // (k_inflate_tok<true>; HDLZ_INFLATE_BYTE_LOCKSTEP keeps round 1's pair: one wave per such stream); everything else is
+    // left untouched
+    e = ((flags & HDLZ_INFLATE_BYTE_LOCKSTEP) || nstreams > 0xFFFFFFFFull) ? hdlz::launch_inflate_dyn(a, st, false)
+                                                                            : hdlz::launch_inflate_tok_dyn(a, st, false);
+    if (e != hipSuccess) return fail_hip(e, "launch the dynamic-tree pass");
     return HDLZ_OK;
 }
 

@@ -15,6 +15,16 @@
 //   * near history (distance <= 120) is read from the ring, far history from the stream's own flushed output, four bytes at a time;
 //   * input arrives through 16-byte LDS-DMA slots per lane (hdlz_inflate.hip explains the ordering rule).
 // Status codes and the ORDER of the reference's checks are those of k_inflate: the slow path is the same code.
+//
+// DYN = true is the same kernel for streams with DYNAMIC-TREE blocks (BTYPE = 2; deflate.py:1084-1202 BL/READBL/REPEAT, :1204-1400
+// HF1..HF4/SPREAD, :1447-1517 D_NEXT), the second pass over the streams the first one flagged HDLZ_E_DYNAMIC_UNSUPPORTED.  A lane
+// cannot hold a 512-entry look-up table per stream, but a canonical code needs none: with the codes left-aligned to 15 bits the
+// codes of length <= l end at hi[l], and the word X[l] = hi[l] << 16 | l << 9 | index of the last symbol of length <= l, minus the
+// reversed stream bits R = r << 16 | 0xFFFF, is -- for the right length -- the smallest of the fifteen differences that did not
+// wrap: 15 v_sub + 7 v_min3 per symbol, all registers (the key-difference trick of the compress search, hdlz_compress_common.h).
+// What is left per lane in LDS is the symbol list sorted by (length, value): 286 bytes + 286 ninth bits + 30 distance symbols,
+// 440 bytes with the counters of the build -- 37 KB per wave with the ring, four waves per CU.  The code lengths themselves are
+// never stored: the header is decoded twice, once to count the lengths and once to place the symbols.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
@@ -32,18 +42,28 @@ constexpr uint32_t NEAR = RINGB - 16;         // distances up to this are served
 constexpr uint32_t CHUNK = RINGB >= 128u ? 64u : RINGB / 2u;   // bytes per flush
 constexpr uint32_t URGENT = RINGB - 44;       // a lane with this many unflushed bytes forces a flush (+3 per move, +8 written ahead,
                                               // and the far prefetch reads 24 bytes from o - dist on: they must be flushed)
-constexpr uint32_t WAVES = 4;
 constexpr uint32_t SLOT_DW = 4;               // input dwords fetched per lane and refill
 #ifndef HDLZ_TOK_MOVES
 #define HDLZ_TOK_MOVES 4
 #endif
 constexpr uint32_t MOVES = HDLZ_TOK_MOVES;    // move iterations (4 bytes per lane each) per round
 
+// DYN: per-lane tables, rows of 64 dwords (row j of lane l = dword j * 64 + l: every lane stays in its own bank)
+constexpr uint32_t T_LS8 = 0;                 // 288 bytes: the low 8 bits of the literal/length symbols, sorted by (code length, value)
+constexpr uint32_t T_LBIT = 72;               // 288 bits: their ninth bit
+constexpr uint32_t T_DS8 = 81;                // 32 bytes: the distance symbols, sorted
+constexpr uint32_t T_CNT = 89;                // 2 x 16 u16: symbols per code length (pass 1), then the next free slot per length (pass 2)
+constexpr uint32_t T_CS8 = 105;               // 19 bytes: the symbols of the code-length code, sorted
+constexpr uint32_t T_ROWS = 110;
+
+template <bool DYN>
 struct __attribute__((aligned(16))) Lds {
+    static constexpr uint32_t WAVES = DYN ? 1u : 4u;
     uint32_t ring[WAVES][RING_DW * 64];   // per wave: [dword][lane]
     uint32_t inq[WAVES][64 * SLOT_DW];    // per lane: SLOT_DW stream dwords from byte `sbase` on (LDS-DMA)
-    uint32_t lit[512];
-    uint32_t dst[32];
+    uint32_t lit[DYN ? 1 : 512];
+    uint32_t dst[DYN ? 1 : 32];
+    uint32_t tab[DYN ? T_ROWS * 64 : 1];
 };
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
@@ -101,16 +121,62 @@ __device__ __forceinline__ uint32_t dst_entry(uint32_t raw5) {
 // byte address of stream position `pos` of lane `lane` inside a wave's ring
 __device__ __forceinline__ uint32_t ring_addr(uint32_t pos, uint32_t lane4) { return ((pos & (RINGB - 4u)) << 6) | lane4 | (pos & 3u); }
 
-__global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
-    __shared__ Lds lds;
+// the X words of a canonical code (see the head of the file), from the per-length symbol counts c(1..NL):
+//   X[l-1] = (hi_l << 16 | l << 9 | last_l) - 1,  hi_l = (number of codes of length <= l, as l-bit values) << (15 - l)
+// `left` is zlib's / puff's completeness count (0 = complete, < 0 = over-subscribed), `cum` the number of coded symbols
+template <int NL, class CountOf>
+__device__ __forceinline__ void x_build(uint32_t (&X)[NL], CountOf count_of, int32_t& left, uint32_t& cum) {
+    uint32_t first = 0;
+    left = 1; cum = 0;
+#pragma unroll
+    for (int l = 1; l <= NL; l++) {
+        const uint32_t c = count_of(l);
+        left = (left << 1) - (int32_t)c;
+        cum += c;
+        first += c;
+        X[l - 1] = (((first << (15 - l)) << 16) | ((uint32_t)l << 9) | (max(cum, 1u) - 1u)) - 1u;
+        first <<= 1;
+    }
+}
+// the code in front of `bits` (LSB first): its length and the index of its symbol in the sorted list.  A difference that wrapped
+// belongs to a length whose codes all lie below the stream bits; equal hi (lengths without codes) tie on the shorter length.
+template <int NL>
+__device__ __forceinline__ void x_decode(const uint32_t (&X)[NL], uint32_t bits, uint32_t& len, uint32_t& idx, bool& valid) {
+    const uint32_t R = (__builtin_bitreverse32(bits) >> 1) | 0xFFFFu;
+    uint32_t d[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) d[l] = X[l] - R;
+    uint32_t m = d[0];
+    static_assert(NL % 2 == 1, "min3 tree");
+#pragma unroll
+    for (int l = 1; l < NL; l += 2) m = min(m, min(d[l], d[l + 1]));
+    valid = (int32_t)m >= 0;
+    len = (m >> 9) & 15u;
+    idx = (m & 511u) - ((m >> 16) >> (15u - len));
+}
+
+template <bool DYN>
+__global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, const uint32_t* __restrict__ list,
+                                                                const uint32_t* __restrict__ list_n) {
+    constexpr uint32_t WAVES = Lds<DYN>::WAVES;
+    __shared__ Lds<DYN> lds;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    for (uint32_t c = threadIdx.x; c < 512u; c += 64u * WAVES) lds.lit[c] = lit_entry(c);
-    if (threadIdx.x < 32u) lds.dst[threadIdx.x] = dst_entry(threadIdx.x);
-    __syncthreads();                 // the only workgroup barrier: the waves are independent from here on
-
-    const uint64_t sid = ((uint64_t)blockIdx.x * WAVES + wave) * 64u + lane;
-    const bool exists = sid < a.nstreams;
+    if constexpr (!DYN) {
+        for (uint32_t c = threadIdx.x; c < 512u; c += 64u * WAVES) lds.lit[c] = lit_entry(c);
+        if (threadIdx.x < 32u) lds.dst[threadIdx.x] = dst_entry(threadIdx.x);
+        __syncthreads();             // the only workgroup barrier: the waves are independent from here on
+    }
+    // DYN: lane g of the grid takes the g-th stream of the list k_collect_dyn made of the streams pass 1 could not finish
+    const uint64_t gid = ((uint64_t)blockIdx.x * WAVES + wave) * 64u + lane;
+    uint64_t sid = gid;
+    bool exists = gid < a.nstreams;
+    if constexpr (DYN) {
+        if (list) {
+            exists = gid < (uint64_t)*list_n;
+            sid = exists ? (uint64_t)list[gid] : 0ull;
+        }
+    }
     uint64_t off = 0;
     uint32_t zn = 0;
     if (exists) {
@@ -197,6 +263,175 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
             /* stored by other lanes and need the workgroup-scope release / acquire, a full store round trip per flush)     */ \
         }                                                                                                  \
     } while (0)
+
+    // ---- the symbol in front of the stream bits, as a stat_leaves-style entry (lit_entry's layout), and the distance code
+    // behind a length: dbase | deb << 16 and the bits of the code; NO_DCODE / BAD_DCODE = no such code / symbols 30, 31
+    constexpr uint32_t NO_DCODE = 0xFFFFFFFEu, BAD_DCODE = 0xFFFFFFFFu;
+    [[maybe_unused]] uint32_t XL[15], XD[15];       // DYN: the X words of this lane's literal/length and distance code
+    [[maybe_unused]] bool fixedblk = false;         // DYN: the current block is a fixed one (its symbol 287 is the reference's zero leaf)
+    [[maybe_unused]] uint8_t* tab8 = reinterpret_cast<uint8_t*>(lds.tab);
+#define TROW(j) lds.tab[(j) * 64u + lane]
+#define TBYTE(base, i) tab8[(((base) + ((i) >> 2)) << 8) | lane4 | ((i) & 3u)]
+    auto lit_at = [&](const uint32_t bits) -> uint32_t {
+        if constexpr (!DYN) return lds.lit[bits & 511u];
+        else {
+            uint32_t len, idx; bool valid;
+            x_decode<15>(XL, bits, len, idx, valid);
+            idx = min(idx, 287u);
+            const uint32_t sym = (uint32_t)TBYTE(T_LS8, idx) | (((TROW(T_LBIT + (idx >> 5)) >> (idx & 31u)) & 1u) << 8);
+            const uint32_t type = sym < 256u ? T_LIT : sym == 256u ? T_EOB : sym <= 285u ? T_LEN : T_BAD;
+            uint32_t lbase, leb;
+            length_info(sym - 257u, lbase, leb);
+            const uint32_t nb = (!valid || (fixedblk && sym == 287u)) ? 0u : len;     // deflate.py:212,:1437-1439
+            return nb | (sym << 4) | (type << 13) | ((lbase & 0x1FFu) << 16) | ((leb & 7u) << 25);
+        }
+    };
+    auto dst_at = [&](const uint32_t bits, uint32_t& nbits) -> uint32_t {
+        if constexpr (!DYN) { nbits = 5u; return lds.dst[bits & 31u]; }
+        else {
+            uint32_t idx; bool valid;
+            x_decode<15>(XD, bits, nbits, idx, valid);
+            const uint32_t ds = TBYTE(T_DS8, min(idx, 31u));
+            uint32_t dbase, deb;
+            dist_info(ds, dbase, deb);
+            return !valid ? NO_DCODE : ds >= 30u ? BAD_DCODE : (dbase | (deb << 16));
+        }
+    };
+    // ---- DYN: restart the bit reader at an absolute bit position (the second pass over a block header)
+#define TOK_RESYNC(bitp) do {                                                                           \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* no LDS-DMA may land in the slot after this */ \
+        ip = (bitp) >> 3; sbase = ip;                                                                      \
+        for (uint32_t k_ = 0; k_ < SLOT_DW; k_++) inq[lane * SLOT_DW + k_] = load32(z, sbase + 4u * k_, zn); \
+        myissue = issued - 1000u;                                                                          \
+        bb = 0; bc = 0;                                                                                    \
+        TOK_REFILL();                                                                                      \
+        bb >>= ((bitp) & 7u); bc -= ((bitp) & 7u);                                                         \
+    } while (0)
+    // ---- DYN: the tables of a block, fixed (hm = 1: deflate.py:1066-1073) or dynamic (hm = 2: BL/READBL/REPEAT deflate.py:1084-1202,
+    // the canonical codes :1204-1400).  Returns the status; the acceptance rules are k_inflate_dyn's (zlib's).
+    auto build_tables = [&](const uint32_t hm) -> uint32_t {
+        if constexpr (!DYN) return HDLZ_E_DYNAMIC_UNSUPPORTED;
+        else {
+            for (uint32_t k = 0; k < 9u; k++) TROW(T_LBIT + k) = 0u;
+            for (uint32_t k = 0; k < 16u; k++) TROW(T_CNT + k) = 0u;
+            uint32_t nlen = 288u, ndist = 32u, p0 = 0u;
+            uint32_t XC[7];
+            // pass 1 (place = false) counts the symbols per code length, pass 2 puts every symbol into its slot of the sorted lists
+            auto lens_pass = [&](auto place) -> uint32_t {
+                const uint32_t total = nlen + ndist;
+                uint32_t idx = 0, prev = 0;
+                bool has256 = false;
+                while (idx < total) {
+                    TOK_REFILL();
+                    uint32_t len, ci; bool valid;
+                    x_decode<7>(XC, (uint32_t)bb, len, ci, valid);
+                    if (!valid) return HDLZ_E_BAD_TREE;
+                    const uint32_t sym = TBYTE(T_CS8, min(ci, 18u));
+                    const uint32_t eb = sym < 16u ? 0u : sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+                    const uint32_t ev = (uint32_t)(bb >> len) & ((1u << eb) - 1u);
+                    const uint32_t rep = sym < 16u ? 1u : sym == 18u ? 11u + ev : 3u + ev;
+                    bb >>= (len + eb); bc -= len + eb;
+                    if (sym == 16u && idx == 0u) return HDLZ_E_BAD_TREE;
+                    if (idx + rep > total) return HDLZ_E_BAD_TREE;
+                    const uint32_t val = sym < 16u ? sym : sym == 16u ? prev : 0u;
+                    // (a repeat may run from the literal/length lengths into the distance lengths)
+                    const uint32_t nl = idx < nlen ? min(rep, nlen - idx) : 0u, nd = rep - nl;
+                    const uint32_t sh = 16u * (val & 1u);
+                    if constexpr (!decltype(place)::value) {
+                        if (nl) atomicAdd(&TROW(T_CNT + (val >> 1)), nl << sh);
+                        if (nd) atomicAdd(&TROW(T_CNT + 8u + (val >> 1)), nd << sh);
+                        has256 = has256 || (val != 0u && idx <= 256u && idx + rep > 256u);
+                    } else if (val != 0u) {
+                        if (nl) {
+                            const uint32_t pos = (atomicAdd(&TROW(T_CNT + (val >> 1)), nl << sh) >> sh) & 0xFFFFu;
+                            for (uint32_t k = 0; k < nl; k++) {
+                                const uint32_t s_ = idx + k, q = pos + k;
+                                TBYTE(T_LS8, q) = (uint8_t)s_;
+                                if (s_ >= 256u) atomicOr(&TROW(T_LBIT + (q >> 5)), 1u << (q & 31u));
+                            }
+                        }
+                        if (nd) {
+                            const uint32_t pos = (atomicAdd(&TROW(T_CNT + 8u + (val >> 1)), nd << sh) >> sh) & 0xFFFFu;
+                            for (uint32_t k = 0; k < nd; k++) TBYTE(T_DS8, pos + k) = (uint8_t)(idx + nl + k - nlen);
+                        }
+                    }
+                    prev = val;
+                    idx += rep;
+                }
+                if constexpr (!decltype(place)::value) { if (!has256) return HDLZ_E_BAD_TREE; }      // no end-of-block code
+                return HDLZ_OK;
+            };
+            if (hm == 1u) {
+                // 24 codes of 7 bits (256..279), 152 of 8 (0..143, 280..287), 112 of 9 (144..255); 32 distance codes of 5 bits
+                TROW(T_CNT + 3u) = 24u << 16; TROW(T_CNT + 4u) = 152u | (112u << 16); TROW(T_CNT + 8u + 2u) = 32u << 16;
+                for (uint32_t q = 0; q < 288u; q++) {
+                    const uint32_t s_ = q < 24u ? 256u + q : q < 168u ? q - 24u : q < 176u ? q + 112u : q - 32u;
+                    TBYTE(T_LS8, q) = (uint8_t)s_;
+                    if (s_ >= 256u) atomicOr(&TROW(T_LBIT + (q >> 5)), 1u << (q & 31u));
+                }
+                for (uint32_t q = 0; q < 32u; q++) TBYTE(T_DS8, q) = (uint8_t)q;
+            } else {
+                // BL (deflate.py:1090-1114)
+                TOK_REFILL();
+                nlen = ((uint32_t)bb & 31u) + 257u;
+                ndist = ((uint32_t)(bb >> 5) & 31u) + 1u;
+                const uint32_t ncode = ((uint32_t)(bb >> 10) & 15u) + 4u;
+                bb >>= 14; bc -= 14u;
+                if (nlen > 286u || ndist > 30u) return HDLZ_E_BAD_TREE;
+                // the code-length code: 3-bit lengths in the order of RFC1951 3.2.7, kept as 3-bit fields by symbol
+                constexpr uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                uint64_t cl = 0;
+#pragma unroll
+                for (int i = 0; i < 19; i++) {
+                    if ((i & 7) == 0) TOK_REFILL();
+                    if ((uint32_t)i < ncode) { cl |= (uint64_t)((uint32_t)bb & 7u) << (3 * order[i]); bb >>= 3; bc -= 3u; }
+                }
+                uint64_t cw = 0;                       // symbols per length, 5-bit fields
+#pragma unroll
+                for (int s_ = 0; s_ < 19; s_++) cw += 1ull << (5u * ((uint32_t)(cl >> (3 * s_)) & 7u));
+                int32_t left; uint32_t cum;
+                x_build<7>(XC, [&](int l) { return (uint32_t)(cw >> (5 * l)) & 31u; }, left, cum);
+                if (left != 0) return HDLZ_E_BAD_TREE;
+                uint64_t ow = 0;                       // first slot per length in the sorted list, then the next free one
+                {
+                    uint32_t off = 0;
+#pragma unroll
+                    for (int l = 1; l < 8; l++) { ow |= (uint64_t)off << (5 * l); off += (uint32_t)(cw >> (5 * l)) & 31u; }
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 19; s_++) {
+                    const uint32_t l5 = 5u * ((uint32_t)(cl >> (3 * s_)) & 7u);
+                    if (l5) { TBYTE(T_CS8, (uint32_t)(ow >> l5) & 31u) = (uint8_t)s_; ow += 1ull << l5; }
+                }
+                p0 = TOK_BITPOS();
+                const uint32_t st1 = lens_pass(std::false_type{});
+                if (st1 != HDLZ_OK) return st1;
+            }
+            int32_t l1, l2; uint32_t c1, c2;
+            x_build<15>(XL, [&](int l) { return (TROW(T_CNT + (uint32_t)(l >> 1)) >> (16 * (l & 1))) & 0xFFFFu; }, l1, c1);
+            x_build<15>(XD, [&](int l) { return (TROW(T_CNT + 8u + (uint32_t)(l >> 1)) >> (16 * (l & 1))) & 0xFFFFu; }, l2, c2);
+            if (hm == 2u) {
+                // incomplete sets only with a single code -- or, for the distance code, with none at all (RFC1951 3.2.7)
+                if (l1 < 0 || (l1 > 0 && c1 != 1u)) return HDLZ_E_BAD_TREE;
+                if (l2 < 0 || (l2 > 0 && c2 > 1u)) return HDLZ_E_BAD_TREE;
+#pragma unroll
+                for (uint32_t w = 0; w < 2u; w++) {    // counts -> first slot per length
+                    uint32_t off = 0, row = 0;
+#pragma unroll
+                    for (uint32_t l = 1; l < 16u; l++) {
+                        const uint32_t c = (TROW(T_CNT + 8u * w + (l >> 1)) >> (16u * (l & 1u))) & 0xFFFFu;
+                        if (l & 1u) { TROW(T_CNT + 8u * w + (l >> 1)) = row | (off << 16); row = 0; }
+                        else row = off;
+                        off += c;
+                    }
+                }
+                TOK_RESYNC(p0);
+                lens_pass(std::true_type{});
+                if ((int32_t)(TOK_BITPOS() >> 3) > isize - 3) return HDLZ_E_NO_EOF;
+            }
+            return HDLZ_OK;
+        }
+    };
 
     if (active) { TOK_REQUEST(issued + 1u); }
     if (__ballot(active && sbase + 16u <= zn) != 0ull) issued += 1u;
@@ -286,27 +521,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
             if (!slow && in_ok) {
                 uint32_t nl = 0;
 #pragma unroll
-                for (uint32_t extra = 0; extra < 3u; extra++) {    // (the third look-up still has 33 - 9 - 9 = 15 valid bits)
-                    const uint32_t e2 = lds.lit[(uint32_t)bb & 511u];
-                    if (nl == extra && ((e2 >> 13) & 3u) == (uint32_t)T_LIT && o + extra < cap) {
+                for (uint32_t extra = 0; extra < 3u; extra++) {    // (the third look-up still has 33 - 9 - 9 = 15 valid bits;
+                    const uint32_t e2 = lit_at((uint32_t)bb);      //  DYN: codes of up to 15 bits, taken while a bit is left behind)
+                    if (nl == extra && ((e2 >> 13) & 3u) == (uint32_t)T_LIT && o + extra < cap && (!DYN || (e2 & 15u) < bc)) {
                         litv = extra == 0u ? ((e2 >> 4) & 0xFFu) : (litv | (((e2 >> 4) & 0xFFu) << (8u * extra)));
                         nl = extra + 1u;
                         bb >>= (e2 & 15u); bc -= (e2 & 15u);
                     }
                 }
                 litn = nl;
-                const uint32_t e = lds.lit[(uint32_t)bb & 511u];
+                const uint32_t e = lit_at((uint32_t)bb);
                 const uint32_t nb = e & 15u, type = (e >> 13) & 3u;
                 const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;
                 uint64_t x = bb >> nb;
                 const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));
                 x >>= leb;
-                const uint32_t de = lds.dst[(uint32_t)x & 31u];
+                uint32_t dnb;
+                const uint32_t de = dst_at((uint32_t)x, dnb);
                 const uint32_t deb = (de >> 16) & 15u;
-                const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> 5) & ((1u << deb) - 1u));
-                const uint32_t mbits = nb + leb + 5u + deb;
+                const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> dnb) & ((1u << deb) - 1u));
+                const uint32_t mbits = nb + leb + dnb + deb;
                 const uint32_t om = o + nl;                        // where the copy will start
-                const bool len_ok = (type == (uint32_t)T_LEN) & (mbits < bc) & (de != 0xFFFFFFFFu) & (distance <= om) &
+                const bool len_ok = (type == (uint32_t)T_LEN) & (mbits < bc) & (de < NO_DCODE) & (distance <= om) &
                                     (distance <= obsize) & (om + tlength <= cap);
                 if (len_ok) {
                     bb >>= mbits; bc -= mbits;
@@ -331,7 +567,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
                     final_ = ((uint32_t)bb & 1u) | oneblock;
                     const uint32_t hm = assume_fixed ? 1u : ((uint32_t)(bb >> 1) & 3u);
                     if (hm == 3u) { TOK_FAIL(HDLZ_E_BAD_BTYPE); break; }
-                    if (hm == 2u) { TOK_FAIL(HDLZ_E_DYNAMIC_UNSUPPORTED); break; }
+                    if (!DYN && hm == 2u) { TOK_FAIL(HDLZ_E_DYNAMIC_UNSUPPORTED); break; }
                     need_header = false;
                     if (hm == 0u) {
                         // stored (deflate.py:709-717): LEN sits `skip` bits after the header start
@@ -351,11 +587,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
                         }
                     } else {
                         bb >>= 3; bc -= 3u;
+                        if constexpr (DYN) {
+                            const uint32_t tst = build_tables(hm);
+                            if (tst != HDLZ_OK) { TOK_FAIL(tst); break; }
+                            fixedblk = hm == 1u;
+                        }
                     }
                     continue;
                 }
-                // NEXT (deflate.py:1409-1445)
-                const uint32_t e = lds.lit[(uint32_t)bb & 511u];
+                // NEXT (deflate.py:1409-1445; DYN: D_NEXT :1447-1517 for the distance)
+                const uint32_t e = lit_at((uint32_t)bb);
                 const uint32_t nb = e & 15u, code = (e >> 4) & 0x1FFu;
                 if (nb < 1u) { TOK_FAIL(HDLZ_E_BAD_SYMBOL); break; }
                 bb >>= nb; bc -= nb;
@@ -373,17 +614,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
                 }
                 const uint32_t token = code - 257u;
                 if (token >= 29u) { TOK_FAIL(HDLZ_E_BAD_SYMBOL); break; }
-                uint32_t lbase, leb, dbase, deb;
+                uint32_t lbase, leb, dnb;
                 length_info(token, lbase, leb);
                 const uint32_t tlength = lbase + ((uint32_t)bb & ((1u << leb) - 1u));
-                bb >>= leb;
-                const uint32_t dc = rev((uint32_t)bb & 31u, 5);
-                bb >>= 5;
-                if (dc >= 30u) { TOK_FAIL(HDLZ_E_BAD_DISTANCE); break; }
-                dist_info(dc, dbase, deb);
-                const uint32_t distance = dbase + ((uint32_t)bb & ((1u << deb) - 1u));
+                bb >>= leb; bc -= leb;
+                if constexpr (DYN) TOK_REFILL();                   // 15 + 5 bits are gone, 15 + 13 may follow
+                const uint32_t de = dst_at((uint32_t)bb, dnb);
+                if (de == NO_DCODE) { TOK_FAIL(HDLZ_E_BAD_SYMBOL); break; }
+                if (de == BAD_DCODE) { TOK_FAIL(HDLZ_E_BAD_DISTANCE); break; }
+                bb >>= dnb;
+                const uint32_t deb = (de >> 16) & 15u;
+                const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)bb & ((1u << deb) - 1u));
                 bb >>= deb;
-                bc -= leb + 5u + deb;
+                bc -= dnb + deb;
                 if (distance > o || distance > obsize) { TOK_FAIL(HDLZ_E_BAD_DISTANCE); break; }        // D8
                 if ((int32_t)(TOK_BITPOS() >> 3) >= isize - 2) { TOK_FAIL(HDLZ_E_NO_EOF); break; }      // COPY hold, :1600
                 if ((uint64_t)o + tlength > cap) { TOK_FAIL(HDLZ_E_OUT_CAPACITY); break; }
@@ -421,6 +664,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
         for (uint32_t q = 0; q < CHUNK / 4u; q++) d32[q] = rp[q * 64u];
         flushed += CHUNK;
     }
+#undef TROW
+#undef TBYTE
+#undef TOK_RESYNC
 #undef TOK_FAIL
 #undef TOK_BITPOS
 #undef TOK_REFILL
@@ -439,14 +685,51 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_tok(InflateArgs a) {
     }
 }
 
+// the streams pass 1 flagged HDLZ_E_DYNAMIC_UNSUPPORTED, as a dense list: the lanes of k_inflate_tok<true> are then all busy whatever
+// the share of such streams is (list[0 .. *n) in no particular order: the streams are independent)
+__global__ __launch_bounds__(256) void k_collect_dyn(const uint32_t* __restrict__ status, uint64_t nstreams, uint32_t* __restrict__ list,
+                                                      uint32_t* __restrict__ n) {
+    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const bool mine = gid < nstreams && status[gid] == HDLZ_E_DYNAMIC_UNSUPPORTED;
+    const uint64_t m = __ballot(mine);
+    if (m == 0ull) return;
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(n, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+    if (mine) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)gid;
+}
+
 }  // namespace tok
 
 hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
     if (a.nstreams == 0) return hipSuccess;
-    const uint64_t per_wg = 64u * tok::WAVES;
-    const dim3 grid((unsigned)((a.nstreams + per_wg - 1u) / per_wg)), block(64 * tok::WAVES);
-    hipLaunchKernelGGL(tok::k_inflate_tok, grid, block, 0, stream, a);
+    const uint64_t per_wg = 64u * tok::Lds<false>::WAVES;
+    const dim3 grid((unsigned)((a.nstreams + per_wg - 1u) / per_wg)), block(64 * tok::Lds<false>::WAVES);
+    hipLaunchKernelGGL(tok::k_inflate_tok<false>, grid, block, 0, stream, a, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     return hipGetLastError();
+}
+
+// second pass of the lane-per-stream mapping: the streams with dynamic-tree blocks, one lane each again.  `all`: every stream
+// is decoded here (no first pass, no list).  The list lives in stream-ordered scratch memory (4 bytes per stream).
+hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool all) {
+    if (a.nstreams == 0 || (a.flags & HDLZ_INFLATE_ASSUME_FIXED)) return hipSuccess;
+    const dim3 grid((unsigned)((a.nstreams + 63u) / 64u)), block(64);
+    if (all) {
+        hipLaunchKernelGGL(tok::k_inflate_tok<true>, grid, block, 0, stream, a, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+        return hipGetLastError();
+    }
+    uint32_t* ws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * (a.nstreams + 1u), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws, 0, sizeof(uint32_t), stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(tok::k_collect_dyn, dim3((unsigned)((a.nstreams + 255u) / 256u)), dim3(256), 0, stream, a.status, a.nstreams,
+                           ws + 1, ws);
+        hipLaunchKernelGGL(tok::k_inflate_tok<true>, grid, block, 0, stream, a, (const uint32_t*)(ws + 1), (const uint32_t*)ws);
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
 }
 
 }  // namespace hdlz
