@@ -47,6 +47,11 @@ constexpr uint32_t SLOT_DW = 4;               // input dwords fetched per lane a
 #define HDLZ_TOK_MOVES 4
 #endif
 constexpr uint32_t MOVES = HDLZ_TOK_MOVES;    // move iterations (4 bytes per lane each) per round
+#ifdef HDLZ_TOK_MARKS                         // tools/phase_count.py --src hdlz_inflate_tok.hip -DHDLZ_TOK_MARKS: static counts per part
+#define TOK_MARK(name) asm volatile("; @@PHASE " name ::: "memory")
+#else
+#define TOK_MARK(name) do {} while (0)
+#endif
 
 // DYN: per-lane tables, rows of 64 dwords (row j of lane l = dword j * 64 + l: every lane stays in its own bank)
 constexpr uint32_t T_LS8 = 0;                 // 288 bytes: the low 8 bits of the literal/length symbols, sorted by (code length, value)
@@ -68,6 +73,8 @@ struct __attribute__((aligned(16))) Lds {
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(1))) u128_unaligned { uint64_t lo, hi; };
 
 __device__ __forceinline__ uint32_t rev(uint32_t v, uint32_t nbits) { return __builtin_bitreverse32(v) >> (32u - nbits); }
 
@@ -197,7 +204,6 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     const uint32_t len_mask = a.obsize ? ((1u << (31u - (uint32_t)__builtin_clz(a.obsize))) - 1u) : 0xFFFFu;   // deflate.py:329,:714
     const bool assume_fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) != 0;
     const uint32_t oneblock = (a.flags & HDLZ_INFLATE_ONEBLOCK) ? 1u : 0u;
-    const bool out16 = ((reinterpret_cast<uintptr_t>(a.out) | a.out_pitch) & 15u) == 0;
     const int32_t isize = (int32_t)zn - 1;            // deflate.py:605
 
     uint32_t status = HDLZ_OK;
@@ -250,12 +256,12 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 const uint32_t* rp_ = &lds.ring[wave][((flushed & (RINGB - 1u)) >> 2) * 64u + lane];       \
                 uint8_t* dp_ = out + flushed;                                                              \
                 _Pragma("unroll") for (uint32_t q_ = 0; q_ < CHUNK / 16u; q_++) {                          \
-                    uint4 v_;                                                                              \
+                    u32x4 v_;                                                                              \
                     v_.x = rp_[(4u * q_) * 64u]; v_.y = rp_[(4u * q_ + 1u) * 64u];                         \
                     v_.z = rp_[(4u * q_ + 2u) * 64u]; v_.w = rp_[(4u * q_ + 3u) * 64u];                    \
-                    if (out16) *reinterpret_cast<uint4*>(dp_ + 16u * q_) = v_;                             \
-                    else { uint32_t* d32_ = reinterpret_cast<uint32_t*>(dp_ + 16u * q_);                   \
-                           d32_[0] = v_.x; d32_[1] = v_.y; d32_[2] = v_.z; d32_[3] = v_.w; }               \
+                    /* one 16-byte store whatever the alignment (d_out / out_pitch are 4-byte aligned, gfx950 needs no more): */ \
+                    /* written as `aligned ? x4 : 4 x dword` hipcc merged the two branches into TEN stores per line (TA 80 % busy) */ \
+                    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dp_ + 16u * q_), "v"(v_) : "memory");     \
                 }                                                                                          \
                 flushed += CHUNK;                                                                          \
             }                                                                                              \
@@ -437,6 +443,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     if (__ballot(active && sbase + 16u <= zn) != 0ull) issued += 1u;
 
     for (;;) {
+        TOK_MARK("move");
         // ------------------------------------------------------------ 0. move the bytes of the tokens decoded in the PREVIOUS round: up to
         // four per lane and iteration.  (Moving first, decoding after: the far history a token needs was requested when it was
         // decoded, a whole round ago -- waiting for it right after the decode left 67 % of the wave cycles in s_waitcnt.)
@@ -482,6 +489,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
             }
             TOK_FLUSH();
         }
+        TOK_MARK("refill");
         // ------------------------------------------------------------ 0b. input refill (a lane waits only when it opens a new slot)
         {
             const bool need = active && bc <= 32u;
@@ -508,6 +516,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 }
             }
         }
+        TOK_MARK("decode");
         // ------------------------------------------------------------ 1a. fast path: up to three literals and then a match, inside a
         // fixed block.  (One token per round made the literal-heavy streams the lanes the whole wave waits for: 362 -> 390 GB/s with
         // literal triples, more with the match behind them.)
@@ -519,6 +528,67 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
             // :1600 before the copy) are guaranteed to pass -- anything closer to the end goes the slow way
             const bool in_ok = ip + 3u <= zn;
             if (!slow && in_ok) {
+              if constexpr (DYN) {
+                // four symbols at once: the LENGTH of a code needs no table (x_decode), so the bit offsets of the next three
+                // symbols are known before a look-up returns -- the four look-ups are in flight together (one LDS round trip
+                // instead of four: this kernel runs one wave per SIMD, nothing else hides them).  Symbols behind a non-literal
+                // are simply not used.
+                uint32_t ln[4], ix[4], of[4], sy[4];
+                bool vd[4];
+                uint32_t off = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    of[k] = off;
+                    x_decode<15>(XL, (uint32_t)(bb >> off), ln[k], ix[k], vd[k]);
+                    off += ln[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i_ = min(ix[k], 287u);
+                    sy[k] = (uint32_t)TBYTE(T_LS8, i_) | (((TROW(T_LBIT + (i_ >> 5)) >> (i_ & 31u)) & 1u) << 8);
+                }
+                bool lt[3];                                        // a literal is taken while a buffered bit is left behind it
+#pragma unroll
+                for (int k = 0; k < 3; k++) lt[k] = vd[k] && sy[k] < 256u && of[k] + ln[k] < bc && o + (uint32_t)k < cap;
+                const uint32_t nl = !lt[0] ? 0u : !lt[1] ? 1u : !lt[2] ? 2u : 3u;
+                litv = (sy[0] & 255u) | ((sy[1] & 255u) << 8) | ((sy[2] & 255u) << 16);     // (bytes behind the nl-th are never used)
+                litn = nl;
+                // the token behind the literals
+                const uint32_t tsy = nl == 0u ? sy[0] : nl == 1u ? sy[1] : nl == 2u ? sy[2] : sy[3];
+                const uint32_t tof = nl == 0u ? 0u : nl == 1u ? of[1] : nl == 2u ? of[2] : of[3];
+                const uint32_t tln = nl == 0u ? ln[0] : nl == 1u ? ln[1] : nl == 2u ? ln[2] : ln[3];
+                const bool tvd = nl == 0u ? vd[0] : nl == 1u ? vd[1] : nl == 2u ? vd[2] : vd[3];
+                const uint32_t token = tsy - 257u;
+                uint32_t lbase, leb;
+                length_info(token, lbase, leb);
+                leb &= 7u;
+                uint64_t x = bb >> (tof + tln);
+                const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));
+                x >>= leb;
+                uint32_t dnb, dix; bool dvd;
+                x_decode<15>(XD, (uint32_t)x, dnb, dix, dvd);
+                const uint32_t ds = TBYTE(T_DS8, min(dix, 31u));
+                uint32_t dbase, deb;
+                dist_info(ds, dbase, deb);
+                deb &= 15u;
+                const uint32_t distance = dbase + ((uint32_t)(x >> dnb) & ((1u << deb) - 1u));
+                const uint32_t mbits = tof + tln + leb + dnb + deb;
+                const uint32_t om = o + nl;                        // where the copy will start
+                const bool len_ok = tvd & (token < 29u) & dvd & (ds < 30u) & (mbits < bc) & (distance <= om) & (distance <= obsize) &
+                                    (om + tlength <= cap);
+                const uint32_t take = len_ok ? mbits : tof;
+                bb >>= take; bc -= take;
+                if (len_ok) {
+                    rem = tlength; dist = distance;
+                    if (distance > NEAR) {
+                        // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 < om - 96 <= flushed)
+                        const u128_unaligned f16 = *reinterpret_cast<const u128_unaligned*>(out + (om - distance));
+                        fpre = f16.lo; fpre2 = f16.hi;
+                    }
+                } else if (nl == 0u) {
+                    slow = true;                                    // EOB, invalid data, any failing check
+                }
+              } else {
                 uint32_t nl = 0;
 #pragma unroll
                 for (uint32_t extra = 0; extra < 3u; extra++) {    // (the third look-up still has 33 - 9 - 9 = 15 valid bits;
@@ -548,16 +618,19 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                     bb >>= mbits; bc -= mbits;
                     rem = tlength; dist = distance;
                     if (distance > NEAR) {
-                        fpre = *reinterpret_cast<const u64_unaligned*>(out + (om - distance));
-                        if (tlength > 8u) fpre2 = *reinterpret_cast<const u64_unaligned*>(out + (om - distance) + 8u);
+                        // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 < om - 96 <= flushed)
+                        const u128_unaligned f16 = *reinterpret_cast<const u128_unaligned*>(out + (om - distance));
+                        fpre = f16.lo; fpre2 = f16.hi;
                     }
                 } else if (nl == 0u) {
                     slow = true;                                    // EOB, invalid data, any failing check
                 }
+              }
             } else {
                 slow = true;                                        // header, end of the input
             }
         }
+        TOK_MARK("slow");
         // ------------------------------------------------------------ 1b. slow path (wave-uniform branch, rare)
         if (__ballot(slow || (active && srem != 0u)) != 0ull) {
             while (slow && active && rem == 0u && srem == 0u && litn == 0u) {
@@ -633,8 +706,8 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 rem = tlength;
                 dist = distance;
                 if (distance > NEAR) {
-                    fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
-                    if (tlength > 8u) fpre2 = *reinterpret_cast<const u64_unaligned*>(out + (o - distance) + 8u);
+                    const u128_unaligned f16 = *reinterpret_cast<const u128_unaligned*>(out + (o - distance));
+                    fpre = f16.lo; fpre2 = f16.hi;
                 }
             }
             // stored COPY (deflate.py:1603-1616): one byte per round (rare: level-0 streams, incompressible blocks)
@@ -654,8 +727,10 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 }
             }
         }
+        TOK_MARK("loopend");
         if (__ballot(active || rem != 0u || litn != 0u) == 0ull) break;
     }
+    TOK_MARK("epilogue");
     // the lines completed since the last batch
     if (exists && (o - flushed) >= CHUNK) {
         const uint32_t* rp = &lds.ring[wave][((flushed & (RINGB - 1u)) >> 2) * 64u + lane];

@@ -3,7 +3,8 @@
 `; @@PHASE name` marks (HDLZ_MARK in hdlz_compress.hip).  The tile body is straight-line code executed once per tile,
 so static counts = dynamic counts per wave-tile; issue cycles are priced with the measured table of
 tools/ubench/valu_rate*.hip (2.8 cycles for v_add/sub/and/or/xor/lshr/mov, 4.25 for every other VALU op, @2.4 GHz).
-Usage: tools/phase_count.py [-DNAME ...] [--kernel MANGLED_SUBSTR]"""
+Usage: tools/phase_count.py [-DNAME ...] [--kernel MANGLED_SUBSTR] [--src FILE.hip]
+(k_inflate_tok: --src hdlz_inflate_tok.hip -DHDLZ_TOK_MARKS --kernel k_inflate_tokILb1E -- parts of the round loop, branches counted once)"""
 import collections
 import re
 import subprocess
@@ -13,12 +14,15 @@ FAST = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xo
         "v_add_co_u32", "v_not_b32")
 defs = [a for a in sys.argv[1:] if a.startswith("-D")]
 kern = "k_compressILi1ELb1ELb1E"
+srcname = "hdlz_compress.hip"
 for i, a in enumerate(sys.argv):
     if a == "--kernel":
         kern = sys.argv[i + 1]
+    if a == "--src":
+        srcname = sys.argv[i + 1]
 import os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "hdl_deflate_amd/csrc/hdlz_compress.hip")
+src = os.path.join(root, "hdl_deflate_amd/csrc", srcname)
 asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-", src] + defs,
                      capture_output=True, text=True).stdout
 m = re.search(r"^(_ZN4hdlz\w*%s\w*):[^\n]*\n(.*?)s_endpgm" % re.escape(kern), asm, re.S | re.M)

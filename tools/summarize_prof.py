@@ -23,7 +23,7 @@ for f in find("trace", "*kernel_stats.csv"):
         print("%-90s calls=%s total_ns=%s avg_ns=%s pct=%s" % (
             name, r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 
-for sub in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
+for sub in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write", "pmc_m1", "pmc_m2", "pmc_m3", "pmc_m4"):
     for f in find(sub, "*counter_collection.csv"):
         acc = defaultdict(lambda: defaultdict(list))
         meta = {}
