@@ -24,6 +24,8 @@
 
 namespace hdlz {
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
 constexpr uint32_t RING_BYTES = 64;           // history kept in LDS per stream = one flush chunk (4 KiB per wave).
                                               // Occupancy is what matters here: measured 110 / 150 / 202 GB/s for 256 / 128 / 64
 constexpr uint32_t RING_DW = RING_BYTES / 4;  // dwords per lane
@@ -144,7 +146,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
     const uint32_t len_mask = a.obsize ? ((1u << (31u - (uint32_t)__builtin_clz(a.obsize))) - 1u) : 0xFFFFu;
     const bool assume_fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) != 0;
     const uint32_t oneblock = (a.flags & HDLZ_INFLATE_ONEBLOCK) ? 1u : 0u;       // deflate.py:678,:1542,:1617
-    const bool out16 = ((reinterpret_cast<uintptr_t>(a.out) | a.out_pitch) & 15u) == 0;
     const int32_t isize = (int32_t)zn - 1;            // deflate.py:605
 
     uint32_t status = HDLZ_OK;
@@ -374,18 +375,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
                 const uint32_t s = (lane >> 2) + 16u * r;               // stream (lane index) this lane copies for
                 if ((live >> s) & 1ull) {
                     const uint32_t* src = &lds.ring[wave][(w0 + 4u * q) * 64u + s];
-                    uint4 v;
+                    u32x4_t v;
                     v.x = src[0]; v.y = src[64]; v.z = src[128]; v.w = src[192];
                     uint8_t* dst = a.out + (sid0 + s) * a.out_pitch + c0 + 16u * q;
-                    if (out16) {
-                        *reinterpret_cast<uint4*>(dst) = v;
-                    } else {
-                        uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
-                        d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
-                    }
+                    // one 16-byte store whatever the alignment (4 bytes is all gfx950 asks for): written as `aligned ? x4 : 4 x dword`
+                    // hipcc merged the two branches into a dwordx3 + dword pair (see hdlz_inflate_tok.hip; s_nop: store-data hazard)
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
                 }
             }
-            // later far copies (distance > 256) read these bytes back through L1/L2
+            // later far copies (distance > 256) read these bytes back through L1/L2 (the stores above are asm: the compiler does
+            // not count them, the release fence would not wait for them)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }

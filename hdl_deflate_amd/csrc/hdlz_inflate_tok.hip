@@ -43,8 +43,12 @@ constexpr uint32_t CHUNK = RINGB >= 128u ? 64u : RINGB / 2u;   // bytes per flus
 constexpr uint32_t URGENT = RINGB - 44;       // a lane with this many unflushed bytes forces a flush (+3 per move, +8 written ahead,
                                               // and the far prefetch reads 24 bytes from o - dist on: they must be flushed)
 constexpr uint32_t SLOT_DW = 4;               // input dwords fetched per lane and refill
+#ifndef HDLZ_TOK_BATCH
+#define HDLZ_TOK_BATCH 16
+#endif
+constexpr uint32_t BATCH = HDLZ_TOK_BATCH;    // lanes with a complete line that start a flush
 #ifndef HDLZ_TOK_MOVES
-#define HDLZ_TOK_MOVES 4
+#define HDLZ_TOK_MOVES 3
 #endif
 constexpr uint32_t MOVES = HDLZ_TOK_MOVES;    // move iterations (4 bytes per lane each) per round
 #ifdef HDLZ_TOK_MARKS                         // tools/phase_count.py --src hdlz_inflate_tok.hip -DHDLZ_TOK_MARKS: static counts per part
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
 #define TOK_FLUSH() do {                                                                                \
         const bool ready_ = exists && (o - flushed) >= CHUNK;                                              \
         const uint64_t rm_ = __ballot(ready_);                                                             \
-        if (rm_ != 0ull && (__popcll(rm_) >= 16 || __ballot(exists && (o - flushed) >= URGENT) != 0ull)) { \
+        if (rm_ != 0ull && (__popcll(rm_) >= (int)BATCH || __ballot(exists && (o - flushed) >= URGENT) != 0ull)) { \
             if (ready_) {                                                                                  \
                 const uint32_t* rp_ = &lds.ring[wave][((flushed & (RINGB - 1u)) >> 2) * 64u + lane];       \
                 uint8_t* dp_ = out + flushed;                                                              \
@@ -260,8 +264,10 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                     v_.x = rp_[(4u * q_) * 64u]; v_.y = rp_[(4u * q_ + 1u) * 64u];                         \
                     v_.z = rp_[(4u * q_ + 2u) * 64u]; v_.w = rp_[(4u * q_ + 3u) * 64u];                    \
                     /* one 16-byte store whatever the alignment (d_out / out_pitch are 4-byte aligned, gfx950 needs no more): */ \
-                    /* written as `aligned ? x4 : 4 x dword` hipcc merged the two branches into TEN stores per line (TA 80 % busy) */ \
-                    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dp_ + 16u * q_), "v"(v_) : "memory");     \
+                    /* written as `aligned ? x4 : 4 x dword` hipcc merged the two branches into TEN stores per line (TA 80 % busy). */ \
+                    /* s_nop: the data registers of a store wider than 8 bytes must not be written in the next two wait states, and  */ \
+                    /* the hazard recognizer does not look into inline asm                                                            */ \
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dp_ + 16u * q_), "v"(v_) : "memory");     \
                 }                                                                                          \
                 flushed += CHUNK;                                                                          \
             }                                                                                              \
