@@ -153,9 +153,13 @@ __device__ __forceinline__ void xwalk(const XCode& X, uint32_t bits15, uint32_t&
 // far runs out (the reference's `di >= isize - 4 and not i_mode == IDLE` stall, deflate.py:1529-1530) or the output limit
 // is reached (its `do >= i_raddr + OBSIZE` hold, deflate.py:1531-1534, :1597-1599), always stopping BETWEEN two tokens.
 template <bool STREAM>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_inflate_dyn(InflateArgs a, hdlz_istate* ist, uint32_t out_limit) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_inflate_dyn(InflateArgs a, hdlz_istate* ist, uint32_t out_limit, const uint32_t* few_n, uint32_t lane_min) {
     __shared__ DynLds L;
     const uint32_t lane = threadIdx.x;
+    // second pass of the lane mapping: this kernel takes the flagged streams only when they are few (*few_n of them, counted by
+    // k_collect_dyn) -- from `lane_min` (HDLZ_INFLATE_DYN_LANE_MIN; 0 with the explicit lane hint) on one lane per stream is
+    // faster (k_inflate_tok<true>)
+    if (!STREAM && few_n && *few_n >= lane_min) return;
     for (uint64_t sid = blockIdx.x; sid < a.nstreams; sid += gridDim.x) {
         if (!STREAM && !(a.flags & DYN_ALL) && a.status[sid] != HDLZ_E_DYNAMIC_UNSUPPORTED) continue;   // pass 1 finished this stream
         uint64_t off;
@@ -582,12 +586,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 
 // second pass after k_inflate (streams it flagged with HDLZ_E_DYNAMIC_UNSUPPORTED), or -- `all` -- the only pass
-hipError_t launch_inflate_dyn(const InflateArgs& a0, hipStream_t stream, bool all) {
+hipError_t launch_inflate_dyn(const InflateArgs& a0, hipStream_t stream, bool all, const uint32_t* few_n, uint32_t lane_min) {
     if (a0.nstreams == 0 || (!all && (a0.flags & HDLZ_INFLATE_ASSUME_FIXED))) return hipSuccess;
     InflateArgs a = a0;
     if (all) a.flags |= DYN_ALL;
     uint64_t g = a.nstreams < 65536u ? a.nstreams : 65536u;
-    hipLaunchKernelGGL(k_inflate_dyn<false>, dim3((unsigned)g), dim3(64), 0, stream, a, (hdlz_istate*)nullptr, 0u);
+    hipLaunchKernelGGL(k_inflate_dyn<false>, dim3((unsigned)g), dim3(64), 0, stream, a, (hdlz_istate*)nullptr, 0u, few_n, lane_min);
     return hipGetLastError();
 }
 
@@ -596,7 +600,8 @@ hipError_t launch_inflate_chunk(const uint8_t* in, uint32_t in_len, int final_, 
                                 uint64_t out_cap, uint32_t out_limit, void* state, hipStream_t stream) {
     InflateArgs a{in, nullptr, 0, in_len, 1, (flags & (HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_ONEBLOCK)) | DYN_ALL | (final_ ? DYN_FINAL : 0u),
                   obsize, out, out_cap, nullptr, nullptr};
-    hipLaunchKernelGGL(k_inflate_dyn<true>, dim3(1), dim3(64), 0, stream, a, static_cast<hdlz_istate*>(state), out_limit);
+    hipLaunchKernelGGL(k_inflate_dyn<true>, dim3(1), dim3(64), 0, stream, a, static_cast<hdlz_istate*>(state), out_limit,
+                       (const uint32_t*)nullptr, 0u);
     return hipGetLastError();
 }
 

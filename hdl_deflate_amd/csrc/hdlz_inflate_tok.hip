@@ -168,7 +168,7 @@ __device__ __forceinline__ void x_decode(const uint32_t (&X)[NL], uint32_t bits,
 
 template <bool DYN>
 __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, const uint32_t* __restrict__ list,
-                                                                const uint32_t* __restrict__ list_n) {
+                                                                const uint32_t* __restrict__ list_n, uint32_t lane_min) {
     constexpr uint32_t WAVES = Lds<DYN>::WAVES;
     __shared__ Lds<DYN> lds;
     const uint32_t lane = threadIdx.x & 63u;
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     bool exists = gid < a.nstreams;
     if constexpr (DYN) {
         if (list) {
+            if (*list_n < lane_min) return;                        // few such streams: k_inflate_dyn takes them, one wave each
             exists = gid < (uint64_t)*list_n;
             sid = exists ? (uint64_t)list[gid] : 0ull;
         }
@@ -786,7 +787,7 @@ hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
     if (a.nstreams == 0) return hipSuccess;
     const uint64_t per_wg = 64u * tok::Lds<false>::WAVES;
     const dim3 grid((unsigned)((a.nstreams + per_wg - 1u) / per_wg)), block(64 * tok::Lds<false>::WAVES);
-    hipLaunchKernelGGL(tok::k_inflate_tok<false>, grid, block, 0, stream, a, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(tok::k_inflate_tok<false>, grid, block, 0, stream, a, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
     return hipGetLastError();
 }
 
@@ -796,18 +797,21 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
     if (a.nstreams == 0 || (a.flags & HDLZ_INFLATE_ASSUME_FIXED)) return hipSuccess;
     const dim3 grid((unsigned)((a.nstreams + 63u) / 64u)), block(64);
     if (all) {
-        hipLaunchKernelGGL(tok::k_inflate_tok<true>, grid, block, 0, stream, a, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(tok::k_inflate_tok<true>, grid, block, 0, stream, a, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
         return hipGetLastError();
     }
     uint32_t* ws = nullptr;
+    // (the explicit lane hint keeps every such stream in the lane kernel)
+    const uint32_t lane_min = (a.flags & HDLZ_INFLATE_LANE_PER_STREAM) ? 0u : HDLZ_INFLATE_DYN_LANE_MIN;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * (a.nstreams + 1u), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws, 0, sizeof(uint32_t), stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(tok::k_collect_dyn, dim3((unsigned)((a.nstreams + 255u) / 256u)), dim3(256), 0, stream, a.status, a.nstreams,
                            ws + 1, ws);
-        hipLaunchKernelGGL(tok::k_inflate_tok<true>, grid, block, 0, stream, a, (const uint32_t*)(ws + 1), (const uint32_t*)ws);
+        hipLaunchKernelGGL(tok::k_inflate_tok<true>, grid, block, 0, stream, a, (const uint32_t*)(ws + 1), (const uint32_t*)ws, lane_min);
         e = hipGetLastError();
+        if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws, lane_min);   // (one of the two returns at once)
     }
     const hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;

@@ -62,10 +62,13 @@ enum {
  * ends at the end of its FIRST block -- EOB (deflate.py:1542) or the last stored byte (:1617) -- whatever follows */
 #define HDLZ_INFLATE_ONEBLOCK 8u
 /* mapping hints (results are identical): by default batches of at most HDLZ_INFLATE_WAVE_THRESHOLD streams are decoded
- * one wave per stream, larger ones one lane per stream with a wave-per-stream second pass for dynamic-tree streams */
+ * one wave per stream, larger ones one lane per stream, with a second pass for the streams that hold dynamic-tree blocks:
+ * again one lane per stream when there are at least HDLZ_INFLATE_DYN_LANE_MIN of them (counted on the device), else one
+ * wave per stream (measured crossovers on 2 KiB and 16 KiB streams, tools/bench_inflate_mapping.py) */
 #define HDLZ_INFLATE_LANE_PER_STREAM 2u
 #define HDLZ_INFLATE_WAVE_PER_STREAM 4u
 #define HDLZ_INFLATE_WAVE_THRESHOLD 14336u
+#define HDLZ_INFLATE_DYN_LANE_MIN 20480u
 /* lane-per-stream kernel variant (results are identical): the default and 16 = one token per round (k_inflate_tok),
  * 32 = one output byte per lockstep iteration (k_inflate, the round-1 kernel) */
 #define HDLZ_INFLATE_TOKEN_ROUNDS 16u

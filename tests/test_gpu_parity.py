@@ -483,6 +483,43 @@ def test_inflate_dynamic_streams_vs_oracle(engine, oracle):
             assert out[k, :ol[k]].tobytes() == ref, (k, mapping)
 
 
+def test_inflate_auto_mapping_second_pass(engine, oracle):
+    """the DEFAULT mapping on batches above HDLZ_INFLATE_WAVE_THRESHOLD: pass 1 one lane per stream; the streams with
+    dynamic-tree blocks are counted on the device and redone one lane each when they are at least
+    HDLZ_INFLATE_DYN_LANE_MIN (case 1: all 24576), else one wave each (case 2: every fourth).  Every stream against
+    the oracle (a small pool of distinct streams -- good, damaged, cut -- repeated)."""
+    import torch
+    r = random.Random(77)
+    pool_dyn, pool_fix = [], []
+    for it in range(96):
+        n = r.choice([40, 300, 2048, 6000])
+        alpha = r.choice([b"abcdefgh", bytes(range(256)), b"0123456789 ", DYN_TEXT[:64]])
+        data = bytes(r.choice(alpha) for _ in range(n))
+        co = zlib.compressobj(r.choice([1, 6, 9]), zlib.DEFLATED, 15, strategy=zlib.Z_DEFAULT_STRATEGY if it % 2 else zlib.Z_FIXED)
+        z = co.compress(data) + co.flush()
+        if it % 8 == 3:
+            zb = bytearray(z)
+            zb[r.randrange(2, len(zb))] ^= 1 << r.randrange(8)
+            z = bytes(zb)
+        rc, ref = oracle.inflate(z, out_cap=6016)
+        (pool_dyn if it % 2 else pool_fix).append((z, rc, ref))
+    B, cap = 24576, 6016
+    for case, pick in (("all dynamic", lambda k: pool_dyn[k % len(pool_dyn)]),
+                       ("every fourth", lambda k: pool_dyn[(k // 4) % len(pool_dyn)] if k % 4 == 0 else pool_fix[k % len(pool_fix)])):
+        sel = [pick(k) for k in range(B)]
+        flat = b"".join(z for z, _, _ in sel) + bytes(64)
+        off = np.cumsum([0] + [len(z) for z, _, _ in sel]).astype(np.int64)
+        d_in = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
+        out, ol, st = engine.inflate_batch(d_in, in_off=torch.from_numpy(off).cuda(), out_pitch=cap)
+        out, ol, st = out.cpu().numpy(), ol.cpu().numpy(), st.cpu().numpy()
+        want_st = np.array([rc for _, rc, _ in sel]); want_len = np.array([len(ref) for _, _, ref in sel])
+        assert (st == want_st).all() and (ol == want_len).all(), case
+        for k in range(0, B, 37):
+            assert out[k, :ol[k]].tobytes() == sel[k][2], (case, k)
+        for k in range(192):                    # (every distinct stream at least once)
+            assert out[k, :ol[k]].tobytes() == sel[k][2], (case, k)
+
+
 def test_inflate_error_statuses(engine, oracle):
     cases = [b"\x78\x9c" + bytes([0x07]) + bytes(8),                                  # BTYPE 3
              zlib.compress(DYN_TEXT, 9),               # dynamic block

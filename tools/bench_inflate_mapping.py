@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
-"""lane-per-stream vs wave-per-stream inflate as a function of the batch size (stock-zlib Z_FIXED streams of 2 KiB):
-where is the crossover that HDLZ_INFLATE_WAVE_THRESHOLD encodes?"""
+"""lane-per-stream vs wave-per-stream inflate as a function of the batch size (stock-zlib streams of 2 KiB, Z_FIXED or -- argument
+`default` -- dynamic trees): where is the crossover that HDLZ_INFLATE_WAVE_THRESHOLD encodes?  Optional 2nd argument: block size."""
 import sys, os, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from hdl_deflate_amd import Engine, INFLATE_LANE_PER_STREAM, INFLATE_WAVE_PER_STREAM
 from hdl_deflate_amd.data import make_blocks
 e = Engine()
-n = 2048
+dyn = len(sys.argv) > 1 and sys.argv[1] == "default"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 h = make_blocks(4096, n, "cuda", seed=4, families=(1, 2, 4)).cpu().numpy()
 zs = []
 for k in range(4096):
-    c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+    c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_DEFAULT_STRATEGY if dyn else zlib.Z_FIXED)
     zs.append(c.compress(h[k].tobytes()) + c.flush())
-for B in (64, 1024, 4096, 16384, 32768, 65536, 262144):
+for B in (1024, 4096, 8192, 16384, 24576, 32768, 49152, 65536, 131072):
     reps = (B + 4095) // 4096
     sel = (zs * reps)[:B]
     lens = np.array([len(z) for z in sel], dtype=np.int64)
