@@ -369,7 +369,8 @@ def bench_inflate(a, eng=None, cpu=True):
                       "streams": B, "block_bytes": n},
            "input_MBps": round(z_bytes / (dt / a.steps) / 1e6, 1),
            "compression_ratio_out_over_in": round(z_bytes / u_bytes, 4),
-           "roofline": roofline(("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok") + ("" if fixed else " + k_inflate_dyn"), algo, k_ms,
+           "roofline": roofline(("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok<false>") +
+                                ("" if fixed else " + k_inflate_dyn" if a.inflate_kernel == "byte" else " + k_inflate_tok<true>"), algo, k_ms,
                                 "%s|streams=%d|block=%d" % ("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok", B, n))}
     if cpu and a.cpu_seconds > 0:
         from oracle import oracle as O
@@ -448,7 +449,7 @@ def main():
     ap.add_argument("--stream-block", type=int, default=2048, help="inflate: plain bytes per stream")
     ap.add_argument("--zlib-strategy", default="fixed", choices=["fixed", "default"],
                     help="inflate: fixed = Z_FIXED streams (configs[3]); default = stock zlib streams with dynamic trees "
-                         "(exercises the second pass k_inflate_dyn, SURVEY 8(f) rank 1)")
+                         "(exercises the second pass k_inflate_tok<true> / k_inflate_dyn, SURVEY 8(f) rank 1)")
     ap.add_argument("--inflate-kernel", default="default", choices=["default", "token", "byte"],
                     help="inflate: lane-per-stream kernel variant (token = k_inflate_tok, byte = k_inflate)")
     ap.add_argument("--mode", default="compress", choices=["compress", "inflate"],

@@ -16,6 +16,6 @@ for grp in "TA_TA_BUSY TA_FLAT_READ_WAVEFRONTS GRBM_GUI_ACTIVE" \
   i=$((i+1))
   timeout 200 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d "$out/pmc_m$i" -o t -- $BENCH > "$out/bench_pmc_m$i.log" 2>&1
 done
-python tools/summarize_prof.py "$out" > "$out/summary.txt" 2>&1
-cat "$out/summary.txt"
+python tools/summarize_prof.py "$out" > "$out/summary_mem.txt" 2>&1
+cat "$out/summary_mem.txt"
 find "$out" -name "*kernel_trace.csv" -delete; find "$out" -name "*counter_collection.csv" -delete; find "$out" -name "*agent_info.csv" -delete
