@@ -229,6 +229,7 @@ def test_calls_are_hip_graph_capturable(engine, oracle):
     sout = torch.empty(pitch_for(nbig), dtype=torch.uint8, device="cuda")
     work = torch.empty((engine.lib.hdlz_stream_work_bytes(nbig) + 7) // 8, dtype=torch.int64, device="cuda")
     back = torch.empty((B, n), dtype=torch.uint8, device="cuda")
+    back2 = torch.empty((B, n), dtype=torch.uint8, device="cuda")
     engine.compress_batch(d, out=out, out_pitch=out.shape[1])          # eager once: device properties get cached
     engine.compress_stream(big, nbig, out=sout, work=work)
     torch.cuda.synchronize()
@@ -239,10 +240,12 @@ def test_calls_are_hip_graph_capturable(engine, oracle):
             _, ol, st = engine.compress_batch(d, out=out, out_pitch=out.shape[1])
             _, sl, ss = engine.compress_stream(big, nbig, out=sout, work=work)
             _, bl, bs = engine.inflate_batch(out, in_len=None, out_pitch=n, out=back)
+            # the lane mapping: pass 1, then the device-side list of streams with dynamic blocks in stream-ordered scratch memory
+            _, bl2, bs2 = engine.inflate_batch(out, in_len=None, out_pitch=n, out=back2, flags=2)
     for seed in (11, 12):
         d.copy_(make_blocks(B, n, "cuda", seed=seed))
         big.copy_(make_blocks(40, n, "cuda", seed=seed + 100).reshape(-1))
-        out.zero_(); sout.zero_(); back.zero_()
+        out.zero_(); sout.zero_(); back.zero_(); back2.zero_()
         g.replay()
         torch.cuda.synchronize()
         assert int((st != 0).sum()) == 0 and int(ss.item()) == 0
@@ -252,6 +255,7 @@ def test_calls_are_hip_graph_capturable(engine, oracle):
         assert sout[:int(sl.item())].cpu().numpy().tobytes() == oracle.compress(big[:nbig].cpu().numpy().tobytes())[1]
         # inflate took the full pitch as in_len: trailing zero bytes after the Adler-32 are ignored (D6)
         assert int((bs != 0).sum()) == 0 and torch.equal(back, d) and int((bl != n).sum()) == 0
+        assert int((bs2 != 0).sum()) == 0 and torch.equal(back2, d) and int((bl2 != n).sum()) == 0
 
 
 def test_api_edge_cases(engine, oracle):
