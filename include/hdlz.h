@@ -102,8 +102,10 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
 /*
  * STARTD for a batch of independent zlib streams: 2 header bytes skipped unvalidated, blocks
  * until BFINAL, stored (BTYPE 0), fixed-Huffman (BTYPE 1) and dynamic-tree (BTYPE 2, deflate.py:1084-1517;
- * handled by a second, wave-per-stream pass -- which is the only pass for small batches, see the mapping
- * hints above) blocks, 4 trailer bytes required
+ * handled by a second pass over the streams that hold such blocks -- see the mapping hints above; in the lane
+ * mapping that pass keeps the list of these streams in stream-ordered scratch memory, hipMallocAsync /
+ * hipFreeAsync on `stream`, 4 bytes per stream: nothing is allocated with HDLZ_INFLATE_ASSUME_FIXED or in the
+ * wave mapping, and the call stays capturable into a HIP graph) blocks, 4 trailer bytes required
  * but Adler-32 not verified -- exactly the reference's acceptance (deflate.py:635-651 IDLE/STARTD,
  * :656-732 HEADER, :1402-1445 NEXT, :1519-1591 INFLATE, :1593-1659 COPY, :517-533 get4/adv).
  * `obsize` != 0 selects the reference-exact behaviour of an OBSIZE build (deflate.py:61-62):
