@@ -110,6 +110,15 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     // any block type
     const bool wave_all = (flags & HDLZ_INFLATE_WAVE_PER_STREAM) ||
                           (!(flags & HDLZ_INFLATE_LANE_PER_STREAM) && nstreams <= HDLZ_INFLATE_WAVE_THRESHOLD);
+    // ONE large stream: cut into 1 KiB pieces and decoded by the whole GPU (hdlz_inflate_par.hip) when it is a single fixed block --
+    // what STARTC writes --, by one wave otherwise (decided on the device); the explicit mapping hints keep the batch kernels
+    if (nstreams == 1 && !d_in_off && in_len >= HDLZ_INFLATE_PAR_MIN &&
+        !(flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_BYTE_LOCKSTEP))) {
+        bool used = false;
+        hipError_t e = hdlz::launch_inflate_par(a, st, &used);
+        if (e != hipSuccess) return fail_hip(e, "launch the parallel single-stream inflate");
+        if (used) return HDLZ_OK;
+    }
     if (wave_all) {
         hipError_t e = hdlz::launch_inflate_dyn(a, st, true);
         if (e != hipSuccess) return fail_hip(e, "launch k_inflate_dyn");

@@ -54,6 +54,7 @@ hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int 
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t stream);
 hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream);
 hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool all);
+hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used);
 hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream, bool all, const uint32_t* few_n = nullptr, uint32_t lane_min = 0);
 size_t stream_work_bytes(uint32_t n, uint32_t nblocks);
 hipError_t launch_compress_streams(const uint8_t* in, uint64_t in_pitch, uint32_t n, uint32_t nblocks, int cwindow, int maxmatch,

@@ -1,0 +1,305 @@
+// hdlz_inflate_par.hip -- STARTD for ONE large stream on the whole GPU (the port adapter's case: the reference inflates one stream
+// at a time, /root/reference/deflate.py:635-732 HEADER, :1402-1445 NEXT, :1519-1591 INFLATE, :1593-1659 COPY).
+//
+// One wave decoding one stream is a serial chain: ~9 MB/s (k_inflate_dyn), a fifth of what the FPGA does at 100 MHz.  A stream of ONE
+// fixed-Huffman block -- what STARTC writes (deflate.py:429-466: 78 9C, BFINAL = 1, BTYPE = 1) and all the reference's DYNAMIC=False
+// build reads -- can be cut anywhere, because a token is at most 32 bits long (9 + 5 + 5 + 13):
+//   1. k_par_spec    every 1 KiB piece of the stream is decoded from all 32 bit offsets a token can start at behind its first bit
+//                    (one lane per offset, two pieces per wave): per offset, where the chain leaves the piece (offset into the next
+//                    one, or EOB, or an undecodable symbol) and how many bytes it produces;
+//   2. k_par_scan    one wave walks these 32-entry maps from the stream's first token on: the true entry offset and the output
+//                    position of every piece, the total length;
+//   3. k_par_decode  one wave per piece decodes it for real, with the reference's checks in the reference's order, and writes the
+//                    bytes -- except that the history before the piece's own output is not there yet.  A byte copied from there
+//                    becomes a MARKER: src[p] = the absolute position it comes from (markers are copied like bytes);
+//   4. k_par_jump    pointer jumping over the markers: src[p] <- src[src[p]] until the source is a byte (double-buffered, one launch
+//                    per pass, log2(pieces) + 1 passes at most; a pass with nothing left returns at once).
+// Anything else -- another block type, more than one block, a failed check (NO EOF, bad symbol, bad distance, capacity) -- sets
+// a fallback flag on the device and k_inflate_dyn redoes the stream from its first byte (it is launched behind the chain and
+// returns at once otherwise): status words and bytes are those of the serial decoder by construction, the parallel path
+// only ever reports HDLZ_OK.  Scratch (stream-ordered): 160 bytes per KiB of input and 8 bytes per possible output byte.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hdlz_device.h"
+#include "hdlz_inflate_tables.h"
+
+namespace hdlz {
+namespace par {
+
+using tok::T_BAD;
+using tok::T_EOB;
+using tok::T_LEN;
+using tok::T_LIT;
+
+constexpr uint32_t CH_BITS = 8192;            // a piece: 1 KiB of the stream
+constexpr uint32_t WIN_DW = CH_BITS / 32 + 8; // its staged window: the piece, the 31 + 64 bits a token starting at its end may read
+constexpr uint32_t FIRST_BIT = 19;            // 2 zlib header bytes, BFINAL, BTYPE
+constexpr uint32_t X_EOB = 0x40, X_BAD = 0x80;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+enum { C_FALLBACK = 0, C_NUSED = 1, C_TOTAL = 2, C_OK = 3, C_MARK = 4, C_PASS0 = 8, C_WORDS = 64 };
+
+struct ParArgs {
+    const uint8_t* z;
+    uint32_t zn;
+    uint32_t flags, obsize;
+    uint8_t* out;
+    uint32_t cap;               // output capacity (bytes)
+    uint32_t srcn;              // entries of srcA / srcB
+    uint32_t* out_len;
+    uint32_t* status;
+    uint32_t nchunks;
+    uint32_t* ctl;              // C_WORDS control words (zeroed)
+    uint8_t* exit8;             // [nchunks][32]
+    uint32_t* nb32;             // [nchunks][32]
+    uint8_t* entry8;            // [nchunks]
+    uint32_t* opos;             // [nchunks]
+    uint32_t* srcA;
+    uint32_t* srcB;
+};
+
+__device__ __forceinline__ void fill_tables(uint32_t* lit, uint32_t* dst, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t c = tid; c < 512u; c += nthreads) lit[c] = tok::lit_entry(c);
+    if (tid < 32u) dst[tid] = tok::dst_entry(tid);
+}
+// the window of piece c: stream dwords from byte B0 = (first bit of the piece / 8) & ~3 on
+__device__ __forceinline__ void stage_window(uint32_t* win, const uint8_t* z, uint32_t zn, uint32_t b_c, uint32_t tid, uint32_t nthreads) {
+    const uint32_t B0 = (b_c >> 3) & ~3u;
+    for (uint32_t k = tid; k < WIN_DW; k += nthreads) win[k] = tok::load32(z, B0 + 4u * k, zn);
+}
+// 64 stream bits from absolute bit position `pos` on
+__device__ __forceinline__ uint64_t bits_at(const uint32_t* win, uint32_t b_c, uint32_t pos) {
+    const uint32_t rel = pos - 8u * ((b_c >> 3) & ~3u);
+    const uint32_t w = rel >> 5, sh = rel & 31u;
+    const uint32_t d0 = win[w], d1 = win[w + 1u], d2 = win[w + 2u];
+    return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+}
+
+// ---- 1. speculative decode: lane (piece, offset)
+__global__ __launch_bounds__(64) void k_par_spec(ParArgs a) {
+    __shared__ uint32_t lit[512], dst[32], win[2][WIN_DW];
+    const uint32_t lane = threadIdx.x, half = lane >> 5, e = lane & 31u;
+    fill_tables(lit, dst, lane, 64u);
+    const uint32_t c = blockIdx.x * 2u + half;
+    const bool have = c < a.nchunks;
+    const uint32_t b_c = FIRST_BIT + c * CH_BITS, end = b_c + CH_BITS;
+    if (have) stage_window(win[half], a.z, a.zn, b_c, e, 32u);
+    __syncthreads();
+    uint32_t pos = b_c + e, nbytes = 0, exitc = 0;
+    bool run = have;
+    while (__ballot(run) != 0ull) {
+        if (run) {
+            const uint64_t x = bits_at(win[half], b_c, pos);
+            const uint32_t e0 = lit[(uint32_t)x & 511u];
+            const uint32_t nb = e0 & 15u, type = (e0 >> 13) & 3u;
+            if (nb == 0u || type == (uint32_t)T_BAD) { exitc = X_BAD; run = false; }
+            else if (type == (uint32_t)T_EOB) { exitc = X_EOB; run = false; }
+            else if (type == (uint32_t)T_LIT) { pos += nb; nbytes += 1u; }
+            else {
+                const uint32_t leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
+                uint64_t y = x >> nb;
+                const uint32_t tl = lbase + ((uint32_t)y & ((1u << leb) - 1u));
+                y >>= leb;
+                const uint32_t de = dst[(uint32_t)y & 31u];
+                if (de == 0xFFFFFFFFu) { exitc = X_BAD; run = false; }
+                else { pos += nb + leb + 5u + ((de >> 16) & 15u); nbytes += tl; }
+            }
+            if (run && pos >= end) { exitc = pos - end; run = false; }
+        }
+    }
+    if (have) { a.exit8[c * 32u + e] = (uint8_t)exitc; a.nb32[c * 32u + e] = nbytes; }
+}
+
+// ---- 2. the true chain through the pieces
+__global__ __launch_bounds__(64) void k_par_scan(ParArgs a) {
+    __shared__ uint8_t ex[64 * 32];
+    __shared__ uint32_t nb[64 * 32];
+    __shared__ uint8_t ent[64];
+    __shared__ uint32_t op[64];
+    __shared__ uint32_t sh_stop, sh_e, sh_bad, sh_n;
+    __shared__ uint64_t sh_acc;
+    const uint32_t lane = threadIdx.x;
+    // the stream must be one fixed block (or be read as one: the DYNAMIC=False / ONEBLOCK builds)
+    const uint32_t hdr = a.zn >= 5u ? (uint32_t)a.z[2] : 0u;
+    const bool fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) || ((hdr >> 1) & 3u) == 1u;
+    const bool last = (a.flags & HDLZ_INFLATE_ONEBLOCK) || (hdr & 1u);
+    if (a.zn < 5u || !fixed || !last) {
+        if (lane == 0) a.ctl[C_FALLBACK] = 1u;
+        return;
+    }
+    if (lane == 0) { sh_stop = 0; sh_e = 0; sh_bad = 0; sh_n = 0; sh_acc = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < a.nchunks && sh_stop == 0u; base += 64u) {
+        const uint32_t cnt = min(64u, a.nchunks - base);
+        for (uint32_t k = lane; k < cnt * 32u; k += 64u) { ex[k] = a.exit8[base * 32u + k]; nb[k] = a.nb32[base * 32u + k]; }
+        __syncthreads();
+        if (lane == 0) {
+            uint32_t e = sh_e, n = 0;
+            uint64_t acc = sh_acc;
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint32_t x = ex[j * 32u + e];
+                ent[j] = (uint8_t)e; op[j] = (uint32_t)acc;
+                acc += nb[j * 32u + e];
+                n = j + 1u;
+                if (x & (X_EOB | X_BAD)) { sh_stop = 1u; sh_bad = x & X_BAD; break; }
+                e = x;
+            }
+            sh_e = e; sh_acc = acc; sh_n = base + n;
+        }
+        __syncthreads();
+        if (lane < cnt) { a.entry8[base + lane] = ent[lane]; a.opos[base + lane] = op[lane]; }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const bool good = sh_stop != 0u && sh_bad == 0u && sh_acc <= (uint64_t)a.cap && sh_acc <= (uint64_t)a.srcn;
+        a.ctl[C_NUSED] = sh_n;
+        a.ctl[C_TOTAL] = (uint32_t)sh_acc;
+        if (!good) a.ctl[C_FALLBACK] = 1u;
+    }
+}
+
+// ---- 3. the real decode of one piece (wave-uniform token chain, lane-parallel copies)
+__global__ __launch_bounds__(64) void k_par_decode(ParArgs a) {
+    __shared__ uint32_t lit[512], dst[32], win[WIN_DW];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (a.ctl[C_FALLBACK] != 0u || c >= a.ctl[C_NUSED]) return;
+    fill_tables(lit, dst, lane, 64u);
+    const uint32_t b_c = FIRST_BIT + c * CH_BITS, end = b_c + CH_BITS;
+    stage_window(win, a.z, a.zn, b_c, lane, 64u);
+    __syncthreads();
+    const int32_t isize = (int32_t)a.zn - 1;              // deflate.py:605
+    const uint32_t obsize = a.obsize ? a.obsize : 32768u;
+    const uint32_t cstart = a.opos[c];
+    uint32_t P = cstart;                                  // output position behind the pending literals
+    uint32_t pos = b_c + a.entry8[c];
+    uint8_t* out = a.out;
+    uint32_t* src = a.srcA;
+    uint32_t litv = 0, nlit = 0, nmark = 0;               // lane k holds the k-th pending literal
+    bool bad = false;
+#define PAR_FLUSH_LITS() do {                                                                 \
+        if (lane < nlit) { out[P - nlit + lane] = (uint8_t)litv; src[P - nlit + lane] = NONE; } \
+        nlit = 0;                                                                               \
+    } while (0)
+    while (pos < end) {
+        const uint64_t x = bits_at(win, b_c, (uint32_t)__builtin_amdgcn_readfirstlane((int)pos));
+        const uint32_t e0 = lit[(uint32_t)x & 511u];
+        const uint32_t nb = e0 & 15u, code = (e0 >> 4) & 0x1FFu;
+        if (nb < 1u) { bad = true; break; }                                              // zero leaf: BAD_SYMBOL
+        pos += nb;
+        if ((int32_t)(pos >> 3) > isize - 3) { bad = true; break; }                      // NO EOF, deflate.py:1535-1539
+        if (code == 256u) break;                                                         // D6: the stream ends here
+        if (code < 256u) {
+            if (P >= a.cap) { bad = true; break; }
+            litv = lane == nlit ? code : litv;
+            nlit++; P++;
+            if (nlit == 64u) PAR_FLUSH_LITS();
+            continue;
+        }
+        if (code - 257u >= 29u) { bad = true; break; }                                   // BAD_SYMBOL
+        const uint32_t leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
+        uint64_t y = x >> nb;
+        const uint32_t tl = lbase + ((uint32_t)y & ((1u << leb) - 1u));
+        y >>= leb;
+        const uint32_t de = dst[(uint32_t)y & 31u];
+        if (de == 0xFFFFFFFFu) { bad = true; break; }                                    // BAD_DISTANCE (codes 30, 31)
+        const uint32_t deb = (de >> 16) & 15u;
+        const uint32_t D = (de & 0xFFFFu) + ((uint32_t)(y >> 5) & ((1u << deb) - 1u));
+        pos += leb + 5u + deb;
+        if (D > P || D > obsize) { bad = true; break; }                                  // D8
+        if ((int32_t)(pos >> 3) >= isize - 2) { bad = true; break; }                     // COPY hold, deflate.py:1600
+        if ((uint64_t)P + tl > a.cap) { bad = true; break; }
+        PAR_FLUSH_LITS();
+        // COPY (deflate.py:1627-1659), lane-parallel: out[P+i] = out[P - D + (i mod D)]; a source in front of this piece's output is
+        // not there yet: the byte becomes a marker, and a marker is copied like a byte
+        for (uint32_t i0 = 0; i0 < tl; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            if (i < tl) {
+                const uint32_t s = P - D + (D >= tl ? i : i % D);
+                uint32_t m = s, v = 0;
+                if (s >= cstart) { m = src[s]; v = out[s]; }
+                out[P + i] = (uint8_t)v;
+                src[P + i] = m;
+                nmark += m != NONE ? 1u : 0u;
+            }
+        }
+        P += tl;
+    }
+    PAR_FLUSH_LITS();
+#undef PAR_FLUSH_LITS
+    if (bad) { if (lane == 0) atomicExch(&a.ctl[C_FALLBACK], 1u); }
+    else if (nmark) atomicAdd(&a.ctl[C_MARK], nmark);
+}
+
+// ---- 4. one pass of pointer jumping over the markers
+__global__ __launch_bounds__(256) void k_par_jump(ParArgs a, uint32_t pass) {
+    if (a.ctl[C_FALLBACK] != 0u) return;
+    if (a.ctl[pass == 0u ? (uint32_t)C_MARK : C_PASS0 + pass - 1u] == 0u) return;            // nothing left
+    const uint32_t n = a.ctl[C_TOTAL];
+    const uint32_t* sin = (pass & 1u) ? a.srcB : a.srcA;
+    uint32_t* sout = (pass & 1u) ? a.srcA : a.srcB;
+    uint32_t left = 0;
+    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+        const uint32_t m = sin[p];
+        uint32_t r = NONE;
+        if (m != NONE) {
+            const uint32_t m2 = sin[m];
+            if (m2 == NONE) a.out[p] = a.out[m];          // (final since an earlier launch: nobody writes it in this one)
+            else { r = m2; left++; }
+        }
+        sout[p] = r;
+    }
+    if (left) atomicAdd(&a.ctl[C_PASS0 + pass], left);
+}
+
+// ---- 5. the verdict: HDLZ_OK and the length, or the serial decoder's turn
+__global__ __launch_bounds__(64) void k_par_finish(ParArgs a, uint32_t passes) {
+    if (threadIdx.x != 0) return;
+    const uint32_t left = a.ctl[C_MARK] == 0u ? 0u : a.ctl[C_PASS0 + passes - 1u];
+    const bool ok = a.ctl[C_FALLBACK] == 0u && left == 0u;
+    if (ok) { a.out_len[0] = a.ctl[C_TOTAL]; a.status[0] = HDLZ_OK; }
+    a.ctl[C_OK] = ok ? 1u : 0u;
+}
+
+}  // namespace par
+
+// one stream of at least HDLZ_INFLATE_PAR_MIN bytes (fixed pitch form): the parallel chain, then -- only if it gave up -- one wave
+hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used) {
+    using namespace par;
+    *used = false;
+    const uint32_t zn = a.in_len;
+    const uint64_t cap64 = a.out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00ull : a.out_pitch;
+    uint64_t srcn = (uint64_t)zn * 172u + 258u;            // a token of 13 bits makes at most 258 bytes
+    if (srcn > cap64) srcn = cap64;
+    if (srcn > (1ull << 30)) return hipSuccess;            // (8 GiB of scratch: leave it to the serial decoder)
+    const uint32_t nchunks = (8u * zn - FIRST_BIT + CH_BITS - 1u) / CH_BITS;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
+    const size_t o_ctl = take(4u * C_WORDS), o_ex = take((size_t)nchunks * 32u), o_nb = take((size_t)nchunks * 128u),
+                 o_en = take(nchunks), o_op = take((size_t)nchunks * 4u), o_sa = take((size_t)srcn * 4u), o_sb = take((size_t)srcn * 4u);
+    uint8_t* ws = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&ws), off, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws + o_ctl, 0, 4u * C_WORDS, stream);
+    if (e == hipSuccess) {
+        ParArgs p{a.in, zn, a.flags, a.obsize, a.out, (uint32_t)cap64, (uint32_t)srcn, a.out_len, a.status, nchunks,
+                  reinterpret_cast<uint32_t*>(ws + o_ctl), ws + o_ex, reinterpret_cast<uint32_t*>(ws + o_nb), ws + o_en,
+                  reinterpret_cast<uint32_t*>(ws + o_op), reinterpret_cast<uint32_t*>(ws + o_sa), reinterpret_cast<uint32_t*>(ws + o_sb)};
+        uint32_t passes = 1;
+        while ((1u << (passes - 1u)) < nchunks + 1u) passes++;         // chains of up to `nchunks` hops
+        if (passes > C_WORDS - C_PASS0) passes = C_WORDS - C_PASS0;
+        hipLaunchKernelGGL(k_par_spec, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_par_scan, dim3(1), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_par_decode, dim3(nchunks), dim3(64), 0, stream, p);
+        const uint32_t jgrid = (uint32_t)((srcn + 255u) / 256u < 8192u ? (srcn + 255u) / 256u : 8192u);
+        for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(jgrid), dim3(256), 0, stream, p, j);
+        hipLaunchKernelGGL(k_par_finish, dim3(1), dim3(64), 0, stream, p, passes);
+        e = hipGetLastError();
+        // the serial decoder returns at once when ctl[C_OK] >= 1
+        if (e == hipSuccess) e = launch_inflate_dyn(a, stream, true, p.ctl + C_OK, 1u);
+        *used = true;
+    }
+    const hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
+}
+
+}  // namespace hdlz

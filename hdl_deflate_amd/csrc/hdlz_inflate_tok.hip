@@ -1,18 +1,19 @@
-// hdlz_inflate_tok.hip -- STARTD for a batch of independent zlib streams, one LANE per stream, one TOKEN per round.
+// hdlz_inflate_tok.hip -- STARTD for a batch of independent zlib streams, one LANE per stream, TOKENS (not bytes) per round.
 //
 // Same contract and same reference lines as hdlz_inflate.hip (/root/reference/deflate.py:635-732 IDLE/HEADER, :1402-1445 NEXT,
 // :1519-1591 INFLATE, :1593-1659 COPY, :517-533 get4/adv); rule names D0..D8 are SURVEY.md 8(a)'s.  k_inflate (round 1) runs its 64
 // streams in lockstep ONE OUTPUT BYTE per iteration, which keeps the output offset wave-uniform -- but every iteration pays the
 // whole token decode (~50 VALU + ~40 SALU instructions) although only the lanes standing at a token boundary need it: with
-// ~6 bytes per token the decode is paid six times.  Here a ROUND decodes one token in every lane, then a short loop moves the
-// bytes: up to four per lane and iteration (the literal, or the next four bytes of the copy), so the decode is paid once per token
-// and a byte of a copy costs ~8 VALU instructions.  What changes with it:
+// ~6 bytes per token the decode is paid six times.  Here a ROUND decodes, in every lane, up to three literals and the match behind
+// them, and a short loop moves the bytes: up to eight per lane and iteration (the literals, or the next bytes of the copy: four
+// from the ring, eight of far history), so the decode is paid once per token.  What changes with it:
 //   * every lane has its own output position.  The ring stays lane-interleaved (dword w of lane l at dword index w*64 + l: each
-//     lane owns a bank, whatever the positions are) and is 128 bytes per lane; four bytes are written at once, unmasked -- the
-//     bytes behind the new end are not-yet-produced positions whose old content (history > 120 back) is never read again;
-//   * a lane's 64-byte line is flushed when complete, by the lane itself (16 conflict-free ds_read_b32 + 4 x 16-byte stores: a full
-//     64-byte sector per lane); flushes are batched: they run when a quarter of the wave is ready or one lane is about to overrun;
-//   * near history (distance <= 120) is read from the ring, far history from the stream's own flushed output, four bytes at a time;
+//     lane owns a bank, whatever the positions are) and is 128 bytes per lane; three dwords are written at once, unmasked -- the
+//     bytes behind the new end are not-yet-produced positions whose old content (history > 112 back) is never read again;
+//   * a lane's 64-byte line is flushed when complete, by the lane itself (16 conflict-free ds_read_b32 + 4 x global_store_dwordx4: a
+//     full 64-byte sector per lane); flushes are batched: they run when a quarter of the wave is ready or one lane is about to overrun;
+//   * near history (distance <= 112) is read from the ring, far history from the stream's own flushed output (one 16-byte load
+//     when the token is decoded);
 //   * input arrives through 16-byte LDS-DMA slots per lane (hdlz_inflate.hip explains the ordering rule).
 // Status codes and the ORDER of the reference's checks are those of k_inflate: the slow path is the same code.
 //
@@ -28,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
+#include "hdlz_inflate_tables.h"
 
 namespace hdlz {
 namespace tok {
@@ -50,7 +52,7 @@ constexpr uint32_t BATCH = HDLZ_TOK_BATCH;    // lanes with a complete line that
 #ifndef HDLZ_TOK_MOVES
 #define HDLZ_TOK_MOVES 3
 #endif
-constexpr uint32_t MOVES = HDLZ_TOK_MOVES;    // move iterations (4 bytes per lane each) per round
+constexpr uint32_t MOVES = HDLZ_TOK_MOVES;    // move iterations (up to 8 bytes per lane each) per round; 2 / 3 / 4 / 6: 4.21 / 3.95 / 4.10 / 3.99 ms
 #ifdef HDLZ_TOK_MARKS                         // tools/phase_count.py --src hdlz_inflate_tok.hip -DHDLZ_TOK_MARKS: static counts per part
 #define TOK_MARK(name) asm volatile("; @@PHASE " name ::: "memory")
 #else
@@ -75,58 +77,10 @@ struct __attribute__((aligned(16))) Lds {
     uint32_t tab[DYN ? T_ROWS * 64 : 1];
 };
 
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-struct __attribute__((packed, aligned(1))) u128_unaligned { uint64_t lo, hi; };
-
-__device__ __forceinline__ uint32_t rev(uint32_t v, uint32_t nbits) { return __builtin_bitreverse32(v) >> (32u - nbits); }
-
-__device__ __forceinline__ uint32_t load32(const uint8_t* __restrict__ z, uint32_t ip, uint32_t zn) {
-    if (ip + 4u <= zn) return *reinterpret_cast<const u32_unaligned*>(z + ip);
-    uint32_t v = 0;
-    for (uint32_t k = 0; k < 4u; k++)
-        if (ip + k < zn) v |= (uint32_t)z[ip + k] << (8u * k);
-    return v;
-}
-
 __device__ __forceinline__ void lds_dma_load16(const uint8_t* gptr, uint32_t lds_base) {
     uint32_t save;      // LDS address = M0 + lane * 16 (see tools/ubench/lds_dma.hip); M0 is saved and restored
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(save) : "v"(gptr), "s"(lds_base) : "memory");
-}
-
-// RFC1951 tables in closed form (deflate.py:100-110)
-__device__ __forceinline__ void length_info(uint32_t token, uint32_t& base, uint32_t& eb) {
-    if (token < 8u) { base = 3u + token; eb = 0; }
-    else if (token == 28u) { base = 258u; eb = 0; }
-    else { eb = (token >> 2) - 1u; base = 3u + ((4u + (token & 3u)) << eb); }
-}
-__device__ __forceinline__ void dist_info(uint32_t dc, uint32_t& base, uint32_t& eb) {
-    if (dc < 4u) { base = 1u + dc; eb = 0; }
-    else { eb = (dc >> 1) - 1u; base = 1u + ((2u + (dc & 1u)) << eb); }
-}
-// the widened stat_leaves (deflate.py:151-216): nbits[3:0] | sym[12:4] | type[14:13] | lbase[24:16] | leb[27:25]
-enum { T_LIT = 0, T_LEN = 1, T_EOB = 2, T_BAD = 3 };
-__device__ __forceinline__ uint32_t lit_entry(uint32_t c) {
-    uint32_t sym, nb;
-    const uint32_t r7 = rev(c & 127u, 7), r8 = rev(c & 255u, 8), r9 = rev(c, 9);
-    if (r7 < 24u) { sym = 256u + r7; nb = 7; }
-    else if (r8 >= 0x30u && r8 < 0xC0u) { sym = r8 - 0x30u; nb = 8; }
-    else if (r8 >= 0xC0u && r8 < 0xC8u) { sym = 280u + (r8 - 0xC0u); nb = 8; }
-    else { sym = r9 - 256u; nb = 9; }
-    uint32_t type = sym < 256u ? T_LIT : sym == 256u ? T_EOB : sym <= 285u ? T_LEN : T_BAD;
-    uint32_t lbase = 0, leb = 0;
-    if (type == T_LEN) length_info(sym - 257u, lbase, leb);
-    if (sym == 287u) nb = 0;                                 // the reference's zero leaf at index 483 (deflate.py:212)
-    return nb | (sym << 4) | (type << 13) | (lbase << 16) | (leb << 25);
-}
-__device__ __forceinline__ uint32_t dst_entry(uint32_t raw5) {
-    const uint32_t dc = rev(raw5, 5);
-    if (dc >= 30u) return 0xFFFFFFFFu;
-    uint32_t dbase, deb;
-    dist_info(dc, dbase, deb);
-    return dbase | (deb << 16);
 }
 
 // byte address of stream position `pos` of lane `lane` inside a wave's ring
@@ -452,7 +406,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     for (;;) {
         TOK_MARK("move");
         // ------------------------------------------------------------ 0. move the bytes of the tokens decoded in the PREVIOUS round: up to
-        // four per lane and iteration.  (Moving first, decoding after: the far history a token needs was requested when it was
+        // eight per lane and iteration.  (Moving first, decoding after: the far history a token needs was requested when it was
         // decoded, a whole round ago -- waiting for it right after the decode left 67 % of the wave cycles in s_waitcnt.)
         // At most MOVES iterations per round: a long copy goes on in the next rounds while the other lanes decode on -- waiting
         // for the longest copy of the wave in every round left the short tokens idle (measured: 91 VALU per byte instead of ~25)

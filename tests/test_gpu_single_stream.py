@@ -1,0 +1,133 @@
+"""GPU (-m gpu): STARTD for ONE large stream (hdlz_inflate_par.hip): the stream is cut into 1 KiB pieces, decoded speculatively,
+chained, decoded for real with markers for the history that is not there yet, and the markers are resolved by pointer jumping.
+Everything that is not a single valid fixed block falls back, on the device, to the serial decoder -- so status AND bytes
+must equal the oracle's for every stream, good or bad."""
+import random
+import time
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _zfixed(data, level=6, wbits=15):
+    co = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, zlib.Z_FIXED)
+    return co.compress(data) + co.flush()
+
+
+def _text(n, seed):
+    r = random.Random(seed)
+    words = [bytes(r.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(r.randint(2, 9))) for _ in range(300)]
+    out = bytearray()
+    while len(out) < n:
+        out += r.choice(words) + b" "
+    return bytes(out[:n])
+
+
+def _check(engine, oracle, z, cap, flags=0, obsize=0):
+    st, got = engine.inflate_bytes(z, flags=flags, out_cap=cap, obsize=obsize)
+    rc, ref = oracle.inflate(z, out_cap=cap, flags=flags, obsize=obsize)
+    assert st == rc, (st, rc, len(z))
+    assert got == ref
+    return st
+
+
+def test_own_streams_cwindow32_and_256(engine, oracle):
+    """what STARTC writes (one fixed block, distances <= CWINDOW): through compress_stream, 1 MiB and 5 MiB + 13"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    for n, cw in ((1 << 20, 32), (5 * (1 << 20) + 13, 32), (1 << 20, 256)):
+        d = make_blocks((n + 2047) // 2048, 2048, "cuda", seed=n & 0xFF).reshape(-1)        # (readable beyond n)
+        out, ol, st = engine.compress_stream(d, n, cwindow=cw)
+        assert int(st.item()) == 0
+        z = out[:int(ol.item())].cpu().numpy().tobytes()
+        st2, got = engine.inflate_bytes(z, out_cap=n + 64)
+        assert st2 == 0 and got == d[:n].cpu().numpy().tobytes()
+        assert oracle.inflate(z, out_cap=n + 64) == (0, got)
+    # ... and it is the parallel path that did it: one wave needs ~110 ms per MiB (9 MB/s)
+    zin = torch.frombuffer(bytearray(z + bytes(64)), dtype=torch.uint8).cuda().reshape(1, -1)
+    engine.inflate_batch(zin, in_len=len(z), out_pitch=n + 64)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    engine.inflate_batch(zin, in_len=len(z), out_pitch=n + 64)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 0.03, time.time() - t0
+
+
+def _timed(engine, z, cap, flags):
+    import torch
+    zin = torch.frombuffer(bytearray(z + bytes(64)), dtype=torch.uint8).cuda().reshape(1, -1)
+    engine.inflate_batch(zin, in_len=len(z), out_pitch=cap, flags=flags)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    engine.inflate_batch(zin, in_len=len(z), out_pitch=cap, flags=flags)
+    torch.cuda.synchronize()
+    return time.time() - t0
+
+
+def test_far_history_and_deep_marker_chains(engine, oracle):
+    """single fixed blocks with every kind of history: stock-zlib Z_FIXED streams of fewer than 32768 symbols are ONE block with
+    distances up to 32 KiB (every piece starts with markers that point far back); a period-3 / period-1 stream from our own
+    compressor makes every byte of every piece a marker (chains as deep as the number of pieces); incompressible literals.
+    The parallel path must have taken them (>= 5x faster than the forced wave-per-stream decoder)."""
+    import torch
+    cases = [_zfixed(_text(150000, 1), level=9), _zfixed(b"x" * 70000 + _text(90000, 2))]
+    for z in cases:
+        assert len(z) >= 16384 and (z[2] & 7) == 3                 # BFINAL = 1, BTYPE = 1: one block
+    for data in (b"abc" * 900000, bytes(3 << 20), _text(2 << 20, 3), np.random.default_rng(3).integers(0, 256, 300000, dtype=np.uint8).tobytes()):
+        d = torch.frombuffer(bytearray(data + bytes(64)), dtype=torch.uint8).cuda()
+        out, ol, st = engine.compress_stream(d, len(data))
+        assert int(st.item()) == 0
+        cases.append(out[:int(ol.item())].cpu().numpy().tobytes())
+    for z in cases:
+        assert _check(engine, oracle, z, 4 << 20) == 0
+        t_par, t_wave = _timed(engine, z, 4 << 20, 0), _timed(engine, z, 4 << 20, 4)
+        assert t_par * 5 < t_wave, (len(z), t_par, t_wave)
+
+
+def test_everything_else_falls_back_with_the_serial_status(engine, oracle):
+    good = _zfixed(_text(600000, 5))
+    r = random.Random(6)
+    cases = []
+    for _ in range(6):                                   # one flipped bit somewhere in the stream
+        zb = bytearray(good)
+        zb[r.randrange(2, len(zb))] ^= 1 << r.randrange(8)
+        cases.append(bytes(zb))
+    cases += [good[:-3], good[:-5], good[:len(good) // 2], good[:20000] + bytes(4000),     # cut streams, zero padding (an EOB)
+              zlib.compress(_text(600000, 7), 6),                                           # dynamic blocks
+              zlib.compress(_text(100000, 8), 0)]                                           # stored blocks
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+    cases.append(co.compress(_text(300000, 9)) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(_text(300000, 10)) + co.flush())   # 2+ blocks
+    for z in cases:
+        _check(engine, oracle, z, 1 << 20)
+    # output capacity: one byte short, exact, generous
+    n = 600000
+    for cap in (n - 16, n, n + 4096):
+        _check(engine, oracle, good, cap)
+    # reference builds: DYNAMIC=False reads every block as fixed, ONEBLOCK stops at the first EOB, a small OBSIZE limits the distance
+    _check(engine, oracle, good, 1 << 20, flags=1)
+    _check(engine, oracle, cases[-1], 1 << 20, flags=8)
+    _check(engine, oracle, cases[-1], 1 << 20, flags=1 | 8)
+    _check(engine, oracle, good, 1 << 20, obsize=512)
+    _check(engine, oracle, _zfixed(_text(600000, 11), wbits=9), 1 << 20, obsize=512)
+
+
+def test_single_stream_inside_a_hip_graph(engine, oracle):
+    import torch
+    z = _zfixed(_text(400000, 12))
+    zin = torch.frombuffer(bytearray(z + bytes(64)), dtype=torch.uint8).cuda().reshape(1, -1)
+    back = torch.empty((1, 400064), dtype=torch.uint8, device="cuda")
+    engine.inflate_batch(zin, in_len=len(z), out_pitch=400064, out=back)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            _, bl, bs = engine.inflate_batch(zin, in_len=len(z), out_pitch=400064, out=back)
+    back.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert int(bs.item()) == 0 and int(bl.item()) == 400000
+    assert back[0, :400000].cpu().numpy().tobytes() == zlib.decompress(z)
