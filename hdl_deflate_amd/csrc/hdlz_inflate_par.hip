@@ -7,8 +7,9 @@
 //   1. k_par_spec    every 1 KiB piece of the stream is decoded from all 32 bit offsets a token can start at behind its first bit
 //                    (one lane per offset, two pieces per wave): per offset, where the chain leaves the piece (offset into the next
 //                    one, or EOB, or an undecodable symbol) and how many bytes it produces;
-//   2. k_par_scan    one wave walks these 32-entry maps from the stream's first token on: the true entry offset and the output
-//                    position of every piece, the total length;
+//   2. k_par_scan_*  the 32-entry maps are walked from the stream's first token on (per group of 64 pieces for all 32 offsets, one
+//                    wave over the groups, the pieces of every group again): the true entry offset and the output position of every
+//                    piece, the total length;
 //   3. k_par_decode  one wave per piece decodes it for real, with the reference's checks in the reference's order, and writes the
 //                    bytes -- except that the history before the piece's own output is not there yet.  A byte copied from there
 //                    becomes a MARKER: src[p] = the absolute position it comes from (markers are copied like bytes);
@@ -53,7 +54,12 @@ struct ParArgs {
     uint32_t* nb32;             // [nchunks][32]
     uint8_t* entry8;            // [nchunks]
     uint32_t* opos;             // [nchunks]
-    uint32_t* srcA;
+    uint8_t* gexit8;            // [ngroups][32]  the same maps for groups of 64 pieces
+    uint8_t* gstop8;            // [ngroups][32]  piece of the group in which the chain ends
+    uint32_t* gnb32;            // [ngroups][32]
+    uint8_t* gentry8;           // [ngroups]
+    uint32_t* gopos;            // [ngroups]
+    uint32_t* srcA;             // [srcn]  marker of every output byte (NONE = the byte is there), double-buffered for the jumps
     uint32_t* srcB;
 };
 
@@ -109,52 +115,85 @@ __global__ __launch_bounds__(64) void k_par_spec(ParArgs a) {
     if (have) { a.exit8[c * 32u + e] = (uint8_t)exitc; a.nb32[c * 32u + e] = nbytes; }
 }
 
-// ---- 2. the true chain through the pieces
-__global__ __launch_bounds__(64) void k_par_scan(ParArgs a) {
-    __shared__ uint8_t ex[64 * 32];
-    __shared__ uint32_t nb[64 * 32];
-    __shared__ uint8_t ent[64];
-    __shared__ uint32_t op[64];
-    __shared__ uint32_t sh_stop, sh_e, sh_bad, sh_n;
-    __shared__ uint64_t sh_acc;
+// ---- 2. the true chain through the pieces.  The maps compose: (a) every group of 64 pieces is walked from all 32 entry offsets at
+// once, (b) one wave walks the groups from the stream's first token on, (c) every group walks its pieces again from its true
+// entry offset and writes their entry offsets and output positions.  (One wave over all the pieces: 115 ns per piece, more than
+// half of the whole path.)
+constexpr uint32_t GROUP = 64;
+struct GroupLds {
+    uint8_t ex[GROUP * 32];
+    uint32_t nb[GROUP * 32];
+};
+__device__ __forceinline__ uint32_t stage_group(GroupLds& L, const ParArgs& a, uint32_t g, uint32_t lane) {
+    const uint32_t base = g * GROUP, cnt = min(GROUP, a.nchunks - base);
+    const uint32_t* ex32 = reinterpret_cast<const uint32_t*>(a.exit8 + (size_t)base * 32u);      // (256-byte aligned scratch)
+    for (uint32_t k = lane; k < cnt * 8u; k += 64u) reinterpret_cast<uint32_t*>(L.ex)[k] = ex32[k];
+    for (uint32_t k = lane; k < cnt * 32u; k += 64u) L.nb[k] = a.nb32[(size_t)base * 32u + k];
+    __syncthreads();
+    return cnt;
+}
+__global__ __launch_bounds__(64) void k_par_scan_groups(ParArgs a) {
+    __shared__ GroupLds L;
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    const uint32_t cnt = stage_group(L, a, g, lane);
+    if (lane < 32u) {
+        uint32_t e = lane, acc = 0, x = 0, j = 0;
+        for (; j < cnt; j++) {
+            x = L.ex[j * 32u + e];
+            acc += L.nb[j * 32u + e];
+            if (x & (X_EOB | X_BAD)) break;
+            e = x;
+        }
+        a.gexit8[g * 32u + lane] = (uint8_t)x;             // exit offset of the group, or where and why the chain ends in it
+        a.gstop8[g * 32u + lane] = (uint8_t)j;
+        a.gnb32[g * 32u + lane] = acc;                     // (a group makes < 64 * 175 KB)
+    }
+}
+__global__ __launch_bounds__(64) void k_par_scan_top(ParArgs a) {
     const uint32_t lane = threadIdx.x;
+    if (lane != 0u) return;
     // the stream must be one fixed block (or be read as one: the DYNAMIC=False / ONEBLOCK builds)
     const uint32_t hdr = a.zn >= 5u ? (uint32_t)a.z[2] : 0u;
     const bool fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) || ((hdr >> 1) & 3u) == 1u;
     const bool last = (a.flags & HDLZ_INFLATE_ONEBLOCK) || (hdr & 1u);
-    if (a.zn < 5u || !fixed || !last) {
-        if (lane == 0) a.ctl[C_FALLBACK] = 1u;
-        return;
+    if (a.zn < 5u || !fixed || !last) { a.ctl[C_FALLBACK] = 1u; return; }
+    const uint32_t ngroups = (a.nchunks + GROUP - 1u) / GROUP;
+    uint32_t e = 0, nused = 0;
+    uint64_t acc = 0;
+    bool stop = false, bad = false;
+    for (uint32_t g = 0; g < ngroups && !stop; g++) {
+        const uint32_t x = a.gexit8[g * 32u + e];
+        a.gentry8[g] = (uint8_t)e;
+        a.gopos[g] = (uint32_t)acc;
+        acc += a.gnb32[g * 32u + e];
+        if (x & (X_EOB | X_BAD)) { stop = true; bad = (x & X_BAD) != 0u; nused = g * GROUP + a.gstop8[g * 32u + e] + 1u; }
+        else e = x;
+        if (acc > 0xFFFFFFFFull) { bad = true; stop = true; }
     }
-    if (lane == 0) { sh_stop = 0; sh_e = 0; sh_bad = 0; sh_n = 0; sh_acc = 0; }
-    __syncthreads();
-    for (uint32_t base = 0; base < a.nchunks && sh_stop == 0u; base += 64u) {
-        const uint32_t cnt = min(64u, a.nchunks - base);
-        for (uint32_t k = lane; k < cnt * 32u; k += 64u) { ex[k] = a.exit8[base * 32u + k]; nb[k] = a.nb32[base * 32u + k]; }
-        __syncthreads();
-        if (lane == 0) {
-            uint32_t e = sh_e, n = 0;
-            uint64_t acc = sh_acc;
-            for (uint32_t j = 0; j < cnt; j++) {
-                const uint32_t x = ex[j * 32u + e];
-                ent[j] = (uint8_t)e; op[j] = (uint32_t)acc;
-                acc += nb[j * 32u + e];
-                n = j + 1u;
-                if (x & (X_EOB | X_BAD)) { sh_stop = 1u; sh_bad = x & X_BAD; break; }
-                e = x;
-            }
-            sh_e = e; sh_acc = acc; sh_n = base + n;
+    const bool good = stop && !bad && acc <= (uint64_t)a.cap && acc <= (uint64_t)a.srcn;
+    a.ctl[C_NUSED] = nused;
+    a.ctl[C_TOTAL] = (uint32_t)acc;
+    if (!good) a.ctl[C_FALLBACK] = 1u;
+}
+__global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a) {
+    __shared__ GroupLds L;
+    __shared__ uint8_t ent[GROUP];
+    __shared__ uint32_t op[GROUP];
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    if (a.ctl[C_FALLBACK] != 0u || g * GROUP >= a.ctl[C_NUSED]) return;
+    const uint32_t cnt = stage_group(L, a, g, lane);
+    if (lane == 0u) {
+        uint32_t e = a.gentry8[g], acc = a.gopos[g];
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t x = L.ex[j * 32u + e];
+            ent[j] = (uint8_t)e; op[j] = acc;
+            acc += L.nb[j * 32u + e];
+            if (x & (X_EOB | X_BAD)) break;                // (the pieces behind it are not used)
+            e = x;
         }
-        __syncthreads();
-        if (lane < cnt) { a.entry8[base + lane] = ent[lane]; a.opos[base + lane] = op[lane]; }
-        __syncthreads();
     }
-    if (lane == 0) {
-        const bool good = sh_stop != 0u && sh_bad == 0u && sh_acc <= (uint64_t)a.cap && sh_acc <= (uint64_t)a.srcn;
-        a.ctl[C_NUSED] = sh_n;
-        a.ctl[C_TOTAL] = (uint32_t)sh_acc;
-        if (!good) a.ctl[C_FALLBACK] = 1u;
-    }
+    __syncthreads();
+    if (lane < cnt) { a.entry8[g * GROUP + lane] = ent[lane]; a.opos[g * GROUP + lane] = op[lane]; }
 }
 
 // ---- 3. the real decode of one piece (wave-uniform token chain, lane-parallel copies)
@@ -274,8 +313,11 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     const uint32_t nchunks = (8u * zn - FIRST_BIT + CH_BITS - 1u) / CH_BITS;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
+    const uint32_t ngroups = (nchunks + GROUP - 1u) / GROUP;
     const size_t o_ctl = take(4u * C_WORDS), o_ex = take((size_t)nchunks * 32u), o_nb = take((size_t)nchunks * 128u),
-                 o_en = take(nchunks), o_op = take((size_t)nchunks * 4u), o_sa = take((size_t)srcn * 4u), o_sb = take((size_t)srcn * 4u);
+                 o_en = take(nchunks), o_op = take((size_t)nchunks * 4u), o_gx = take((size_t)ngroups * 32u), o_gs = take((size_t)ngroups * 32u),
+                 o_gn = take((size_t)ngroups * 128u), o_ge = take(ngroups), o_go = take((size_t)ngroups * 4u), o_sa = take((size_t)srcn * 4u),
+                 o_sb = take((size_t)srcn * 4u);
     uint8_t* ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&ws), off, stream);
     if (e != hipSuccess) return e;
@@ -283,12 +325,15 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     if (e == hipSuccess) {
         ParArgs p{a.in, zn, a.flags, a.obsize, a.out, (uint32_t)cap64, (uint32_t)srcn, a.out_len, a.status, nchunks,
                   reinterpret_cast<uint32_t*>(ws + o_ctl), ws + o_ex, reinterpret_cast<uint32_t*>(ws + o_nb), ws + o_en,
-                  reinterpret_cast<uint32_t*>(ws + o_op), reinterpret_cast<uint32_t*>(ws + o_sa), reinterpret_cast<uint32_t*>(ws + o_sb)};
+                  reinterpret_cast<uint32_t*>(ws + o_op), ws + o_gx, ws + o_gs, reinterpret_cast<uint32_t*>(ws + o_gn), ws + o_ge,
+                  reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_sa), reinterpret_cast<uint32_t*>(ws + o_sb)};
         uint32_t passes = 1;
         while ((1u << (passes - 1u)) < nchunks + 1u) passes++;         // chains of up to `nchunks` hops
         if (passes > C_WORDS - C_PASS0) passes = C_WORDS - C_PASS0;
         hipLaunchKernelGGL(k_par_spec, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p);
-        hipLaunchKernelGGL(k_par_scan, dim3(1), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_par_scan_groups, dim3(ngroups), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_par_scan_top, dim3(1), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_par_scan_pieces, dim3(ngroups), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_decode, dim3(nchunks), dim3(64), 0, stream, p);
         const uint32_t jgrid = (uint32_t)((srcn + 255u) / 256u < 8192u ? (srcn + 255u) / 256u : 8192u);
         for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(jgrid), dim3(256), 0, stream, p, j);
