@@ -249,7 +249,9 @@ __global__ __launch_bounds__(64) void k_par_decode(ParArgs a) {
         if ((uint64_t)P + tl > a.cap) { bad = true; break; }
         PAR_FLUSH_LITS();
         // COPY (deflate.py:1627-1659), lane-parallel: out[P+i] = out[P - D + (i mod D)]; a source in front of this piece's output is
-        // not there yet: the byte becomes a marker, and a marker is copied like a byte
+        // not there yet: the byte becomes a marker, and a marker is copied like a byte.  (The piece's own output is read back from
+        // memory: a 1 KiB LDS ring of bytes and markers for the near sources was measured 15 % SLOWER -- 8 waves per SIMD hide the
+        // round trip, the ring's extra LDS writes and 8 KB per wave do not pay)
         for (uint32_t i0 = 0; i0 < tl; i0 += 64u) {
             const uint32_t i = i0 + lane;
             if (i < tl) {

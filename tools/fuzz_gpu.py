@@ -124,6 +124,30 @@ def main():
                 if not ((hs2 == rs2).all() and (hl2 == rl2).all() and ((hb2 == ro2) | ~mask2).all()):
                     print("STREAMS MISMATCH it=%d seed=%d nbk=%d n=%d cw=%d mm=%d kind=%d" % (it, a.seed, nbk, nbytes_, cw, mm, kind))
                     return 1
+        # now and then: ONE large stream through STARTD (hdlz_inflate_par.hip: pieces, markers, pointer jumping -- or, for anything
+        # that is not one valid fixed block, the device-side fallback to the serial decoder): our own stream of a slice of the data,
+        # as it is, with one flipped bit, cut short, or with a tight output capacity -- status and bytes against the oracle
+        if it % 6 == 2 and total >= 60000:
+            sl_n = int(min(total, rng.integers(60000, 900000)))
+            pad_ = torch.zeros((sl_n + 15) // 16 * 16 + 16, dtype=torch.uint8, device="cuda")
+            pad_[:sl_n] = d_in[mis:mis + sl_n]
+            so, sl_, ss_ = eng.compress_stream(pad_, sl_n, cwindow=cw, maxmatch=mm)
+            zs_ = so[:int(sl_.item())].cpu().numpy().tobytes()
+            how = int(rng.integers(0, 4))
+            cap_ = sl_n + 64
+            if how == 1 and len(zs_) > 8:
+                zb_ = bytearray(zs_)
+                zb_[int(rng.integers(2, len(zb_)))] ^= 1 << int(rng.integers(0, 8))
+                zs_ = bytes(zb_)
+            elif how == 2:
+                zs_ = zs_[:int(rng.integers(len(zs_) // 2, len(zs_)))]
+            elif how == 3:
+                cap_ = max(16, (sl_n - int(rng.integers(0, 4096))) // 16 * 16)
+            st_g, out_g = eng.inflate_bytes(zs_, out_cap=cap_)
+            st_o, out_o = O.inflate(zs_, out_cap=(cap_ + 15) // 16 * 16)
+            if st_g != st_o or out_g != out_o:
+                print("SINGLE-STREAM INFLATE MISMATCH it=%d seed=%d n=%d how=%d cw=%d status %d / %d" % (it, a.seed, sl_n, how, cw, st_g, st_o))
+                return 1
         # now and then: a slice of the data through the RESUMABLE kernels (hdlz_compress_chunk / hdlz_inflate_chunk), fed in
         # random pieces with random caps on the work per call -- must equal the one-shot oracle
         if it % 3 == 1 and total >= 5:
