@@ -225,8 +225,43 @@ def main_single(a):
         torch.cuda.empty_cache()
         # -- configs[3]: inflate
         sec.append(bench_inflate(a, eng, cpu=False))
+        # -- the reference's own use: ONE stream at a time.  STARTC then STARTD on one 16 MiB stream (the most a port with LMAX = 24
+        #    holds), each on the whole GPU (k_stream_*, k_par_*)
+        sec.append(bench_single_stream(torch, eng, dev, a))
         res["secondary"] = sec
     print(json.dumps(res), flush=True)
+
+
+def bench_single_stream(torch, eng, dev, a, n=1 << 24):
+    from hdl_deflate_amd.data import make_blocks
+    d = make_blocks(n // 2048, 2048, dev, seed=5).reshape(-1)
+    out, ol, st = eng.compress_stream(d, n)
+    zn = int(ol.item())
+    assert int(st.item()) == 0
+    zin = torch.cat([out[:zn], torch.zeros(64, dtype=torch.uint8, device=dev)]).reshape(1, -1)
+    back = torch.empty((1, n), dtype=torch.uint8, device=dev)
+
+    def step_c():
+        return eng.compress_stream(d, n, out=out)
+
+    def step_d():
+        return eng.inflate_batch(zin, in_len=zn, out_pitch=n, out=back)
+
+    _, bl, bs = step_d()
+    torch.cuda.synchronize()
+    assert int(bs.item()) == 0 and int(bl.item()) == n and torch.equal(back.reshape(-1), d[:n]), "single-stream round trip failed"
+    kc = kernel_ms(torch, step_c, max(3, a.steps))
+    kd = kernel_ms(torch, step_d, max(3, a.steps))
+    ms_c, ms_d = sum(kc) / len(kc), sum(kd) / len(kd)
+    return {"name": "one 16 MiB stream", "metric": "single-stream throughput (STARTC then STARTD of ONE stream, whole GPU each)",
+            "value": round(n / ms_d / 1e3, 1), "unit": "MB/s", "ms_per_step": round(ms_d, 4), "higher_is_better": True,
+            "config": {"workload": "one stream of %d bytes (families 1-4), CWINDOW=32, MATCH10: compressed by hdlz_compress_stream, "
+                                   "inflated by hdlz_inflate_batch(nstreams = 1), round trip checked" % n,
+                       "stream_bytes": n, "compressed_bytes": zn},
+            "inflate_MBps": round(n / ms_d / 1e3, 1), "inflate_ms": round(ms_d, 4),
+            "compress_MBps": round(n / ms_c / 1e3, 1), "compress_ms": round(ms_c, 4),
+            "note": "one wave (every single stream before hdlz_inflate_par.hip): 9 MB/s; timed with HIP events around whole calls "
+                    "(all kernels of the path)"}
 
 
 # ------------------------------------------------------------------------------------------------ N > 1
