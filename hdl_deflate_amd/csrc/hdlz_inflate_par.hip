@@ -13,8 +13,8 @@
 //   3. k_par_decode  one wave per piece decodes it for real, with the reference's checks in the reference's order, and writes the
 //                    bytes -- except that the history before the piece's own output is not there yet.  A byte copied from there
 //                    becomes a MARKER: src[p] = the absolute position it comes from (markers are copied like bytes);
-//   4. k_par_jump    pointer jumping over the markers: src[p] <- src[src[p]] until the source is a byte (double-buffered, one launch
-//                    per pass, log2(pieces) + 1 passes at most; a pass with nothing left returns at once).
+//   4. k_par_jump    pointer jumping over the markers: src[p] <- eight steps along its chain, until the source is a byte (double-
+//                    buffered, one launch per pass, log8(pieces) + 1 passes at most; a pass with nothing left returns at once).
 // Anything else -- another block type, more than one block, a failed check (NO EOF, bad symbol, bad distance, capacity) -- sets
 // a fallback flag on the device and k_inflate_dyn redoes the stream from its first byte (it is launched behind the chain and
 // returns at once otherwise): status words and bytes are those of the serial decoder by construction, the parallel path
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(64) void k_par_decode(ParArgs a) {
 }
 
 // ---- 4. one pass of pointer jumping over the markers
+constexpr uint32_t HOPS = 8;
 __global__ __launch_bounds__(256) void k_par_jump(ParArgs a, uint32_t pass) {
     if (a.ctl[C_FALLBACK] != 0u) return;
     if (a.ctl[pass == 0u ? (uint32_t)C_MARK : C_PASS0 + pass - 1u] == 0u) return;            // nothing left
@@ -281,12 +282,18 @@ __global__ __launch_bounds__(256) void k_par_jump(ParArgs a, uint32_t pass) {
     uint32_t* sout = (pass & 1u) ? a.srcA : a.srcB;
     uint32_t left = 0;
     for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
-        const uint32_t m = sin[p];
+        uint32_t m = sin[p];
         uint32_t r = NONE;
         if (m != NONE) {
-            const uint32_t m2 = sin[m];
-            if (m2 == NONE) a.out[p] = a.out[m];          // (final since an earlier launch: nobody writes it in this one)
-            else { r = m2; left++; }
+            // up to HOPS steps along the chain as it was before this launch: a chain of length L is L / HOPS long afterwards
+            r = m;
+#pragma unroll 1
+            for (uint32_t h = 0; h < HOPS; h++) {
+                const uint32_t m2 = sin[m];
+                if (m2 == NONE) { a.out[p] = a.out[m]; r = NONE; break; }     // (final since an earlier launch: nobody writes it now)
+                m = m2; r = m2;
+            }
+            left += r != NONE ? 1u : 0u;
         }
         sout[p] = r;
     }
@@ -330,8 +337,8 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                   reinterpret_cast<uint32_t*>(ws + o_ctl), ws + o_ex, reinterpret_cast<uint32_t*>(ws + o_nb), ws + o_en,
                   reinterpret_cast<uint32_t*>(ws + o_op), ws + o_gx, ws + o_gs, reinterpret_cast<uint32_t*>(ws + o_gn), ws + o_ge,
                   reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_sa), reinterpret_cast<uint32_t*>(ws + o_sb)};
-        uint32_t passes = 1;
-        while ((1u << (passes - 1u)) < nchunks + 1u) passes++;         // chains of up to `nchunks` hops
+        uint32_t passes = 1;                                            // chains of up to `nchunks` hops, HOPS-fold shorter per pass
+        for (uint64_t reach = 1; reach < (uint64_t)nchunks + 1u; reach *= HOPS) passes++;
         if (passes > C_WORDS - C_PASS0) passes = C_WORDS - C_PASS0;
         hipLaunchKernelGGL(k_par_spec, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_groups, dim3(ngroups), dim3(64), 0, stream, p);
