@@ -4,7 +4,7 @@
 // One wave decoding one stream is a serial chain: ~9 MB/s (k_inflate_dyn), a fifth of what the FPGA does at 100 MHz.  A stream of ONE
 // fixed-Huffman block -- what STARTC writes (deflate.py:429-466: 78 9C, BFINAL = 1, BTYPE = 1) and all the reference's DYNAMIC=False
 // build reads -- can be cut anywhere, because a token is at most 32 bits long (9 + 5 + 5 + 13):
-//   1. k_par_spec    every 1 KiB piece of the stream is decoded from all 32 bit offsets a token can start at behind its first bit
+//   1. k_par_spec    every piece of the stream (1 KiB; less for small streams) is decoded from all 32 bit offsets a token can start at behind its first bit
 //                    (one lane per offset, two pieces per wave): per offset, where the chain leaves the piece (offset into the next
 //                    one, or EOB, or an undecodable symbol) and how many bytes it produces;
 //   2. k_par_scan_*  the 32-entry maps are walked from the stream's first token on (per group of 64 pieces for all 32 offsets, one
@@ -18,7 +18,7 @@
 // Anything else -- another block type, more than one block, a failed check (NO EOF, bad symbol, bad distance, capacity) -- sets
 // a fallback flag on the device and k_inflate_dyn redoes the stream from its first byte (it is launched behind the chain and
 // returns at once otherwise): status words and bytes are those of the serial decoder by construction, the parallel path
-// only ever reports HDLZ_OK.  Scratch (stream-ordered): 160 bytes per KiB of input and 8 bytes per possible output byte.
+// only ever reports HDLZ_OK.  Scratch (stream-ordered): 160 bytes per piece and 8 bytes per possible output byte.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
@@ -32,8 +32,10 @@ using tok::T_EOB;
 using tok::T_LEN;
 using tok::T_LIT;
 
-constexpr uint32_t CH_BITS = 8192;            // a piece: 1 KiB of the stream
-constexpr uint32_t WIN_DW = CH_BITS / 32 + 8; // its staged window: the piece, the 31 + 64 bits a token starting at its end may read
+constexpr uint32_t CH_BITS_MAX = 8192;        // a piece: 1 KiB of the stream -- 512 bytes for streams below 24 MiB, 256 below 3 MiB: a piece is ONE
+                                              // wave's serial chain in k_par_spec and k_par_decode, and 16 MiB in 1 KiB pieces do not fill the
+                                              // GPU twice (16 MiB: 1.37 -> 1.24 ms, 1 MiB: 0.76 -> 0.45 ms with 512-byte pieces)
+constexpr uint32_t WIN_DW = CH_BITS_MAX / 32 + 8; // its staged window: the piece, the 31 + 64 bits a token starting at its end may read
 constexpr uint32_t FIRST_BIT = 19;            // 2 zlib header bytes, BFINAL, BTYPE
 constexpr uint32_t X_EOB = 0x40, X_BAD = 0x80;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -49,6 +51,7 @@ struct ParArgs {
     uint32_t* out_len;
     uint32_t* status;
     uint32_t nchunks;
+    uint32_t chbits;            // bits per piece
     uint32_t* ctl;              // C_WORDS control words (zeroed)
     uint8_t* exit8;             // [nchunks][32]
     uint32_t* nb32;             // [nchunks][32]
@@ -68,9 +71,10 @@ __device__ __forceinline__ void fill_tables(uint32_t* lit, uint32_t* dst, uint32
     if (tid < 32u) dst[tid] = tok::dst_entry(tid);
 }
 // the window of piece c: stream dwords from byte B0 = (first bit of the piece / 8) & ~3 on
-__device__ __forceinline__ void stage_window(uint32_t* win, const uint8_t* z, uint32_t zn, uint32_t b_c, uint32_t tid, uint32_t nthreads) {
+__device__ __forceinline__ void stage_window(uint32_t* win, const uint8_t* z, uint32_t zn, uint32_t b_c, uint32_t chbits, uint32_t tid,
+                                             uint32_t nthreads) {
     const uint32_t B0 = (b_c >> 3) & ~3u;
-    for (uint32_t k = tid; k < WIN_DW; k += nthreads) win[k] = tok::load32(z, B0 + 4u * k, zn);
+    for (uint32_t k = tid; k < chbits / 32u + 8u; k += nthreads) win[k] = tok::load32(z, B0 + 4u * k, zn);
 }
 // 64 stream bits from absolute bit position `pos` on
 __device__ __forceinline__ uint64_t bits_at(const uint32_t* win, uint32_t b_c, uint32_t pos) {
@@ -87,8 +91,8 @@ __global__ __launch_bounds__(64) void k_par_spec(ParArgs a) {
     fill_tables(lit, dst, lane, 64u);
     const uint32_t c = blockIdx.x * 2u + half;
     const bool have = c < a.nchunks;
-    const uint32_t b_c = FIRST_BIT + c * CH_BITS, end = b_c + CH_BITS;
-    if (have) stage_window(win[half], a.z, a.zn, b_c, e, 32u);
+    const uint32_t b_c = FIRST_BIT + c * a.chbits, end = b_c + a.chbits;
+    if (have) stage_window(win[half], a.z, a.zn, b_c, a.chbits, e, 32u);
     __syncthreads();
     uint32_t pos = b_c + e, nbytes = 0, exitc = 0;
     bool run = have;
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(64) void k_par_decode(ParArgs a) {
     const uint32_t c = blockIdx.x;
     if (a.ctl[C_FALLBACK] != 0u || c >= a.ctl[C_NUSED]) return;
     fill_tables(lit, dst, lane, 64u);
-    const uint32_t b_c = FIRST_BIT + c * CH_BITS, end = b_c + CH_BITS;
-    stage_window(win, a.z, a.zn, b_c, lane, 64u);
+    const uint32_t b_c = FIRST_BIT + c * a.chbits, end = b_c + a.chbits;
+    stage_window(win, a.z, a.zn, b_c, a.chbits, lane, 64u);
     __syncthreads();
     const int32_t isize = (int32_t)a.zn - 1;              // deflate.py:605
     const uint32_t obsize = a.obsize ? a.obsize : 32768u;
@@ -320,7 +324,8 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     uint64_t srcn = (uint64_t)zn * 172u + 258u;            // a token of 13 bits makes at most 258 bytes
     if (srcn > cap64) srcn = cap64;
     if (srcn > (1ull << 30)) return hipSuccess;            // (8 GiB of scratch: leave it to the serial decoder)
-    const uint32_t nchunks = (8u * zn - FIRST_BIT + CH_BITS - 1u) / CH_BITS;
+    const uint32_t chbits = zn < (3u << 20) ? CH_BITS_MAX / 4u : zn < (24u << 20) ? CH_BITS_MAX / 2u : CH_BITS_MAX;
+    const uint32_t nchunks = (8u * zn - FIRST_BIT + chbits - 1u) / chbits;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
     const uint32_t ngroups = (nchunks + GROUP - 1u) / GROUP;
@@ -333,7 +338,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // no scratch: the caller goes on with the serial decoder
     e = hipMemsetAsync(ws + o_ctl, 0, 4u * C_WORDS, stream);
     if (e == hipSuccess) {
-        ParArgs p{a.in, zn, a.flags, a.obsize, a.out, (uint32_t)cap64, (uint32_t)srcn, a.out_len, a.status, nchunks,
+        ParArgs p{a.in, zn, a.flags, a.obsize, a.out, (uint32_t)cap64, (uint32_t)srcn, a.out_len, a.status, nchunks, chbits,
                   reinterpret_cast<uint32_t*>(ws + o_ctl), ws + o_ex, reinterpret_cast<uint32_t*>(ws + o_nb), ws + o_en,
                   reinterpret_cast<uint32_t*>(ws + o_op), ws + o_gx, ws + o_gs, reinterpret_cast<uint32_t*>(ws + o_gn), ws + o_ge,
                   reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_sa), reinterpret_cast<uint32_t*>(ws + o_sb)};
