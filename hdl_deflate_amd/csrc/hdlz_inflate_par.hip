@@ -10,9 +10,10 @@
 //   2. k_par_scan_*  the 32-entry maps are walked from the stream's first token on (per group of 64 pieces for all 32 offsets, one
 //                    wave over the groups, the pieces of every group again): the true entry offset and the output position of every
 //                    piece, the total length;
-//   3. k_par_decode  one wave per piece decodes it for real, with the reference's checks in the reference's order, and writes the
-//                    bytes -- except that the history before the piece's own output is not there yet.  A byte copied from there
-//                    becomes a MARKER: src[p] = the absolute position it comes from (markers are copied like bytes);
+//   3. k_par_tokens  one LANE per piece decodes it for real, with the reference's checks in the reference's order, into a token list;
+//      k_par_emit    one wave per piece writes the bytes, 64 tokens at a time -- except that the history before the piece's own output
+//                    is not there yet.  A byte copied from there becomes a MARKER: src[p] = the absolute position it comes from
+//                    (markers are copied like bytes);
 //   4. k_par_jump    pointer jumping over the markers: src[p] <- eight steps along its chain, until the source is a byte (double-
 //                    buffered, one launch per pass, log8(pieces) + 1 passes at most; a pass with nothing left returns at once).
 // Anything else -- another block type, more than one block, a failed check (NO EOF, bad symbol, bad distance, capacity) -- sets
@@ -62,6 +63,8 @@ struct ParArgs {
     uint32_t* gnb32;            // [ngroups][32]
     uint8_t* gentry8;           // [ngroups]
     uint32_t* gopos;            // [ngroups]
+    uint32_t* tokens;           // [nchunks][tmax_of(chbits)]  the tokens of every piece
+    uint32_t* ntok;             // [nchunks]
     uint32_t* srcA;             // [srcn]  marker of every output byte (NONE = the byte is there), double-buffered for the jumps
     uint32_t* srcB;
 };
@@ -154,30 +157,49 @@ __global__ __launch_bounds__(64) void k_par_scan_groups(ParArgs a) {
     }
 }
 __global__ __launch_bounds__(64) void k_par_scan_top(ParArgs a) {
+    __shared__ GroupLds L;                                 // (the maps of 64 GROUPS at a time, staged like a group's pieces)
+    __shared__ uint8_t stp[GROUP * 32], ent[GROUP];
+    __shared__ uint32_t op[GROUP];
+    __shared__ uint32_t sh_stop, sh_e, sh_bad, sh_nused;
+    __shared__ uint64_t sh_acc;
     const uint32_t lane = threadIdx.x;
-    if (lane != 0u) return;
     // the stream must be one fixed block (or be read as one: the DYNAMIC=False / ONEBLOCK builds)
     const uint32_t hdr = a.zn >= 5u ? (uint32_t)a.z[2] : 0u;
     const bool fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) || ((hdr >> 1) & 3u) == 1u;
     const bool last = (a.flags & HDLZ_INFLATE_ONEBLOCK) || (hdr & 1u);
-    if (a.zn < 5u || !fixed || !last) { a.ctl[C_FALLBACK] = 1u; return; }
+    if (a.zn < 5u || !fixed || !last) { if (lane == 0u) a.ctl[C_FALLBACK] = 1u; return; }
     const uint32_t ngroups = (a.nchunks + GROUP - 1u) / GROUP;
-    uint32_t e = 0, nused = 0;
-    uint64_t acc = 0;
-    bool stop = false, bad = false;
-    for (uint32_t g = 0; g < ngroups && !stop; g++) {
-        const uint32_t x = a.gexit8[g * 32u + e];
-        a.gentry8[g] = (uint8_t)e;
-        a.gopos[g] = (uint32_t)acc;
-        acc += a.gnb32[g * 32u + e];
-        if (x & (X_EOB | X_BAD)) { stop = true; bad = (x & X_BAD) != 0u; nused = g * GROUP + a.gstop8[g * 32u + e] + 1u; }
-        else e = x;
-        if (acc > 0xFFFFFFFFull) { bad = true; stop = true; }
+    if (lane == 0u) { sh_stop = 0; sh_e = 0; sh_bad = 0; sh_nused = 0; sh_acc = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < ngroups && sh_stop == 0u; base += GROUP) {
+        const uint32_t cnt = min(GROUP, ngroups - base);
+        for (uint32_t k = lane; k < cnt * 32u; k += 64u) {
+            L.ex[k] = a.gexit8[(size_t)base * 32u + k]; stp[k] = a.gstop8[(size_t)base * 32u + k]; L.nb[k] = a.gnb32[(size_t)base * 32u + k];
+        }
+        __syncthreads();
+        if (lane == 0u) {
+            uint32_t e = sh_e;
+            uint64_t acc = sh_acc;
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint32_t x = L.ex[j * 32u + e];
+                ent[j] = (uint8_t)e; op[j] = (uint32_t)acc;
+                acc += L.nb[j * 32u + e];
+                if (x & (X_EOB | X_BAD)) { sh_stop = 1u; sh_bad = x & X_BAD; sh_nused = (base + j) * GROUP + stp[j * 32u + e] + 1u; break; }
+                e = x;
+                if (acc > 0xFFFFFFFFull) { sh_stop = 1u; sh_bad = 1u; break; }
+            }
+            sh_e = e; sh_acc = acc;
+        }
+        __syncthreads();
+        if (lane < cnt) { a.gentry8[base + lane] = ent[lane]; a.gopos[base + lane] = op[lane]; }
+        __syncthreads();
     }
-    const bool good = stop && !bad && acc <= (uint64_t)a.cap && acc <= (uint64_t)a.srcn;
-    a.ctl[C_NUSED] = nused;
-    a.ctl[C_TOTAL] = (uint32_t)acc;
-    if (!good) a.ctl[C_FALLBACK] = 1u;
+    if (lane == 0u) {
+        const bool good = sh_stop != 0u && sh_bad == 0u && sh_acc <= (uint64_t)a.cap && sh_acc <= (uint64_t)a.srcn;
+        a.ctl[C_NUSED] = sh_nused;
+        a.ctl[C_TOTAL] = (uint32_t)sh_acc;
+        if (!good) a.ctl[C_FALLBACK] = 1u;
+    }
 }
 __global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a) {
     __shared__ GroupLds L;
@@ -200,80 +222,136 @@ __global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a) {
     if (lane < cnt) { a.entry8[g * GROUP + lane] = ent[lane]; a.opos[g * GROUP + lane] = op[lane]; }
 }
 
-// ---- 3. the real decode of one piece (wave-uniform token chain, lane-parallel copies)
-__global__ __launch_bounds__(64) void k_par_decode(ParArgs a) {
-    __shared__ uint32_t lit[512], dst[32], win[WIN_DW];
+// ---- 3a. the real decode, tokens only: one LANE per piece (64 pieces per wave), the reference's checks
+// in the reference's order, the tokens into a list per piece.  (One WAVE per piece decoding and copying kept the CU's one scalar unit
+// 89 % busy -- the token chain of a piece is wave-uniform, 115 scalar instructions per token: 8.2 of 13.7 ms at 256 MiB.)
+constexpr uint32_t TOK_LIT = 0x80000000u;     // a token: TOK_LIT | byte, or length | distance << 9
+__host__ __device__ inline uint32_t tmax_of(uint32_t chbits) { return chbits / 8u + 2u; }      // the shortest token is 8 bits long
+__global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
+    __shared__ uint32_t lit[512], dst[32];
     const uint32_t lane = threadIdx.x;
-    const uint32_t c = blockIdx.x;
-    if (a.ctl[C_FALLBACK] != 0u || c >= a.ctl[C_NUSED]) return;
+    if (a.ctl[C_FALLBACK] != 0u) return;
+    const uint32_t nused = a.ctl[C_NUSED], c0 = blockIdx.x * 64u;
+    if (c0 >= nused) return;
     fill_tables(lit, dst, lane, 64u);
-    const uint32_t b_c = FIRST_BIT + c * a.chbits, end = b_c + a.chbits;
-    stage_window(win, a.z, a.zn, b_c, a.chbits, lane, 64u);
     __syncthreads();
+    const uint32_t c = c0 + lane;
+    const bool have = c < nused;
     const int32_t isize = (int32_t)a.zn - 1;              // deflate.py:605
     const uint32_t obsize = a.obsize ? a.obsize : 32768u;
+    const uint32_t b_c = FIRST_BIT + c * a.chbits, end = b_c + a.chbits;
+    uint32_t pos = have ? b_c + a.entry8[c] : 0u, P = have ? a.opos[c] : 0u;
+    uint32_t* tk = a.tokens + (size_t)c * tmax_of(a.chbits);
+    // bit reader straight from the stream (64 KB of LDS windows per wave left two waves per CU and every LDS / store round trip
+    // exposed: 2.9 ms at 256 MiB): bb holds bc valid bits from `pos` on, `nxt` is the dword behind them, requested a refill ahead
+    uint32_t ip = (pos >> 3) & ~3u, bc = 64u - (pos - 8u * ip), n = 0;
+    uint64_t bb = have ? (((uint64_t)tok::load32(a.z, ip + 4u, a.zn) << 32) | tok::load32(a.z, ip, a.zn)) >> (pos - 8u * ip) : 0ull;
+    ip += 8u;
+    uint32_t nxt = have ? tok::load32(a.z, ip, a.zn) : 0u;
+    bool run = have, bad = false;
+    while (__ballot(run) != 0ull) {
+        if (run) {
+            if (bc <= 32u) { bb |= (uint64_t)nxt << bc; bc += 32u; ip += 4u; nxt = tok::load32(a.z, ip, a.zn); }    // (a token: <= 32 bits)
+            const uint32_t e0 = lit[(uint32_t)bb & 511u];
+            const uint32_t nb = e0 & 15u, code = (e0 >> 4) & 0x1FFu;
+            uint32_t used = nb;
+            if (nb < 1u) { bad = true; run = false; }                                            // zero leaf: BAD_SYMBOL
+            else if ((int32_t)((pos + nb) >> 3) > isize - 3) { bad = true; run = false; }        // NO EOF, deflate.py:1535-1539
+            else if (code == 256u) run = false;                                                  // D6: the stream ends here
+            else if (code < 256u) {
+                if (P >= a.cap) { bad = true; run = false; }
+                else { tk[n++] = TOK_LIT | code; P++; }
+            } else if (code - 257u >= 29u) { bad = true; run = false; }                          // BAD_SYMBOL
+            else {
+                const uint32_t leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
+                uint64_t y = bb >> nb;
+                const uint32_t tl = lbase + ((uint32_t)y & ((1u << leb) - 1u));
+                y >>= leb;
+                const uint32_t de = dst[(uint32_t)y & 31u];
+                const uint32_t deb = (de >> 16) & 15u;
+                const uint32_t D = (de & 0xFFFFu) + ((uint32_t)(y >> 5) & ((1u << deb) - 1u));
+                used = nb + leb + 5u + deb;
+                if (de == 0xFFFFFFFFu) { bad = true; run = false; }                              // BAD_DISTANCE (codes 30, 31)
+                else if (D > P || D > obsize) { bad = true; run = false; }                       // D8
+                else if ((int32_t)((pos + used) >> 3) >= isize - 2) { bad = true; run = false; } // COPY hold, deflate.py:1600
+                else if ((uint64_t)P + tl > a.cap) { bad = true; run = false; }
+                else { tk[n++] = tl | (D << 9); P += tl; }
+            }
+            pos += used; bb >>= used; bc -= used;
+            if (pos >= end) run = false;
+        }
+    }
+    if (have) a.ntok[c] = n;
+    if (__ballot(bad) != 0ull && lane == 0u) atomicExch(&a.ctl[C_FALLBACK], 1u);
+}
+
+// ---- 3b. the bytes: one wave per piece, 64 tokens at a time -- a wave scan gives every token its output position, the literals are
+// written in parallel, the copies in stream order (lane-parallel inside each copy).  The history in front of the piece's own output is
+// not there yet: a byte copied from there becomes a MARKER (src[p] = the absolute position it comes from), and a marker is copied like
+// a byte.  The piece's newest output lives in an LDS ring of bytes and markers too: the copies are a chain of round trips now.
+constexpr uint32_t HRING = 2048;
+constexpr uint32_t SPAN = 768;                // a batch ends with the token that takes its output beyond this many bytes (literals are
+                                              // written ahead of the copies in front of them)
+constexpr uint32_t HREACH = HRING - SPAN - 258u - 128u;   // distances served from the ring: nothing written ahead may alias them
+__global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
+    __shared__ uint8_t hb[HRING];
+    __shared__ uint32_t hm[HRING];
+    const uint32_t lane = threadIdx.x, c = blockIdx.x;
+    if (a.ctl[C_FALLBACK] != 0u || c >= a.ctl[C_NUSED]) return;
+    const uint32_t n = a.ntok[c];
+    const uint32_t* tk = a.tokens + (size_t)c * tmax_of(a.chbits);
     const uint32_t cstart = a.opos[c];
-    uint32_t P = cstart;                                  // output position behind the pending literals
-    uint32_t pos = b_c + a.entry8[c];
     uint8_t* out = a.out;
     uint32_t* src = a.srcA;
-    uint32_t litv = 0, nlit = 0, nmark = 0;               // lane k holds the k-th pending literal
-    bool bad = false;
-#define PAR_FLUSH_LITS() do {                                                                 \
-        if (lane < nlit) { out[P - nlit + lane] = (uint8_t)litv; src[P - nlit + lane] = NONE; } \
-        nlit = 0;                                                                               \
-    } while (0)
-    while (pos < end) {
-        const uint64_t x = bits_at(win, b_c, (uint32_t)__builtin_amdgcn_readfirstlane((int)pos));
-        const uint32_t e0 = lit[(uint32_t)x & 511u];
-        const uint32_t nb = e0 & 15u, code = (e0 >> 4) & 0x1FFu;
-        if (nb < 1u) { bad = true; break; }                                              // zero leaf: BAD_SYMBOL
-        pos += nb;
-        if ((int32_t)(pos >> 3) > isize - 3) { bad = true; break; }                      // NO EOF, deflate.py:1535-1539
-        if (code == 256u) break;                                                         // D6: the stream ends here
-        if (code < 256u) {
-            if (P >= a.cap) { bad = true; break; }
-            litv = lane == nlit ? code : litv;
-            nlit++; P++;
-            if (nlit == 64u) PAR_FLUSH_LITS();
-            continue;
+    uint32_t Pb = cstart, nmark = 0;
+    for (uint32_t base = 0; base < n;) {
+        const uint32_t k = base + lane;
+        const uint32_t t = k < n ? tk[k] : 0u;
+        const bool islit = (t >> 31) != 0u;
+        const uint32_t len = k < n ? (islit ? 1u : (t & 511u)) : 0u;
+        uint32_t incl = len;
+#pragma unroll
+        for (int ofs = 1; ofs < 64; ofs <<= 1) {
+            const uint32_t o = __shfl_up(incl, ofs, 64);
+            if (lane >= (uint32_t)ofs) incl += o;
         }
-        if (code - 257u >= 29u) { bad = true; break; }                                   // BAD_SYMBOL
-        const uint32_t leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
-        uint64_t y = x >> nb;
-        const uint32_t tl = lbase + ((uint32_t)y & ((1u << leb) - 1u));
-        y >>= leb;
-        const uint32_t de = dst[(uint32_t)y & 31u];
-        if (de == 0xFFFFFFFFu) { bad = true; break; }                                    // BAD_DISTANCE (codes 30, 31)
-        const uint32_t deb = (de >> 16) & 15u;
-        const uint32_t D = (de & 0xFFFFu) + ((uint32_t)(y >> 5) & ((1u << deb) - 1u));
-        pos += leb + 5u + deb;
-        if (D > P || D > obsize) { bad = true; break; }                                  // D8
-        if ((int32_t)(pos >> 3) >= isize - 2) { bad = true; break; }                     // COPY hold, deflate.py:1600
-        if ((uint64_t)P + tl > a.cap) { bad = true; break; }
-        PAR_FLUSH_LITS();
-        // COPY (deflate.py:1627-1659), lane-parallel: out[P+i] = out[P - D + (i mod D)]; a source in front of this piece's output is
-        // not there yet: the byte becomes a marker, and a marker is copied like a byte.  (The piece's own output is read back from
-        // memory: a 1 KiB LDS ring of bytes and markers for the near sources was measured 15 % SLOWER -- 8 waves per SIMD hide the
-        // round trip, the ring's extra LDS writes and 8 KB per wave do not pay)
-        const bool wrap = (uint32_t)__builtin_amdgcn_readfirstlane((int)(D < tl ? 1u : 0u)) != 0u;   // (an overlapping copy: rare, and a division)
-        for (uint32_t i0 = 0; i0 < tl; i0 += 64u) {
-            const uint32_t i = i0 + lane;
-            if (i < tl) {
-                const uint32_t s = P - D + (wrap ? i % D : i);
-                uint32_t m = s, v = 0;
-                if (s >= cstart) { m = src[s]; v = out[s]; }
-                out[P + i] = (uint8_t)v;
-                src[P + i] = m;
-                nmark += m != NONE ? 1u : 0u;
+        // the batch: the leading tokens up to the first one that ends beyond SPAN bytes (that one included)
+        const uint64_t over = __ballot(k < n && incl > SPAN);
+        const uint32_t cnt = min(over != 0ull ? (uint32_t)__builtin_ctzll(over) + 1u : 64u, n - base);
+        const bool mine = lane < cnt;
+        const uint32_t P = Pb + incl - len;
+        if (mine && islit) {
+            out[P] = (uint8_t)t; src[P] = NONE;
+            hb[P & (HRING - 1u)] = (uint8_t)t; hm[P & (HRING - 1u)] = NONE;
+        }
+        uint64_t mm = __ballot(mine && !islit);
+        while (mm != 0ull) {
+            const int j = __builtin_ctzll(mm);
+            mm &= mm - 1ull;
+            const uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, j);
+            const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)t, j);
+            const uint32_t tl = tj & 511u, D = tj >> 9;
+            // COPY (deflate.py:1627-1659): out[Pj+i] = out[Pj - D + (i mod D)]
+            const bool near = D <= HREACH && Pj - cstart >= D;            // the whole source is this piece's own, recent output
+            for (uint32_t i0 = 0; i0 < tl; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                if (i < tl) {
+                    uint32_t s = Pj - D + i;
+                    if (D < tl) s = Pj - D + i % D;                        // (an overlapping copy -- wave-uniform branch: a division)
+                    uint32_t m = s, v = 0;
+                    if (near) { m = hm[s & (HRING - 1u)]; v = hb[s & (HRING - 1u)]; }
+                    else if (s >= cstart) { m = src[s]; v = out[s]; }
+                    out[Pj + i] = (uint8_t)v;
+                    src[Pj + i] = m;
+                    hb[(Pj + i) & (HRING - 1u)] = (uint8_t)v; hm[(Pj + i) & (HRING - 1u)] = m;
+                    nmark += m != NONE ? 1u : 0u;
+                }
             }
         }
-        P += tl;
+        Pb += (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
+        base += cnt;
     }
-    PAR_FLUSH_LITS();
-#undef PAR_FLUSH_LITS
-    if (bad) { if (lane == 0) atomicExch(&a.ctl[C_FALLBACK], 1u); }
-    else if (nmark) atomicAdd(&a.ctl[C_MARK], nmark);
+    if (nmark) atomicAdd(&a.ctl[C_MARK], nmark);
 }
 
 // ---- 4. one pass of pointer jumping over the markers
@@ -331,7 +409,8 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     const uint32_t ngroups = (nchunks + GROUP - 1u) / GROUP;
     const size_t o_ctl = take(4u * C_WORDS), o_ex = take((size_t)nchunks * 32u), o_nb = take((size_t)nchunks * 128u),
                  o_en = take(nchunks), o_op = take((size_t)nchunks * 4u), o_gx = take((size_t)ngroups * 32u), o_gs = take((size_t)ngroups * 32u),
-                 o_gn = take((size_t)ngroups * 128u), o_ge = take(ngroups), o_go = take((size_t)ngroups * 4u), o_sa = take((size_t)srcn * 4u),
+                 o_gn = take((size_t)ngroups * 128u), o_ge = take(ngroups), o_go = take((size_t)ngroups * 4u),
+                 o_tk = take((size_t)nchunks * tmax_of(chbits) * 4u), o_nt = take((size_t)nchunks * 4u), o_sa = take((size_t)srcn * 4u),
                  o_sb = take((size_t)srcn * 4u);
     uint8_t* ws = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&ws), off, stream);
@@ -341,7 +420,8 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         ParArgs p{a.in, zn, a.flags, a.obsize, a.out, (uint32_t)cap64, (uint32_t)srcn, a.out_len, a.status, nchunks, chbits,
                   reinterpret_cast<uint32_t*>(ws + o_ctl), ws + o_ex, reinterpret_cast<uint32_t*>(ws + o_nb), ws + o_en,
                   reinterpret_cast<uint32_t*>(ws + o_op), ws + o_gx, ws + o_gs, reinterpret_cast<uint32_t*>(ws + o_gn), ws + o_ge,
-                  reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_sa), reinterpret_cast<uint32_t*>(ws + o_sb)};
+                  reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_tk), reinterpret_cast<uint32_t*>(ws + o_nt),
+                  reinterpret_cast<uint32_t*>(ws + o_sa), reinterpret_cast<uint32_t*>(ws + o_sb)};
         uint32_t passes = 1;                                            // chains of up to `nchunks` hops, HOPS-fold shorter per pass
         for (uint64_t reach = 1; reach < (uint64_t)nchunks + 1u; reach *= HOPS) passes++;
         if (passes > C_WORDS - C_PASS0) passes = C_WORDS - C_PASS0;
@@ -349,7 +429,8 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         hipLaunchKernelGGL(k_par_scan_groups, dim3(ngroups), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_top, dim3(1), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_pieces, dim3(ngroups), dim3(64), 0, stream, p);
-        hipLaunchKernelGGL(k_par_decode, dim3(nchunks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_par_tokens, dim3((nchunks + 63u) / 64u), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_par_emit, dim3(nchunks), dim3(64), 0, stream, p);
         const uint32_t jgrid = (uint32_t)((srcn + 255u) / 256u < 8192u ? (srcn + 255u) / 256u : 8192u);
         for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(jgrid), dim3(256), 0, stream, p, j);
         hipLaunchKernelGGL(k_par_finish, dim3(1), dim3(64), 0, stream, p, passes);

