@@ -30,11 +30,10 @@ namespace par {
 
 using tok::T_BAD;
 using tok::T_EOB;
-using tok::T_LEN;
 using tok::T_LIT;
 
 constexpr uint32_t CH_BITS_MAX = 8192;        // a piece: 1 KiB of the stream -- 512 bytes for streams below 24 MiB, 256 below 3 MiB: a piece is ONE
-                                              // wave's serial chain in k_par_spec and k_par_decode, and 16 MiB in 1 KiB pieces do not fill the
+                                              // wave's (lane's) serial chain in k_par_spec and k_par_tokens, and 16 MiB in 1 KiB pieces do not fill the
                                               // GPU twice (16 MiB: 1.37 -> 1.24 ms, 1 MiB: 0.76 -> 0.45 ms with 512-byte pieces)
 constexpr uint32_t WIN_DW = CH_BITS_MAX / 32 + 8; // its staged window: the piece, the 31 + 64 bits a token starting at its end may read
 constexpr uint32_t FIRST_BIT = 19;            // 2 zlib header bytes, BFINAL, BTYPE
