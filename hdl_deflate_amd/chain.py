@@ -72,8 +72,15 @@ def inflate_chained(engine, archive, offsets, block=8 << 20, flags=0):
     """inverse of compress_chained -> flat uint8 device tensor (every stream must inflate to at most `block` bytes)"""
     B = offsets.numel() - 1
     padded = torch.cat([archive, torch.zeros(64, dtype=torch.uint8, device=archive.device)])
-    out, ol, st = engine.inflate_batch(padded, in_off=offsets.contiguous(), out_pitch=(block + 15) // 16 * 16, flags=flags)
-    if int((st != OK).sum().item()):
-        raise Error("inflate_chained: a stream failed")
-    lens = ol.tolist()
-    return torch.cat([out[b, :lens[b]] for b in range(B)])
+    offs = offsets.tolist()
+    pitch = (block + 15) // 16 * 16
+    parts = []
+    # stream by stream: ONE large stream is decoded by the whole GPU (hdlz_inflate_par.hip); a batch of a few large streams would
+    # get one wave each (9 MB/s per stream)
+    for b in range(B):
+        zn = offs[b + 1] - offs[b]
+        out, ol, st = engine.inflate_batch(padded[offs[b]:offs[b] + zn + 64].view(1, -1), in_len=zn, out_pitch=pitch, flags=flags)
+        if int(st.item()) != OK:
+            raise Error("inflate_chained: a stream failed")
+        parts.append(out[0, :int(ol.item())])
+    return torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device=archive.device)
