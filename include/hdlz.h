@@ -71,7 +71,8 @@ enum {
 #define HDLZ_INFLATE_DYN_LANE_MIN 20480u
 /* a batch of ONE stream of at least this many bytes (fixed-pitch form, no mapping hint) is cut into 1 KiB pieces and decoded by
  * the whole GPU when it is a single fixed-Huffman block -- the streams STARTC writes --, else by one wave as before (decided on
- * the device, same results); scratch: stream-ordered, 8 bytes per possible output byte (min(out_pitch, 172 * in_len)) */
+ * the device, same results); scratch: stream-ordered, 8 bytes per possible output byte (min(out_pitch, 172 * in_len)).
+ * A batch of a FEW such streams (fixed pitch, nstreams * 2 KiB <= in_len) goes through the same path stream by stream. */
 #define HDLZ_INFLATE_PAR_MIN 16384u
 /* lane-per-stream kernel variant (results are identical): the default and 16 = one token per round (k_inflate_tok),
  * 32 = one output byte per lockstep iteration (k_inflate, the round-1 kernel) */

@@ -118,6 +118,26 @@ def test_everything_else_falls_back_with_the_serial_status(engine, oracle):
     _check(engine, oracle, _zfixed(_text(600000, 11), wbits=9), 1 << 20, obsize=512)
 
 
+def test_a_few_large_streams_in_one_batch(engine, oracle):
+    """fixed-pitch batches of a few large streams (nstreams * 2 KiB <= in_len) take the same path stream by stream: good ones, a
+    damaged one and a dynamic one in the same batch, every stream against the oracle"""
+    import torch
+    zs = [_zfixed(_text(100000 + 3000 * k, 20 + k), level=9) for k in range(6)]
+    zb = bytearray(zs[2]); zb[len(zb) // 2] ^= 0x10; zs[2] = bytes(zb)
+    zs[4] = zlib.compress(_text(120000, 30), 6)
+    pitch = (max(len(z) for z in zs) + 64 + 15) // 16 * 16
+    host = np.zeros((len(zs), pitch), np.uint8)
+    for k, z in enumerate(zs):
+        host[k, :len(z)] = np.frombuffer(z, np.uint8)
+    for in_len in (pitch,):                                # (every stream is followed by zero padding: ignored, D6)
+        out, ol, st = engine.inflate_batch(torch.from_numpy(host).cuda(), in_len=in_len, out_pitch=131072)
+        out, ol, st = out.cpu().numpy(), ol.cpu().numpy(), st.cpu().numpy()
+        for k, z in enumerate(zs):
+            rc, ref = oracle.inflate(host[k, :in_len].tobytes(), out_cap=131072)
+            assert st[k] == rc and out[k, :ol[k]].tobytes() == ref, (k, int(st[k]), rc)
+    assert st[0] == 0 and st[4] == 0
+
+
 def test_single_stream_inside_a_hip_graph(engine, oracle):
     import torch
     z = _zfixed(_text(400000, 12))
