@@ -41,7 +41,7 @@ namespace hdlz {
 // wave-tile (N <= 2048: BASELINE configs[1]'s block size and the reference's own IBSIZE scale) -- no tile loop, no halo
 // carried from a previous tile, no carried bit / Adler state
 template <int NCH, bool FULLWIN, bool ONE_TILE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? HDLZ_W1 : 4, NCH == 1 ? HDLZ_W1 : 4))) void k_compress(CompressArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? HDLZ_W1 : NCH == 2 ? HDLZ_W2 : 4, NCH == 1 ? HDLZ_W1 : NCH == 2 ? HDLZ_W2 : 4))) void k_compress(CompressArgs a) {
     __shared__ WaveLds lds;
     const uint32_t lane = threadIdx.x;
 

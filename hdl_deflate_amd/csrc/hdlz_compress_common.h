@@ -9,6 +9,9 @@
 namespace hdlz {
 
 // waves per SIMD the CWINDOW <= 32 kernels are register-capped for (96 VGPRs at 5)
+#ifndef HDLZ_W2
+#define HDLZ_W2 4                             // waves per SIMD of the CWINDOW = 64 kernels
+#endif
 #ifndef HDLZ_W1
 #define HDLZ_W1 5
 #endif
@@ -124,6 +127,57 @@ __device__ __forceinline__ void load_own(const uint32_t* in, uint32_t run_dw, ui
 // bytes are the register peak of the whole kernel; later phases reload the 48 bytes from LDS, three ds_read_b128.)
 template <int NCH>
 __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw, uint32_t (&best)[RUN]) {
+#ifndef HDLZ_CW64_TWO_PASSES
+    if constexpr (NCH == 2) {
+        // CWINDOW = 64 in ONE pass: with the tag at scale 2 (2 * window index <= 190) the 95 candidate positions of a run fit the
+        // key's tag byte, so there is no second chunk, no best[] beside the running minima and no set-up twice.  Own index i pairs
+        // with candidates j in [i, i + 63]; candidate j >= 64 IS own position j - 64 (same tag 2j); the minimum is 2 * distance.
+        uint32_t ko[RUN], cd[17];
+        {
+            uint32_t ow[12];
+            load_own(in, run_dw, ow);
+            static_for<0, RUN>([&](auto I) { constexpr int i = decltype(I)::value; ko[i] = key3<i>(ow, (uint32_t)(2 * (i + 64))); });
+            const uint32_t cdw = run_dw - 16u;
+            const uint4 c0 = *reinterpret_cast<const uint4*>(&in[cdw]), c1 = *reinterpret_cast<const uint4*>(&in[cdw + 4]);
+            const uint4 c2 = *reinterpret_cast<const uint4*>(&in[cdw + 8]), c3 = *reinterpret_cast<const uint4*>(&in[cdw + 12]);
+            cd[0] = c0.x; cd[1] = c0.y; cd[2] = c0.z; cd[3] = c0.w; cd[4] = c1.x; cd[5] = c1.y; cd[6] = c1.z; cd[7] = c1.w;
+            cd[8] = c2.x; cd[9] = c2.y; cd[10] = c2.z; cd[11] = c2.w; cd[12] = c3.x; cd[13] = c3.y; cd[14] = c3.z; cd[15] = c3.w;
+            cd[16] = ow[0];                                   // candidate 63 needs the first own bytes
+        }
+        pin(ko);
+        PHASE_FENCE();
+        uint32_t (&m)[RUN] = best;
+#pragma unroll
+        for (int i = 0; i < RUN; i++) m[i] = 0xFFFFFFFFu;
+        static_for<0, 95>([&](auto J) {
+            constexpr int j = decltype(J)::value;             // handles candidates j and j+1 (j even)
+            if constexpr ((j & 1) == 0) {
+                uint32_t kc0, kc1;
+                if constexpr (j >= 64) {
+                    asm volatile("" : "+v"(ko[j - 64]), "+v"(ko[j - 63 > 31 ? 31 : j - 63]));
+                    kc0 = ko[j - 64];
+                    kc1 = ko[j - 63 > 31 ? 31 : j - 63];
+                } else {
+                    kc0 = key3<j>(cd, (uint32_t)(2 * j));
+                    kc1 = key3<j + 1>(cd, (uint32_t)(2 * (j + 1)));
+                }
+                static_for<0, RUN>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    constexpr bool use0 = (j >= i) && (j <= i + 63);
+                    constexpr bool use1 = (j + 1 >= i) && (j + 1 <= i + 63);
+                    if constexpr (use0 && use1) m[i] = umin3(m[i], ko[i] - kc0, ko[i] - kc1);
+                    else if constexpr (use0) m[i] = min(m[i], ko[i] - kc0);
+                    else if constexpr (use1) m[i] = min(m[i], ko[i] - kc1);
+                });
+                if constexpr ((j & 7) == 6) { pin(m); PHASE_FENCE(); }
+            }
+        });
+        // 2 * distance -> the 4 * distance make_tokens reads; "none" (>= 256) -> a value its position test rejects
+#pragma unroll
+        for (int i = 0; i < RUN; i++) best[i] = m[i] < 256u ? m[i] << 1 : 0xFFFFFFFFu;
+        return;
+    }
+#endif
     uint32_t ko[RUN];
     uint32_t ow0;
     {
