@@ -25,6 +25,8 @@ constexpr int OUT_WORDS = 592;      // 9 bits * 2048 = 576 words + carry word + 
 constexpr int LUT_LIT = 256;        // [byte]                                  at LUT word 0
 constexpr int LUT_MATCH = 256;      // [len-3][dist-1] (CWINDOW <= 32) or [dist-1]  at LUT word 256
 constexpr uint32_t LUT_MATCH_BYTE = 4u * LUT_LIT;
+constexpr int LUT_LEN = 16;         // [len-1] -> the length code (wide windows: the match LUT is [dist-1] only)   at LUT word 512
+constexpr uint32_t LUT_LEN_BYTE = 4u * (LUT_LIT + LUT_MATCH);
 constexpr uint32_t ADLER_MOD = 65521u;
 constexpr uint32_t NB_SHIFT = 27;   // LUT entry = code (27 bits) | nbits << 27
 constexpr uint32_t CODE_MASK = (1u << NB_SHIFT) - 1u;
@@ -32,7 +34,7 @@ constexpr uint32_t CODE_MASK = (1u << NB_SHIFT) - 1u;
 struct __attribute__((aligned(16))) WaveLds {
     uint32_t in[IN_BYTES / 4];      // byte index = position - tile_start + HALO
     uint32_t out[OUT_WORDS];        // bit buffer of the current tile
-    uint32_t lut[LUT_LIT + LUT_MATCH];
+    uint32_t lut[LUT_LIT + LUT_MATCH + LUT_LEN];
 };
 
 // fence for the instruction scheduler + value fences: keep independent phases from being overlapped
@@ -375,8 +377,8 @@ __device__ __forceinline__ uint32_t token_codes(const uint8_t* lut8, uint32_t (&
         const uint32_t lenm1 = tok[i] >> 16;
         c = start ? lenm1 : (c - 1u);
         uint32_t ee = e;
-        if constexpr (NCH != 1)                               // wide windows: [dist] LUT + computed length code
-            ee |= lenm1 ? (__builtin_bitreverse32(lenm1 - 1u) >> 25) : 0u;
+        if constexpr (NCH != 1)                               // wide windows: [dist] LUT + the length code from its own small LUT
+            ee |= *reinterpret_cast<const uint32_t*>(lut8 + LUT_LEN_BYTE + 4u * lenm1);     // (computed: six VALU instructions per position)
         code[i] = start ? ee : 0u;
         lane_bits += code[i] >> NB_SHIFT;
         if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(code); asm volatile("" : "+v"(c), "+v"(lane_bits)); PHASE_FENCE(); }
@@ -427,6 +429,7 @@ __device__ __forceinline__ void fill_luts(uint32_t* lut, uint32_t lane) {
         if (NCH == 1) lut[LUT_LIT + e] = dist_entry((e & 31u) + 1u) | length_code((e >> 5) + 3u);
         else lut[LUT_LIT + e] = dist_entry(e + 1u);
     }
+    if (lane < (uint32_t)LUT_LEN) lut[LUT_LIT + LUT_MATCH + lane] = lane ? length_code(lane + 1u) : 0u;      // index len-1; 0: a literal
 }
 
 // one 16-byte chunk of a block at position p (p < n), from a source of any alignment; bytes at or beyond n read as zero
