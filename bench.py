@@ -11,7 +11,8 @@ STARTC (CWINDOW=32, MATCH10, static tree), whole job, plus the compression ratio
     * configs[2]: CWINDOW=64 + MATCH10 on 64 KiB blocks of Zipf pseudo-English (enwik8 is not obtainable:
       no network), next to CWINDOW=32 on the same data (ratio vs throughput)
     * configs[3]: inflate of 2^20 stock-zlib Z_FIXED streams, DYNAMIC=False semantics, every stream checked
---gpus N > 1 (one rank per GPU, launched by torch.distributed.run).  BASELINE configs[4] as written: the 8 GiB
+--gpus N > 1 (one rank per GPU; launched by torch.distributed.run, or plainly as `python3 bench.py --gpus N`, which starts
+  its own N ranks).  BASELINE configs[4] as written: the 8 GiB
   job of 131 072 x 64 KiB blocks is split into contiguous shards of B/N blocks (shard.shard_range); a step =
   the rank's hdlz_compress_batch launch + the RCCL all-gather of the uint32[B/N] output lengths
   (SURVEY 8(e)); STRONG scaling: total work is fixed, value = 8 GiB / max-over-ranks step time.
@@ -33,6 +34,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+METRIC_C32 = "compress_input_throughput (CWINDOW=32, MATCH10=True, static tree)"
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 CFG5_BLOCKS, CFG5_BLOCK = 131072, 65536          # BASELINE configs[4]: 8 GiB of 64 KiB blocks
 
@@ -55,14 +57,19 @@ def kname_for(cwindow, n=1 << 16):
     return "k_compress<%d, %s, %s>" % (nch, "true" if cwindow == 32 * nch else "false", "true" if (nch == 1 and n <= 2048) else "false")
 
 
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
 def roofline(kname, algo_bytes, k_ms, traffic_key=None, extra=None):
     k_avg = sum(k_ms) / len(k_ms)
     achieved = algo_bytes / (k_avg * 1e-3) / 1e9
     traffic, tsrc = measured_traffic(traffic_key) if traffic_key else (None, None)
     r = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg, 4), "kernel_ms_min": round(min(k_ms), 4),
-         "launches_timed": len(k_ms)}
+         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg, 4), "kernel_ms_median": round(median(k_ms), 4),
+         "kernel_ms_min": round(min(k_ms), 4), "launches_timed": len(k_ms)}
     if extra:
         r.update(extra)
     return r
@@ -125,12 +132,51 @@ def run_compress(torch, eng, d_in, cwindow, maxmatch, steps, warmup, verify, d_o
         return eng.compress_batch(d_in, cwindow=cwindow, maxmatch=maxmatch, out=d_out, out_pitch=pitch)
 
     dt, (out, ol, st) = time_steps(torch, None, step, steps, warmup, 1, None)
-    k_ms = kernel_ms(torch, step, max(3, steps))
+    k_ms = kernel_ms(torch, step, max(10, steps))
     assert int((st != 0).sum().item()) == 0, "blocks failed"
     out_bytes = int(ol.to(torch.int64).sum().item())
     if verify:
         zlib_spot_check(torch, d_in, d_out, ol, verify)
     return {"dt": dt, "k_ms": k_ms, "in_bytes": B * n, "out_bytes": out_bytes, "B": B, "n": n, "d_out": d_out, "ol": ol}
+
+
+def end_to_end(torch, eng, d_in, r, cwindow, maxmatch, reps=3):
+    """SURVEY 8(d) "Timing": the same job INCLUDING the PCIe hops -- pinned host input -> HBM, the launch, pitched output rows +
+    lengths -> pinned host memory, all on the launch stream; reported beside the metric, never as `value`"""
+    from hdl_deflate_amd.constants import pitch_for
+    B, n = d_in.shape
+    pitch = pitch_for(n)
+    d_out, ol = r["d_out"], r["ol"]
+    h_in = torch.empty((B, n), dtype=torch.uint8, pin_memory=True)
+    h_in.copy_(d_in)
+    h_out = torch.empty((B, pitch), dtype=torch.uint8, pin_memory=True)
+    h_len = torch.empty(B, dtype=ol.dtype, pin_memory=True)
+    d_stage = torch.empty_like(d_in)
+    tot, h2d, d2h = [], [], []
+    for _ in range(reps + 1):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev[0].record()
+        d_stage.copy_(h_in, non_blocking=True)
+        ev[1].record()
+        _, ol2, _ = eng.compress_batch(d_stage, cwindow=cwindow, maxmatch=maxmatch, out=d_out, out_pitch=pitch)
+        ev[2].record()
+        h_out.copy_(d_out, non_blocking=True)
+        h_len.copy_(ol2, non_blocking=True)
+        ev[3].record()
+        torch.cuda.synchronize()
+        tot.append((time.perf_counter() - t0) * 1e3)
+        h2d.append(ev[0].elapsed_time(ev[1]))
+        d2h.append(ev[2].elapsed_time(ev[3]))
+    tot, h2d, d2h = tot[1:], h2d[1:], d2h[1:]                      # the first pass warms the pinned pages
+    assert int(h_len.to(torch.int64).sum().item()) == r["out_bytes"]
+    return {"ms_median": round(median(tot), 3), "ms_min": round(min(tot), 3), "input_MBps": round(B * n / median(tot) / 1e3, 1),
+            "h2d_ms": round(median(h2d), 3), "h2d_GBps": round(B * n / median(h2d) / 1e6, 1),
+            "d2h_ms": round(median(d2h), 3), "d2h_GBps": round(B * pitch / median(d2h) / 1e6, 1),
+            "d2h_bytes": B * pitch + 4 * B, "reps": reps,
+            "note": "pinned host buffers; H2D of the input, one hdlz_compress_batch launch, D2H of the pitched rows (out_pitch = %d) and "
+                    "the lengths; PCIe-bound, not the metric" % pitch}
 
 
 def compress_entry(name, workload, r, cwindow, maxmatch, steps, warmup, traffic_key=None):
@@ -188,6 +234,8 @@ def main_single(a):
         "compression_ratio_out_over_in": round(r["out_bytes"] / r["in_bytes"], 4),
         "roofline": rl,
     }
+    if a.end_to_end:
+        res["end_to_end"] = end_to_end(torch, eng, d_in, r, a.cwindow, a.maxmatch)
     if a.cpu_seconds > 0:
         res["cpu_baseline"] = cpu_baseline(d_in, n, a)
     del r, d_in
@@ -276,7 +324,11 @@ def main_sharded(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus)
+    if world != a.gpus:                                     # a launcher with another world size than --gpus: say so, do not hang
+        if rank == 0:
+            print(json.dumps({"metric": METRIC_C32, "value": None, "unit": "MB/s", "n_gpus": a.gpus,
+                              "error": "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)}), flush=True)
+        sys.exit(2)
     ndev = torch.cuda.device_count()
     backend = os.environ.get("HDLZ_BENCH_BACKEND", "nccl")   # "gloo": functional check of the N>1 flow on fewer GPUs
     if backend == "nccl":
@@ -294,10 +346,21 @@ def main_sharded(a):
 
     eng = hdl_deflate_amd.Engine(dev)
     total, n = a.cfg5_blocks, CFG5_BLOCK
+    pitch = pitch_for(n)
+    # T(1): the WHOLE job on rank 0's GPU first (the other ranks wait at the barrier), so that the line carries its own
+    # single-GPU reference -- same blocks, same kernel, same process; the driver computes efficiency from its own N = 1 run
+    t1 = None
+    if a.t1:
+        if rank == 0:
+            d1 = make_blocks(total, n, dev, seed=0)
+            r1 = run_compress(torch, eng, d1, 32, 10, a.steps, a.warmup, 0)
+            t1 = {"ms": r1["dt"] / a.steps * 1e3, "out_bytes": r1["out_bytes"], "k_ms": r1["k_ms"]}
+            del r1, d1
+            torch.cuda.empty_cache()
+        dist.barrier()
     b0, b1 = shard_range(total, rank, world)               # contiguous shard of the job
     B = b1 - b0
-    d_in = make_blocks(B, n, dev, seed=0, first_block=b0)  # the same blocks the 1-GPU run holds at [b0, b1)
-    pitch = pitch_for(n)
+    d_in = make_blocks(B, n, dev, seed=0, first_block=b0)  # exactly the blocks the 1-GPU run holds at [b0, b1) (any world size)
     d_out = torch.empty((B, pitch), dtype=torch.uint8, device=dev)
     lg = LengthGather(total, dev)
     torch.cuda.synchronize()
@@ -307,8 +370,8 @@ def main_sharded(a):
         return ol, st, lg.gather(ol)                       # the ONLY exchange step: uint32[B/N] lengths
 
     dt, (ol, st, all_len) = time_steps(torch, dist, step, a.steps, a.warmup, world, cdev)
-    k_ms = kernel_ms(torch, lambda: eng.compress_batch(d_in, cwindow=32, maxmatch=10, out=d_out, out_pitch=pitch), max(3, a.steps))
-    g_ms = kernel_ms(torch, lambda: lg.gather(ol), max(3, a.steps)) if backend == "nccl" else [0.0]
+    k_ms = kernel_ms(torch, lambda: eng.compress_batch(d_in, cwindow=32, maxmatch=10, out=d_out, out_pitch=pitch), max(10, a.steps))
+    g_ms = kernel_ms(torch, lambda: lg.gather(ol), max(10, a.steps)) if backend == "nccl" else [0.0]
 
     tot = torch.tensor([int(ol.to(torch.int64).sum().item()), B * n, int((st != 0).sum().item())], dtype=torch.int64, device=cdev)
     dist.all_reduce(tot)
@@ -316,6 +379,8 @@ def main_sharded(a):
     assert bad == 0, "%d blocks failed" % bad
     assert all_len.numel() == total and int(all_len.to(torch.int64).sum().item()) == out_bytes, "gathered lengths disagree"
     assert torch.equal(all_len[b0:b1].to(ol.device), ol.to(torch.int32)), "own shard not at its place in the gathered lengths"
+    if t1 is not None:                                     # the shards together ARE the single-GPU job: same bytes in, same bytes out
+        assert out_bytes == t1["out_bytes"], "sharded job wrote %d bytes, the 1-GPU job %d" % (out_bytes, t1["out_bytes"])
     if rank == 0 and a.verify:
         zlib_spot_check(torch, d_in, d_out, ol, min(a.verify, 32))
     if rank == 0:
@@ -332,8 +397,15 @@ def main_sharded(a):
                "per_gpu_MBps": round(value / world, 1),
                "compression_ratio_out_over_in": round(out_bytes / in_bytes, 4),
                "length_allgather_ms_avg": round(sum(g_ms) / len(g_ms), 4),
-               "roofline": roofline(kname_for(32, n), algo, k_ms, None, {"note": "rank 0's shard; per-GPU figure"}),
-               "note": "T(1) of this job is the ms_per_step of the 'configs[4]-shape, 1 GPU' entry of `bench.py --gpus 1`"}
+               "roofline": roofline(kname_for(32, n), algo, k_ms, None, {"note": "rank 0's shard; per-GPU figure"})}
+        if t1 is not None:
+            res["T1_ms"] = round(t1["ms"], 4)
+            res["T1_kernel_ms_median"] = round(median(t1["k_ms"]), 4)
+            res["speedup_vs_T1"] = round(t1["ms"] / (dt / a.steps * 1e3), 3)
+            res["note"] = ("T1_ms = the whole job (%d blocks) on rank 0's GPU alone, measured in this run before the shards (same blocks: "
+                           "output byte counts asserted equal); speedup_vs_T1 / n_gpus is the strong-scaling efficiency" % total)
+        else:
+            res["note"] = "T(1) of this job is the ms_per_step of the 'configs[4]-shape, 1 GPU' entry of `bench.py --gpus 1`"
         print(json.dumps(res), flush=True)
     dist.destroy_process_group()
 
@@ -463,6 +535,31 @@ def cpu_baseline(d_in, n, a):
             "reference_constants": {"fpga_100MHz_3cyc_per_byte_MBps": 33, "standin_sim_KBps": "0.5-1 (BASELINE.md)"}}
 
 
+def spawn_ranks(a):
+    """`python3 bench.py --gpus N` started WITHOUT a launcher (the form the driver uses for N = 1): start the N ranks here, one
+    per visible device, through torch.distributed.run on 127.0.0.1; rank 0 prints the ONE JSON line.  With fewer than N
+    visible devices a JSON line says so and the exit code is non-zero (HDLZ_BENCH_BACKEND=gloo: functional check, ranks share
+    the devices that are there)."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("HDLZ_BENCH_BACKEND", "nccl")
+    if ndev < 1 or (backend == "nccl" and ndev < a.gpus):
+        print(json.dumps({"metric": METRIC_C32, "value": None, "unit": "MB/s", "n_gpus": a.gpus, "visible_devices": ndev,
+                          "error": "--gpus %d needs %d visible GPUs (one rank per GPU over RCCL); %d visible -- not run"
+                                   % (a.gpus, a.gpus, ndev)}), flush=True)
+        return 3
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env, cwd=REPO)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -489,9 +586,15 @@ def main():
                     help="inflate: lane-per-stream kernel variant (token = k_inflate_tok, byte = k_inflate)")
     ap.add_argument("--mode", default="compress", choices=["compress", "inflate"],
                     help="compress = BASELINE metric (default); inflate = only the configs[3] side metric (1 GPU)")
+    ap.add_argument("--no-end-to-end", dest="end_to_end", action="store_false",
+                    help="N=1: skip the PCIe-inclusive measurement of the headline job (SURVEY 8(d) Timing)")
+    ap.add_argument("--no-t1", dest="t1", action="store_false",
+                    help="N>1: do not run the whole job on rank 0 first (T1_ms / speedup_vs_T1 are then absent)")
     a = ap.parse_args()
     if a.mode == "inflate":
         print(json.dumps(bench_inflate(a)), flush=True)
+    elif a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     elif a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
         main_sharded(a)
     else:

@@ -24,7 +24,7 @@ constexpr int SMALL_OUT_WORDS = 704;          // G * ceil(out_bound(N)/4) is lar
 struct __attribute__((aligned(16))) SmallLds {
     uint32_t in[IN_BYTES / 4];
     uint32_t out[SMALL_OUT_WORDS];
-    uint32_t lut[LUT_LIT + LUT_MATCH];
+    uint32_t lut[LUT_LIT + LUT_MATCH + LUT_LEN];      // fill_luts writes all three tables
     uint32_t ad[2][64];                       // per-lane Adler partials, summed per block by its first lane
 };
 

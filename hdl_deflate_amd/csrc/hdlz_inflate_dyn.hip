@@ -558,6 +558,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
     done:
         __syncthreads();
+        // STREAM: a stop for output room that no larger out_limit can ever give (the limit is not below the capacity) is the
+        // batch call's HDLZ_E_OUT_CAPACITY, not need = 2 forever
+        if (STREAM && status == HDLZ_OK && need == 2u && cap0 <= out_limit) status = HDLZ_E_OUT_CAPACITY;
         if (status == HDLZ_OK) {
             const uint32_t c0 = o & ~(DCHUNK - 1u);
             if (c0 + lane < o) out[c0 + lane] = L.ring[(c0 + lane) & (DRING - 1u)];

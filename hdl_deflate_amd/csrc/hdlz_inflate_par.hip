@@ -332,6 +332,13 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
             const uint32_t tl = tj & 511u, D = tj >> 9;
             // COPY (deflate.py:1627-1659): out[Pj+i] = out[Pj - D + (i mod D)]
             const bool near = D <= HREACH && Pj - cstart >= D;            // the whole source is this piece's own, recent output
+            if (!near) {
+                // in-piece sources beyond the LDS ring were stored to out[] / src[] by OTHER lanes of this wave in earlier
+                // iterations: order those stores before the loads below (same-wave VMEM is ordered on gfx950,
+                // the fences make it a rule instead of an observation -- wave-uniform branch)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
             for (uint32_t i0 = 0; i0 < tl; i0 += 64u) {
                 const uint32_t i = i0 + lane;
                 if (i < tl) {

@@ -758,7 +758,10 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
     // (the explicit lane hint keeps every such stream in the lane kernel)
     const uint32_t lane_min = (a.flags & HDLZ_INFLATE_LANE_PER_STREAM) ? 0u : HDLZ_INFLATE_DYN_LANE_MIN;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * (a.nstreams + 1u), stream);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) {                      // no scratch: the wave-per-stream second pass needs none and finishes the job
+        (void)hipGetLastError();
+        return launch_inflate_dyn(a, stream, false);
+    }
     e = hipMemsetAsync(ws, 0, sizeof(uint32_t), stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(tok::k_collect_dyn, dim3((unsigned)((a.nstreams + 255u) / 256u)), dim3(256), 0, stream, a.status, a.nstreams,

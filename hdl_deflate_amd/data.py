@@ -56,15 +56,31 @@ def _item_text(torch, numbers, prefix, suffix_len, n, device):
     return ch
 
 
+def _mix32(torch, x):
+    """murmur3's 32-bit finaliser on int64 tensors holding 32-bit values (a bijection: distinct counters -> distinct words)"""
+    m = 0xFFFFFFFF
+    x = (x ^ (x >> 16)) * 0x85EBCA6B & m
+    x = (x ^ (x >> 13)) * 0xC2B2AE35 & m
+    return x ^ (x >> 16)
+
+
+def _block_words(torch, gsel, K, salt, device):
+    """counter-based random words: int64 [rows, K] in [0, 2^32), a function of (seed salt, GLOBAL block index, k) only"""
+    ctr = (gsel.unsqueeze(1) * 0x9E3779B1 + salt) & 0xFFFFFFFF
+    k = torch.arange(K, device=device, dtype=torch.int64).unsqueeze(0)
+    return _mix32(torch, _mix32(torch, ctr) + k * 0x632BE5AB & 0xFFFFFFFF)
+
+
 def make_blocks(nblocks, n, device, seed=0, families=(1, 2, 3, 4), first_block=0, chunk=16384):
     """uint8 [nblocks, n] on `device`; block b (global index first_block + b) is family
-    families[b % len(families)], every block distinct."""
+    families[b % len(families)], every block distinct.  The content of a block is a function of (seed, global
+    block index) alone (counter-based generator): any shard [b0, b1) of a job -- whatever the world size or the chunk
+    grid -- holds exactly the bytes the single-GPU job holds at [b0, b1)."""
     import torch
-    g = torch.Generator(device=device)
     out = torch.empty((nblocks, n), dtype=torch.uint8, device=device)
     nf = len(families)
     # the text families build int64 [rows, n] intermediates: bound a chunk to 2^25 elements (16384 rows of 2 KiB -- the
-    # default -- or 512 rows of 64 KiB).  Block contents depend on the chunk grid: shards must start on a chunk multiple.
+    # default -- or 512 rows of 64 KiB).  The grid only bounds memory; it does not enter the contents.
     chunk = max(nf, min(chunk, (1 << 25) // max(n, 1)))
     for c0 in range(0, nblocks, chunk):
         c1 = min(nblocks, c0 + chunk)
@@ -76,14 +92,18 @@ def make_blocks(nblocks, n, device, seed=0, families=(1, 2, 3, 4), first_block=0
             B = rows.numel()
             if B == 0:
                 continue
-            g.manual_seed(seed * 1000003 + (first_block + c0) * 7 + f)
+            salt = (seed * 1000003 + f * 7919 + 12345) & 0xFFFFFFFF
             if f == 3:
-                blk = torch.randint(0, 256, (B, n), generator=g, device=device, dtype=torch.uint8)
+                w = _block_words(torch, gsel, (n + 3) // 4, salt, device)               # four bytes per word
+                blk = w.unsqueeze(2) >> torch.tensor([0, 8, 16, 24], device=device)
+                blk = (blk & 255).to(torch.uint8).reshape(B, -1)[:, :n]
             elif f == 4:
-                blk = torch.randint(0, 2, (B, n), generator=g, device=device, dtype=torch.uint8) + 48
+                w = _block_words(torch, gsel, (n + 31) // 32, salt, device)             # 32 characters per word
+                blk = w.unsqueeze(2) >> torch.arange(32, device=device)
+                blk = ((blk & 1) + 48).to(torch.uint8).reshape(B, -1)[:, :n]
             elif f == 2:
                 K = n // 7 + 2
-                nums = torch.randint(0, 0x1000, (B, K), generator=g, device=device, dtype=torch.int64)
+                nums = _block_words(torch, gsel, K, salt, device) >> 20                 # 0 .. 4095
                 blk = _item_text(torch, nums, "Hi: ", 2, n, device)
             elif f == 1:
                 K = n // 23 + 2

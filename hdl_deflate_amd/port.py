@@ -231,7 +231,12 @@ class DeflatePort(object):
                 self._start(mode)
                 self.consumed = 0
                 self.n_at_step = 0
-                if mode == STARTC:
+                if mode == STARTC and self.stream_obsize < 128:
+                    # progress needs room for either a non-final call (32 positions: >= 43 pending bytes) or the final one
+                    # (<= 42 pending: ceil(9*42/8) + 8 + 11 = 67 bytes): 64 bytes of output memory can dead-lock
+                    self.state = self.ST_IDLE
+                    raise ValueError("streaming STARTC needs stream_obsize >= 128")
+                elif mode == STARTC:
                     self.session = self.engine.compress_session(cwindow=self.cwindow, maxmatch=self.maxmatch)
                 elif self.stream_obsize < 512:
                     # a copy is only started when all of it fits (deflate.py:1597: `do + length >= i_raddr + OBSIZE` holds), so
@@ -278,16 +283,20 @@ class DeflatePort(object):
 
     def _step_compress(self, s, room):
         # a call over k positions writes at most ceil(9k/8) + 8 bytes (+ 11 for EOB, padding and the trailer at the end)
-        fit = ((room - 24) * 8 // 9) // 32 * 32 if room > 24 else 0
+        bound = (room - 24) * 8 // 9 if room > 24 else 0     # positions whose output certainly fits the room (unrounded)
+        fit = bound // 32 * 32                               # ... as a non-final call may take them (whole lanes)
         pending = s.n - s.pos
         if self.ended:
             if s.n < 5:                                  # R0: the reference never starts (deflate.py:429-431) -- it hangs; we say so
                 self.state = self.ST_IDLE
                 self._set(self.o_done, True)
                 raise HdlzStatusError(1, "STARTC")
-            if fit <= 0:
-                return
-            st = s.step(final=True, max_positions=max(fit, 32) if pending > fit else None)
+            if pending <= bound:
+                st = s.step(final=True)                  # everything that is left, EOB and the trailer fit
+            elif fit >= 32 and s.encodable() >= 32:
+                st = s.step(max_positions=fit)           # a non-final piece; the rest when the reader has made room
+            else:
+                return                                   # HOLD: the reader must advance first
         else:
             if pending - 11 < self.window or fit < 32:
                 return                                   # window not filled yet / held by the reader

@@ -109,8 +109,10 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
  * until BFINAL, stored (BTYPE 0), fixed-Huffman (BTYPE 1) and dynamic-tree (BTYPE 2, deflate.py:1084-1517;
  * handled by a second pass over the streams that hold such blocks -- see the mapping hints above; in the lane
  * mapping that pass keeps the list of these streams in stream-ordered scratch memory, hipMallocAsync /
- * hipFreeAsync on `stream`, 4 bytes per stream: nothing is allocated with HDLZ_INFLATE_ASSUME_FIXED or in the
- * wave mapping, and the call stays capturable into a HIP graph) blocks, 4 trailer bytes required
+ * hipFreeAsync on `stream`, 4 bytes per stream (if that allocation fails the wave mapping finishes the job); the
+ * parallel path for ONE large stream or a few of them -- HDLZ_INFLATE_PAR_MIN below -- allocates 8 bytes per possible
+ * output byte the same way, whatever the flags; no other case allocates, and every case stays capturable into a HIP
+ * graph) blocks, 4 trailer bytes required
  * but Adler-32 not verified -- exactly the reference's acceptance (deflate.py:635-651 IDLE/STARTD,
  * :656-732 HEADER, :1402-1445 NEXT, :1519-1591 INFLATE, :1593-1659 COPY, :517-533 get4/adv).
  * `obsize` != 0 selects the reference-exact behaviour of an OBSIZE build (deflate.py:61-62):
@@ -197,7 +199,9 @@ int hdlz_compress_chunk(const uint8_t* d_in, uint32_t in_len, uint32_t q_end, in
  *   - the stream ends                      -> state.done = 1, state.out_pos = the output length
  *   - the input known so far runs out      -> state.need = 1  (call again with more bytes / final = 1)
  *   - out_limit output bytes are reached   -> state.need = 2  (call again with a larger limit: the reader has advanced)
- *   - the stream is bad                    -> state.status = HDLZ_E_* (the codes of hdlz_inflate_batch)
+ *   - the stream is bad                    -> state.status = HDLZ_E_* (the codes of hdlz_inflate_batch; also
+ *                                             HDLZ_E_OUT_CAPACITY when the stream needs more than out_cap bytes and
+ *                                             out_limit >= out_cap: no larger limit could help)
  * always stopping BETWEEN two tokens, so the bytes [0, state.out_pos) of d_out are final after every call.
  *   d_in / in_len  the stream from its first byte on, in_len = bytes known so far (the pointer may change between calls,
  *                  the bytes may not); final != 0: in_len is the stream length and the reference's end-of-input checks apply

@@ -104,3 +104,41 @@ def test_bench_sharded_entry_cfg5_shape():
     assert r["scaling"] == "strong" and r["n_gpus"] == max(ndev, 2) and r["value"] > 0
     assert r["config"]["blocks_total"] == 2048 and r["config"]["block_bytes"] == 65536
     assert 0.3 < r["compression_ratio_out_over_in"] < 0.8 and r["roofline"]["frac"] > 0
+
+
+def test_bench_gpus_n_without_a_launcher():
+    """`python3 bench.py --gpus N` started plainly (the form the driver uses for N = 1) starts its own N ranks.
+    With one visible device: over RCCL it must say so in ONE JSON line and exit non-zero instead of hanging or asserting; the
+    functional flow (ranks sharing the device over gloo) must produce the line with T1_ms in it."""
+    import torch
+    ndev = torch.cuda.device_count()
+    n = max(2, ndev)
+    base = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--cfg5-blocks", "2048", "--steps", "2", "--warmup", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HDLZ_BENCH_BACKEND")}
+    if ndev < n:
+        p = subprocess.run(base, cwd=REPO, env=env, capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert p.returncode != 0 and len(lines) == 1, p.stdout[-2000:] + p.stderr[-2000:]
+        r = json.loads(lines[0])
+        assert r["value"] is None and r["visible_devices"] == ndev and "error" in r
+        env["HDLZ_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run(base, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == n and r["scaling"] == "strong" and r["value"] > 0 and r["config"]["blocks_total"] == 2048
+    assert r["T1_ms"] > 0 and r["speedup_vs_T1"] > 0 and r["roofline"]["kernel_ms_median"] > 0
+
+
+def test_shards_of_any_world_size_hold_the_single_gpu_jobs_bytes():
+    """block contents depend on (seed, global block index) only -- uneven shards (world 3, 5, 7) and any chunk
+    grid give exactly the bytes of the one-GPU job"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    from hdl_deflate_amd.shard import shard_range
+    whole = make_blocks(203, 4096, "cuda", seed=0)
+    for world in (2, 3, 5, 7):
+        parts = [make_blocks(b1 - b0, 4096, "cuda", seed=0, first_block=b0, chunk=5 + world)
+                 for b0, b1 in (shard_range(203, r, world) for r in range(world))]
+        assert torch.equal(torch.cat(parts), whole), world

@@ -142,3 +142,24 @@ def test_session_edge_cases(engine, oracle):
     p = isn.out_pos
     assert isn.step(final=True, out_limit=100) == 0 and isn.need == 2 and isn.out_pos == p and isn.output(0, p) == d[:p]
     assert isn.step(final=True, out_limit=1 << 20) == 0 and isn.done and isn.output(0, isn.out_pos) == d
+
+
+def test_inflate_chunk_capacity_is_an_error_not_a_hold(engine):
+    """hdlz_inflate_chunk with out_limit >= out_cap on a stream that needs more than out_cap bytes: raising the limit
+    can never help, so the session reports HDLZ_E_OUT_CAPACITY (the batch call's code) instead of need = 2 forever; with a
+    limit BELOW the capacity the same stop stays a hold"""
+    import torch
+    L = engine.lib
+    d = bytes(random.Random(5).choice(b"hello world ") for _ in range(3000))
+    z = zlib.compress(d)
+    d_in = torch.frombuffer(bytearray(z + bytes(64)), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    for limit, want_status, want_need in ((4096, 2, 0), (1024, 2, 0), (512, 0, 2)):
+        st = torch.zeros(16 + 80, dtype=torch.int32, device="cuda")
+        rc = L.hdlz_inflate_chunk(d_in.data_ptr(), len(z), 1, 0, 0, d_out.data_ptr(), 1024, limit, st.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        s = st.cpu().tolist()
+        assert (s[10], s[11]) == (want_status, want_need), (limit, s[:12])
+        if want_need == 2:
+            assert 0 < s[1] <= limit and bytes(d_out[:s[1]].cpu().numpy().tobytes()) == d[:s[1]]

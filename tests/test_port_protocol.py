@@ -31,6 +31,9 @@ class OracleCompressSession(object):
         self.buf += data
         self.n = len(self.buf)
 
+    def encodable(self, final=False):
+        return self.n - self.pos if final else max(0, (self.n - 11 - self.pos) // 32 * 32)
+
     def step(self, final=False, max_positions=None):
         if self.done:
             return 0
@@ -311,6 +314,22 @@ def run_streaming_mode_flows(engine):
 
 def test_streaming_mode_reference_modes():
     run_streaming_mode_flows(OracleEngine())
+
+
+def test_streaming_compress_at_minimal_obsize():
+    """ADVICE r2: a streaming STARTC must finish for every input length at the smallest output memory the port accepts (128);
+    64 bytes cannot hold the final call of 33..42 pending positions and is refused"""
+    from hdl_deflate_amd.data import family_bytes
+    eng = OracleEngine()
+    src = family_bytes(2, 400, seed=9)
+    for n in list(range(100, 180)) + [5, 31, 32, 43, 44, 64, 75, 76, 77, 399]:
+        for rd in (1, 3):
+            dut, s = make_dut(eng, streaming=True, stream_obsize=128)
+            res, total, _, _ = port_harness.stream_leg(dut, s, src[:n], STARTC, maxw=MAXW, read_every=rd)
+            assert res == eng.compress_bytes(src[:n])[1] and total == len(res), (n, rd)
+    dut, s = make_dut(eng, streaming=True, stream_obsize=64)
+    with pytest.raises(ValueError):
+        port_harness.stream_leg(dut, s, src[:100], STARTC, maxw=MAXW)
 
 
 def test_streaming_ring_overrun_and_lmax():
