@@ -40,9 +40,26 @@ namespace hdlz {
 // own windows 32 and 256, and 64), which spares the per-position window compare; ONE_TILE: every block of the batch fits one
 // wave-tile (N <= 2048: BASELINE configs[1]'s block size and the reference's own IBSIZE scale) -- no tile loop, no halo
 // carried from a previous tile, no carried bit / Adler state
+#ifndef HDLZ_WH
+#define HDLZ_WH 3                               // waves per SIMD of the kernels with the hash finder (13.6 KB of LDS per wave: 12 per CU)
+#endif
+template <int NCH> constexpr bool wide_hash() {
+#ifdef HDLZ_CW64_BRUTE
+    return NCH > 2;
+#else
+    return NCH > 1;
+#endif
+}
+template <int NCH> constexpr int waves_eu() { return NCH == 1 ? HDLZ_W1 : wide_hash<NCH>() ? HDLZ_WH : NCH == 2 ? HDLZ_W2 : 4; }
+
 template <int NCH, bool FULLWIN, bool ONE_TILE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? HDLZ_W1 : NCH == 2 ? HDLZ_W2 : 4, NCH == 1 ? HDLZ_W1 : NCH == 2 ? HDLZ_W2 : 4))) void k_compress(CompressArgs a) {
-    __shared__ WaveLds lds;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH>(), waves_eu<NCH>()))) void k_compress(CompressArgs a) {
+    constexpr bool HASH = wide_hash<NCH>();         // windows > 32 (64: see HDLZ_CW64_BRUTE): the window-independent finder
+    __shared__ typename std::conditional<HASH, WaveLdsNoOut, WaveLds>::type lds;
+    __shared__ typename std::conditional<HASH, HashLds<NCH>, uint32_t>::type hl;
+    // the bit buffer of a tile: HASH kernels keep it in the finder's transposition buffer, which is dead once best[] is in registers
+    // (28 KB of LDS per wave left ONE wave per SIMD: VALU 31 %, LDS 39 % busy -- this kernel lives on overlapping the two)
+    uint32_t* const lout = lds_out(lds, hl);
     const uint32_t lane = threadIdx.x;
 
     fill_luts<NCH>(lds.lut, lane);                  // per-wave look-up tables (once per wave lifetime)
@@ -52,7 +69,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
     const uint32_t kmax = (uint32_t)a.maxmatch;
     uint8_t* lin8 = reinterpret_cast<uint8_t*>(lds.in);
     const uint8_t* lut8 = reinterpret_cast<const uint8_t*>(lds.lut);
-    uint8_t* out8 = reinterpret_cast<uint8_t*>(lds.out);
+    uint8_t* out8 = reinterpret_cast<uint8_t*>(lout);
 
     for (uint64_t blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
         uint64_t off;
@@ -113,7 +130,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
                 }
             }
             // zero the bit buffer, seed the carry
-            for (uint32_t w = lane; w < OUT_WORDS; w += 64) lds.out[w] = (w == 0) ? carry_word : 0u;
+            if constexpr (!HASH) for (uint32_t w = lane; w < OUT_WORDS; w += 64) lout[w] = (w == 0) ? carry_word : 0u;
             __syncthreads();
 
             // -------------------------------------------------------------- 2..6: the shared tile phases (hdlz_compress_common.h)
@@ -122,7 +139,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
             const uint32_t nrem = n - min(p_run, n);                  // positions of the block from p_run on
             uint32_t best[RUN], tok[RUN], code[RUN];
             HDLZ_MARK("search");
-            match_search<NCH>(lds.in, run_dw, best);                                               // 2. R3/R4
+            if constexpr (HASH) {
+                match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);               // 2. R3/R4, wide windows
+                for (uint32_t w = lane; w < OUT_WORDS; w += 64) lout[w] = (w == 0) ? carry_word : 0u;      // (ordered before the scatter by the fences below)
+            } else match_search<NCH>(lds.in, run_dw, best);                                        // 2. R3/R4
             {
                 HDLZ_MARK("adler");
                 uint32_t ow[12];                                      // own 32 bytes + 16 look-ahead (reloaded: see match_search)
@@ -168,8 +188,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
             if (!last) {
                 const uint32_t end_bits = base_bits + tile_bits_all;
                 const uint32_t full = end_bits >> 5;
-                for (uint32_t w = lane; w < full; w += 64) outw[gw + w] = lds.out[w];
-                carry_word = lds.out[full];
+                for (uint32_t w = lane; w < full; w += 64) outw[gw + w] = lout[w];
+                carry_word = lout[full];
                 gw += full;
                 base_bits = end_bits & 31u;
             } else {
@@ -181,7 +201,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
                 {
                     const uint32_t ew = end_bits >> 5, rb = end_bits & 31u;
                     for (uint32_t w = ew + lane; w < OUT_WORDS; w += 64)
-                        lds.out[w] = (w == ew) ? (lds.out[w] & ((1u << rb) - 1u)) : 0u;
+                        lout[w] = (w == ew) ? (lout[w] & ((1u << rb) - 1u)) : 0u;
                 }
                 // R8: EOB = 7 zero bits, zero pad to a byte, Adler-32 big-endian (s2 then s1)
                 uint32_t s1 = ad_a % ADLER_MOD, s2 = ad_w;
@@ -203,7 +223,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
                 __syncthreads();
                 const uint32_t total = nbytes + 4u;
                 const uint32_t words = (total + 3u) >> 2;
-                for (uint32_t w = lane; w < words; w += 64) outw[gw + w] = lds.out[w];
+                for (uint32_t w = lane; w < words; w += 64) outw[gw + w] = lout[w];
                 if (lane == 0) {
                     a.out_len[blk] = gw * 4u + total;     // R9
                     a.status[blk] = HDLZ_OK;

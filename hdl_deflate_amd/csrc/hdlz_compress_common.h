@@ -37,6 +37,11 @@ struct __attribute__((aligned(16))) WaveLds {
     uint32_t lut[LUT_LIT + LUT_MATCH + LUT_LEN];
 };
 
+struct __attribute__((aligned(16))) WaveLdsNoOut {       // kernels with the hash finder: the bit buffer lives in HashLds::D's memory
+    uint32_t in[IN_BYTES / 4];
+    uint32_t lut[LUT_LIT + LUT_MATCH + LUT_LEN];
+};
+
 // fence for the instruction scheduler + value fences: keep independent phases from being overlapped
 // (that blew the VGPR budget to 239 and spilled ~200 SGPR lane masks in the first version)
 #define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -250,6 +255,223 @@ __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw
             else if (m[i] < 256u) best[i] = m[i] + 128u * (uint32_t)k;
         }
     }
+}
+
+// ---- phase 2 for WIDE windows: a window-independent match finder ------------------------------------------
+// "Nearest previous occurrence of the same 3-byte string" (matcher3 x CWINDOW + first-set-bit pick, deflate.py:407-421, :966-1016)
+// is a predecessor query; its cost need not grow with the window.  match_search pays 1.5 VALU instructions per (position,
+// distance) pair -- 48 per position at CWINDOW = 32, 384 at 256.  Here the tile is walked in ROUNDS of 64 consecutive positions,
+// one lane per position, through three LDS structures:
+//   T[h]    last position with hash h among the rounds before the current one (updated by ds_max_u32: order-independent);
+//   B[l]    the lanes of the CURRENT round that share a hash, as a 64-bit map kept at the slot of their LEADER: after the round's
+//           ds_max every lane of the class reads T[h] back -- the class's last lane, the leader they all agree on; ds_or_b64 into
+//           B[leader], read back, cleared.  The highest set bit below the own lane is the nearest previous position of the same
+//           round -- deterministic, no reliance on the order in which the LDS serialises same-address atomics.  (A map per BUCKET -- the first version -- cost 8 bytes per bucket
+//           and capped the table at 512 buckets; 64 maps cost 512 bytes, and leader slots are distinct addresses: no conflicts.)
+//   E[p]    (distance from p to the previous position with the same HASH) - 1 as one byte, 255 = none or >= 256: every hash class
+//           is a chain in descending position order.
+// h = the top HB bits of (K * odd) mod 2^24 (K = the three bytes): a bijection of the key, well mixed in its high bits.  A lane
+// follows its chain, nearest first, comparing the exact three bytes, until they are equal (the answer), or the window is left;
+// positions with the same hash and another key are the only wasted steps (about CWINDOW / 2^HB per query).
+// Result: best[i] = 4 * distance for own position i of the lane's RUN (the layout of all later phases; transposed through LDS),
+// a value > 4 * CWINDOW = none.  The zero halo in front of a block's first tile only yields distances > p (rejected by
+// make_tokens' position test; a valid candidate is always nearer and therefore found first).
+template <int NCH> struct HashCfg {
+#ifndef HDLZ_HASH_BITS
+#define HDLZ_HASH_BITS 10
+#endif
+    static constexpr int HB = HDLZ_HASH_BITS;
+    static constexpr int NT = 1 << HB;
+    static constexpr int PRE = 64 * ((32 * NCH + 63) / 64);     // positions in front of the tile that are inserted first
+    static_assert(PRE <= HALO && HB >= 8 && HB <= 16, "halo / tag position");
+};
+template <int NCH> struct __attribute__((aligned(16))) HashLds {
+    union {
+        uint32_t T[HashCfg<NCH>::NT];
+        uint16_t D[TILE];                   // the results on their way from the round layout to the run layout
+    };
+    uint64_t B[64];                         // zero between rounds
+    uint16_t E[HALO + TILE];                // per position: eight tag bits of the key << 8 | link
+    static_assert(sizeof(uint32_t) * HashCfg<NCH>::NT >= sizeof(uint16_t) * TILE, "D overlays T");
+};
+
+__device__ __forceinline__ uint32_t* lds_out(WaveLds& l, uint32_t&) { return l.out; }
+template <int NCH> __device__ __forceinline__ uint32_t* lds_out(WaveLdsNoOut&, HashLds<NCH>& h) {
+    static_assert(sizeof(h.T) >= sizeof(uint32_t) * OUT_WORDS, "the bit buffer overlays T / D");
+    return h.T;
+}
+
+template <int NCH>
+__device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NCH>& hl, uint32_t lane, uint32_t cw, uint32_t (&best)[RUN]) {
+    constexpr int HB = HashCfg<NCH>::HB, NT = HashCfg<NCH>::NT, PRE = HashCfg<NCH>::PRE;
+    constexpr uint32_t base = HALO - PRE;
+    // empty table (it was the transposition buffer and the bit buffer of the previous tile)
+    for (uint32_t k = lane * 4u; k < (uint32_t)NT; k += 256u) *reinterpret_cast<uint4*>(&hl.T[k]) = make_uint4(0, 0, 0, 0);
+    hl.B[lane] = 0ull;
+    __syncthreads();
+    const uint64_t bit = 1ull << lane, lower = bit - 1ull;
+
+    // Rounds are batched in groups of G: the LDS executes a wave's instructions in order, so the table operations of G rounds
+    // are ISSUED back to back (round r+1's T read behind round r's ds_max) and their results are consumed afterwards -- one
+    // LDS round trip per group instead of four dependent ones per round (a first version that finished a round before it
+    // started the next was latency-bound at 5 waves per CU: 63 k cycles per tile).
+    // Costs in CU cycles per wave instruction (tools/ubench/lds_ops.hip): random ds_read_b32 7, ds_max_u32 7, ds_or_b64 11,
+    // ds_read_b64 7..10, ds_write_b64 11 -- and 65 for an UNALIGNED ds_read_b32 (one lane per cycle), 11..22 for ds_write_b8: the key
+    // therefore comes from two aligned dwords + v_alignbyte, and the chain entries are dwords that carry the key themselves
+    constexpr int G = 8;
+    static_assert(RUN % G == 0 && PRE / 64 <= G, "groups");
+    uint32_t res2[RUN / 2];                  // round layout, two rounds per register: 4 * distance of position 64 r + lane, 16 bits each
+    // A group's work comes in three pieces: issue (key, hash, the table operations), consume (first candidate, chain entry) and
+    // walk (the chain steps of its queries).  (Issuing group g+1 before walking group g changed nothing measurable.)
+    struct Grp { uint32_t kw[G], ow[G], c0[G], dd[G]; uint64_t bm[G]; };
+    auto issue = [&](auto G0, auto CNT, Grp& q) {             // rounds [g0, g0 + cnt), counted from position `base`
+        constexpr int g0 = decltype(G0)::value, cnt = decltype(CNT)::value;
+        // three stages, each over all rounds of the group, so that a stage's LDS operations are in flight together: the leader's
+        // slot address depends on a table read-back, and a round-by-round order would wait for two round trips per round
+        uint32_t w0_[cnt], w1_[cnt], lead_[cnt];
+        static_for<0, cnt>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const uint32_t idx = base + 64u * (uint32_t)(g0 + j) + lane;      // byte index of the position in `in`
+            w0_[j] = in[idx >> 2]; w1_[j] = in[(idx >> 2) + 1u];
+        });
+        static_for<0, cnt>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr uint32_t rbase = base + 64u * (uint32_t)(g0 + j);
+            const uint32_t idx = rbase + lane;
+            q.kw[j] = alignbyte(w1_[j], w0_[j], lane);                        // (rbase is a multiple of 4) the key is its low three bytes
+            uint32_t mix;
+            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(mix) : "v"(q.kw[j]), "v"(0x9E3779u));     // (ignores the top byte; hipcc picks the quarter-rate v_mul_lo_u32)
+            q.ow[j] = (mix << (HB - 8)) & 0xFF00u;            // the eight bits BELOW the hash bits of (K * odd) mod 2^24, as the entry's tag
+            const uint32_t h = __builtin_amdgcn_ubfe(mix, 24 - HB, HB);
+            q.c0[j] = __hip_atomic_load(&hl.T[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // the last position of the hash class: what the next rounds must find -- and the leader its lanes agree on
+            __hip_atomic_fetch_max(&hl.T[h], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lead_[j] = __hip_atomic_load(&hl.T[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - rbase;
+        });
+        static_for<0, cnt>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            __hip_atomic_fetch_or(&hl.B[lead_[j]], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            q.bm[j] = __hip_atomic_load(&hl.B[lead_[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&hl.B[lead_[j]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        });
+    };
+    auto consume = [&](auto G0, auto CNT, Grp& q) {
+        constexpr int g0 = decltype(G0)::value, cnt = decltype(CNT)::value;
+        static_for<0, cnt>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr uint32_t rbase = base + 64u * (uint32_t)(g0 + j);
+            const uint32_t idx = rbase + lane;
+            const uint64_t below = q.bm[j] & lower;
+            const uint32_t c = below != 0ull ? rbase + 63u - (uint32_t)__builtin_clzll(below) : q.c0[j];
+            const uint32_t d = idx - c;                       // (an empty T entry reads as position 0: a distance that is either outside
+                                                              //  the window or leads to a real position whose key is then compared)
+            hl.E[idx] = (uint16_t)(q.ow[j] | min(d - 1u, 255u));
+            q.dd[j] = (d - 1u) < cw ? d : 0u;                 // 0 = this lane has nothing (more) to look at
+        });
+    };
+    // follow the chains, nearest first: the nearest position with the same three bytes inside the window.  The first step of
+    // the group's rounds is issued together; the (rare) further steps run per round, branch-free in the body (the scalar unit
+    // is shared by the CU's four SIMDs: a compare-and-branch ladder per step would make IT the limit).  An entry carries eight
+    // tag bits of its key (a dword per entry with the whole key cost 9 KB of LDS = a wave per SIMD): a candidate whose tag agrees
+    // is CONFIRMED against its three bytes, and the one in 256 wrong candidates that gets that far sends its lane back to the walk.
+    auto walk = [&](auto G0, Grp& q) {
+        constexpr int g0 = decltype(G0)::value;
+        uint32_t ev_[G], found_[G];                           // found: 0 = none
+        auto step = [&](uint32_t ev, uint32_t ow, uint32_t& dd, uint32_t& found) {
+            const uint32_t nd = dd + (ev & 255u) + 1u;
+            const bool live = dd != 0u;
+            const bool same = (ev ^ ow) < 256u;
+            found = (live & same) ? dd : found;
+            dd = (live & !same & (nd <= cw)) ? nd : 0u;
+        };
+        // two steps for all rounds of the group, their reads in flight together (every dependent LDS round trip that is paid per
+        // ROUND -- a step, the confirmation -- is paid 32 times per tile: at two to three waves per SIMD that latency is the kernel)
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            static_for<0, G>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                ev_[j] = hl.E[base + 64u * (uint32_t)(g0 + j) + lane - q.dd[j]];     // (a finished lane reads its own entry: in range, unused)
+            });
+            static_for<0, G>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                if (pass == 0) found_[j] = 0u;
+                step(ev_[j], q.ow[j], q.dd[j], found_[j]);
+            });
+        }
+        // the chains that are longer, round by round
+        static_for<0, G>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const uint32_t idx = base + 64u * (uint32_t)(g0 + j) + lane;
+            while (__ballot(q.dd[j] != 0u) != 0ull) step(hl.E[idx - q.dd[j]], q.ow[j], q.dd[j], found_[j]);
+        });
+        // confirm the candidates: the three bytes at idx - found against the own ones (none: the own position, trivially equal)
+        uint32_t c0_[G], c1_[G];
+        static_for<0, G>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const uint32_t a = base + 64u * (uint32_t)(g0 + j) + lane - found_[j];
+            c0_[j] = in[a >> 2]; c1_[j] = in[(a >> 2) + 1u];
+        });
+        uint32_t anybad = 0;
+        static_for<0, G>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const uint32_t a = base + 64u * (uint32_t)(g0 + j) + lane - found_[j];
+            ev_[j] = (alignbyte(c1_[j], c0_[j], a) ^ q.kw[j]) << 8;          // != 0: a wrong candidate with the right tag
+            anybad |= ev_[j];
+        });
+        if (__ballot(anybad != 0u) != 0ull) {
+            // (rare: one candidate in 256 wrong ones) the lane goes on behind it -- serial walk and confirmation
+            static_for<0, G>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const uint32_t idx = base + 64u * (uint32_t)(g0 + j) + lane;
+                bool bad = ev_[j] != 0u;
+                while (__ballot(bad) != 0ull) {
+                    uint32_t dd = 0u;
+                    if (bad) {
+                        const uint32_t nd = found_[j] + ((uint32_t)hl.E[idx - found_[j]] & 255u) + 1u;
+                        dd = nd <= cw ? nd : 0u;
+                        found_[j] = 0u;
+                    }
+                    while (__ballot(dd != 0u) != 0ull) step(hl.E[idx - dd], q.ow[j], dd, found_[j]);
+                    const uint32_t a = idx - found_[j];
+                    bad = bad && ((alignbyte(in[(a >> 2) + 1u], in[a >> 2], a) ^ q.kw[j]) << 8) != 0u;
+                }
+            });
+        }
+        static_for<0, G>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int r = g0 + j - PRE / 64;
+            const uint32_t f = found_[j] ? found_[j] : 0x3FFFu;
+            if constexpr ((r & 1) == 0) res2[r >> 1] = f << 2;
+            else res2[r >> 1] |= f << 18;
+        });
+    };
+    {
+        Grp q;
+        issue(std::integral_constant<int, 0>{}, std::integral_constant<int, PRE / 64>{}, q);      // the positions in front of the tile
+        consume(std::integral_constant<int, 0>{}, std::integral_constant<int, PRE / 64>{}, q);
+        static_for<0, RUN / G>([&](auto GI) {
+            constexpr int g0 = PRE / 64 + decltype(GI)::value * G;
+            issue(std::integral_constant<int, g0>{}, std::integral_constant<int, G>{}, q);
+            consume(std::integral_constant<int, g0>{}, std::integral_constant<int, G>{}, q);
+            walk(std::integral_constant<int, g0>{}, q);
+            pin(res2);
+            PHASE_FENCE();
+        });
+    }
+    // round layout -> run layout
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RUN; r++) hl.D[64 * r + lane] = (uint16_t)(res2[r >> 1] >> (16 * (r & 1)));
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&hl.D[32u * lane + 8u * q]);
+        best[8 * q + 0] = v.x & 0xFFFFu; best[8 * q + 1] = v.x >> 16;
+        best[8 * q + 2] = v.y & 0xFFFFu; best[8 * q + 3] = v.y >> 16;
+        best[8 * q + 4] = v.z & 0xFFFFu; best[8 * q + 5] = v.z >> 16;
+        best[8 * q + 6] = v.w & 0xFFFFu; best[8 * q + 7] = v.w >> 16;
+    }
+    __syncthreads();
 }
 
 // ---- phase 3, eligibility + extension (R3/R5; SEARCHF / SEARCH10, deflate.py:899-964, :1018-1062):
