@@ -34,6 +34,37 @@ int check_device() {
 }
 }  // namespace
 
+namespace hdlz {
+hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t stream) {
+    static hipMemPool_t pools[64] = {nullptr};
+    static bool tried[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    if (dev >= 0 && dev < 64 && !tried[dev]) {          // (a benign race at worst creates a pool twice)
+        tried[dev] = true;
+        hipMemPoolProps props;
+        memset(&props, 0, sizeof(props));
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        hipMemPool_t pool = nullptr;
+        if (hipMemPoolCreate(&pool, &props) == hipSuccess) {
+            uint64_t keep = ~0ull;
+            if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) pools[dev] = pool;
+            else (void)hipMemPoolDestroy(pool);
+        }
+        (void)hipGetLastError();
+    }
+    if (dev >= 0 && dev < 64 && pools[dev]) {
+        const hipError_t e = hipMallocFromPoolAsync(p, bytes, pools[dev], stream);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+    }
+    return hipMallocAsync(p, bytes, stream);
+}
+}  // namespace hdlz
+
 extern "C" {
 
 int hdlz_version(void) { return HDLZ_VERSION; }

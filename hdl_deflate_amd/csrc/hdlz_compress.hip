@@ -40,18 +40,6 @@ namespace hdlz {
 // own windows 32 and 256, and 64), which spares the per-position window compare; ONE_TILE: every block of the batch fits one
 // wave-tile (N <= 2048: BASELINE configs[1]'s block size and the reference's own IBSIZE scale) -- no tile loop, no halo
 // carried from a previous tile, no carried bit / Adler state
-#ifndef HDLZ_WH
-#define HDLZ_WH 3                               // waves per SIMD of the kernels with the hash finder (13.6 KB of LDS per wave: 12 per CU)
-#endif
-template <int NCH> constexpr bool wide_hash() {
-#ifdef HDLZ_CW64_BRUTE
-    return NCH > 2;
-#else
-    return NCH > 1;
-#endif
-}
-template <int NCH> constexpr int waves_eu() { return NCH == 1 ? HDLZ_W1 : wide_hash<NCH>() ? HDLZ_WH : NCH == 2 ? HDLZ_W2 : 4; }
-
 template <int NCH, bool FULLWIN, bool ONE_TILE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH>(), waves_eu<NCH>()))) void k_compress(CompressArgs a) {
     constexpr bool HASH = wide_hash<NCH>();         // windows > 32 (64: see HDLZ_CW64_BRUTE): the window-independent finder

@@ -474,6 +474,20 @@ __device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NC
     __syncthreads();
 }
 
+// which kernels use the hash finder, and the waves per SIMD they are register-capped for
+#ifndef HDLZ_WH
+#define HDLZ_WH 3                               // waves per SIMD of the kernels with the hash finder (13.6 KB of LDS per wave: 12 per CU)
+#endif
+template <int NCH> constexpr bool wide_hash() {
+#ifdef HDLZ_CW64_HASH
+    return NCH > 1;      // CWINDOW = 64 through the hash finder: 237 / 211 GB/s (text / families) against 247 for the one-pass brute force
+#else
+    return NCH > 2;
+#endif
+}
+template <int NCH> constexpr int waves_eu() { return NCH == 1 ? HDLZ_W1 : wide_hash<NCH>() ? HDLZ_WH : NCH == 2 ? HDLZ_W2 : 4; }
+
+
 // ---- phase 3, eligibility + extension (R3/R5; SEARCHF / SEARCH10, deflate.py:899-964, :1018-1062):
 // tok[i] = (len-1) << 16 | LUT byte offset of the token  (len-1 = 0 for a literal).
 //   lds_run  byte offset of the run in `in`;  nrem = positions of the block from the run's first position on (0 = none)

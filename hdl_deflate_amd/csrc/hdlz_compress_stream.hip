@@ -55,7 +55,10 @@ constexpr uint64_t XF_IDENT = 0x9876543210ull;                     // transfer f
 constexpr uint64_t XF_MARK = 0xFFFFFFFFFFFFFFFFull;                  // "not known yet: needs the full pass"
 
 #define HDLZ_STREAM_PROLOGUE()                                                                         \
-    __shared__ WaveLds lds;                                                                            \
+    constexpr bool HASH = wide_hash<NCH>();           /* wide windows: the window-independent finder */ \
+    __shared__ typename std::conditional<HASH, WaveLdsNoOut, WaveLds>::type lds;                       \
+    __shared__ typename std::conditional<HASH, HashLds<NCH>, uint32_t>::type hl;                       \
+    uint32_t* const lout = lds_out(lds, hl);          /* HASH: the bit buffer overlays the dead tables */ \
     const uint32_t lane = threadIdx.x;                                                                 \
     fill_luts<NCH>(lds.lut, lane);                                                                     \
     __syncthreads();                                                                                   \
@@ -64,7 +67,7 @@ constexpr uint64_t XF_MARK = 0xFFFFFFFFFFFFFFFFull;                  // "not kno
     const uint32_t n = a.n;                                                                            \
     uint8_t* lin8 = reinterpret_cast<uint8_t*>(lds.in);                                                \
     const uint8_t* lut8 = reinterpret_cast<const uint8_t*>(lds.lut);                                   \
-    uint8_t* out8 = reinterpret_cast<uint8_t*>(lds.out);                                               \
+    uint8_t* out8 = reinterpret_cast<uint8_t*>(lout);                                                  \
     (void)lut8; (void)out8; (void)kmax; (void)cw4;
 // tile t -> its block, its first position inside the block, the block's bytes
 #define HDLZ_TILE_COORDS(t)                                                                            \
@@ -83,13 +86,13 @@ __global__ __launch_bounds__(64) void k_stream_xfer(StreamArgs a) {
         HDLZ_TILE_COORDS(t)
 
         stage_tile(lin8, src, t0, n, aligned16, mis, lane);
-        for (uint32_t w = lane; w < OUT_WORDS; w += 64) lds.out[w] = 0u;
         __syncthreads();
         const uint32_t p_run = t0 + lane * RUN;
         const uint32_t nrem = n - min(p_run, n);
         const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);       // dword index of the run in lds.in
         uint32_t best[RUN], tok[RUN];
-        match_search<NCH>(lds.in, run_dw, best);                                                   // 2. R3/R4
+        if constexpr (HASH) match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);   // 2. R3/R4, wide windows
+        else match_search<NCH>(lds.in, run_dw, best);                                              // 2. R3/R4
         {
             uint32_t ow[12];
             load_own(lds.in, run_dw, ow);
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(64) void k_stream_offsets_blocks(StreamArgs a) {
 
 // ------------------------------------------------------------------------------------------------ pass C
 template <int NCH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? HDLZ_W1 : 4, NCH == 1 ? HDLZ_W1 : 4))) void k_stream_tile(StreamArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? HDLZ_W1 : wide_hash<NCH>() ? HDLZ_WH : 4, NCH == 1 ? HDLZ_W1 : wide_hash<NCH>() ? HDLZ_WH : 4))) void k_stream_tile(StreamArgs a) {
     HDLZ_STREAM_PROLOGUE()
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         HDLZ_TILE_COORDS(t)
@@ -330,14 +333,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
         const uint32_t base_bits = 0;                                // the tile's bits are built from local bit 0
 
         stage_tile(lin8, src, t0, n, aligned16, mis, lane);
-        for (uint32_t w = lane; w < OUT_WORDS; w += 64) lds.out[w] = 0u;
+        if constexpr (!HASH) for (uint32_t w = lane; w < OUT_WORDS; w += 64) lout[w] = 0u;
         __syncthreads();
         const uint32_t p_run = t0 + lane * RUN;
         const uint32_t nrem = n - min(p_run, n);
         const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);       // dword index of the run in lds.in
         uint32_t best[RUN], tok[RUN], code[RUN];
         uint32_t sa, sc;                                             // Adler partials of the run
-        match_search<NCH>(lds.in, run_dw, best);                                                   // 2. R3/R4
+        if constexpr (HASH) {
+            match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);                   // 2. R3/R4, wide windows
+            for (uint32_t w = lane; w < OUT_WORDS; w += 64) lout[w] = 0u;                          // (the bit buffer: in the finder's dead tables)
+        } else match_search<NCH>(lds.in, run_dw, best);                                            // 2. R3/R4
         {
             uint32_t ow[12];
             load_own(lds.in, run_dw, ow);
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
         {
             uint32_t* __restrict__ slot = a.tmp + (size_t)t * OUT_WORDS;
             const uint32_t nw = (tile_bits_all + 31u) >> 5;
-            for (uint32_t w = lane; w < nw; w += 64) slot[w] = lds.out[w];
+            for (uint32_t w = lane; w < nw; w += 64) slot[w] = lout[w];
         }
     }
 }

@@ -419,7 +419,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                  o_tk = take((size_t)nchunks * tmax_of(chbits) * 4u), o_nt = take((size_t)nchunks * 4u), o_sa = take((size_t)srcn * 4u),
                  o_sb = take((size_t)srcn * 4u);
     uint8_t* ws = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&ws), off, stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), off, stream);
     if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // no scratch: the caller goes on with the serial decoder
     e = hipMemsetAsync(ws + o_ctl, 0, 4u * C_WORDS, stream);
     if (e == hipSuccess) {

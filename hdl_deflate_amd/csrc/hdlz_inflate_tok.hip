@@ -757,7 +757,7 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
     uint32_t* ws = nullptr;
     // (the explicit lane hint keeps every such stream in the lane kernel)
     const uint32_t lane_min = (a.flags & HDLZ_INFLATE_LANE_PER_STREAM) ? 0u : HDLZ_INFLATE_DYN_LANE_MIN;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * (a.nstreams + 1u), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * (a.nstreams + 1u), stream);
     if (e != hipSuccess) {                      // no scratch: the wave-per-stream second pass needs none and finishes the job
         (void)hipGetLastError();
         return launch_inflate_dyn(a, stream, false);
