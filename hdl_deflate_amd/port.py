@@ -24,7 +24,8 @@ circular memories on both sides and work that overlaps WRITE and READ.
   * output: `oram` is the circular buffer of OBSIZE bytes (`o_byte = oram[i_raddr & OBS]`, deflate.py:601) and the
     engine is HELD while it could overwrite unread bytes: nothing is produced beyond `i_raddr + OBSIZE`
     (deflate.py:1531-1534, :1597-1599 for inflate; the reference's compress side has no such hold and simply
-    overwrites -- here both directions hold, which is the safe superset);
+    overwrites -- here both directions hold by default, the safe superset; `compress_hold=False` selects the reference's
+    overwrite behaviour);
   * `o_oprogress` counts the bytes produced so far, `o_done` rises when the last one is produced.
 Addresses and counters are LMAX bits wide (deflate.py:73-76: 24, or 16 in a LOWLUT build): ports wrap like the
 reference's modbv signals, and a stream whose input or output does not fit raises HdlzRangeError where MyHDL
@@ -91,7 +92,8 @@ class DeflatePort(object):
 
     def __init__(self, i_mode, o_done, i_data, o_iprogress, o_oprogress, o_byte, i_waddr, i_raddr,
                  clk=None, reset=None, engine=None, cwindow=CWINDOW, maxmatch=MAXMATCH,
-                 inflate_flags=0, obsize=0, stream_obsize=None, lmax=LMAX, streaming=False, ibsize=None, window=None):
+                 inflate_flags=0, obsize=0, stream_obsize=None, lmax=LMAX, streaming=False, ibsize=None, window=None,
+                 compress_hold=True):
         self.i_mode, self.o_done, self.i_data = i_mode, o_done, i_data
         self.o_iprogress, self.o_oprogress, self.o_byte = o_iprogress, o_oprogress, o_byte
         self.i_waddr, self.i_raddr, self.clk, self.reset = i_waddr, i_raddr, clk, reset
@@ -106,6 +108,11 @@ class DeflatePort(object):
         if stream_obsize is not None and (stream_obsize < 64 or stream_obsize & (stream_obsize - 1)):
             raise ValueError("stream_obsize must be a power of two >= 64")
         self.stream_obsize = stream_obsize
+        # streaming STARTC and a reader that lags: True (default) = the engine is held like the inflate side, the reader always gets
+        # the stream; False = the reference's behaviour -- put / do_flush write oram[do & OBS] unconditionally (deflate.py:535-567,
+        # no counterpart of the inflate hold deflate.py:1531-1534), so a reader more than OBSIZE behind reads overwritten bytes
+        # (fixture lagging_reader of tests/golden/streaming_r3_vectors.json: 654 bytes ahead of a 512-byte memory, not a stream)
+        self.compress_hold = bool(compress_hold)
         self.lmax = lmax
         self.mask = (1 << lmax) - 1
         self.streaming = bool(streaming)
@@ -265,7 +272,7 @@ class DeflatePort(object):
             self._set(self.o_iprogress, hi - 1)
         room = ra + self.stream_obsize - len(self.oram)  # bytes that may still be produced: the hold of deflate.py:1531-1534
         if self.state == self.ST_COMPRESS:
-            self._step_compress(s, room)
+            self._step_compress(s, room if self.compress_hold else 1 << 30)
         else:
             self._step_inflate(s, ra, room)
 

@@ -332,6 +332,59 @@ def test_streaming_compress_at_minimal_obsize():
         port_harness.stream_leg(dut, s, src[:100], STARTC, maxw=MAXW)
 
 
+def test_writer_timing_fixtures():
+    """VERDICT r2 #5a: what the reference emits when the writer supplies a byte every k-th iteration (oracle/gen_golden_r3.py, the
+    executed reference): k = 1, 2 give the eager stream (1260 bytes), k >= 3 a longer one (1262: fill_buf prefetched b5..b10
+    beyond isize during the stall of deflate.py:768-770 and SEARCHF cut a match short, deflate.py:913-952).  All of them inflate
+    to the input; the engine emits the EAGER stream for every arrival pattern -- a position is only encoded once its ten
+    look-ahead bytes are known -- which INTEGRATION.md states as the one documented divergence of the streaming port."""
+    g = load_golden("streaming_r3_vectors.json")
+    recs = {v["write_every"]: v for v in g["writer_timing"]}
+    assert set(recs) >= {1, 2, 3, 4, 6, 8}
+    payload = bytes.fromhex(recs[1]["in_hex"])
+    eager = bytes.fromhex(recs[1]["out_hex"])
+    eng = OracleEngine()
+    assert eng.compress_bytes(payload)[1] == eager
+    differ = []
+    for k, v in sorted(recs.items()):
+        ref = bytes.fromhex(v["out_hex"])
+        assert zlib.decompress(ref) == payload and v["oprogress"] == len(ref)
+        if ref != eager:
+            differ.append(k)
+        dut, s = make_dut(eng, streaming=True)
+        res, total, _, _ = port_harness.stream_leg(dut, s, payload, STARTC, maxw=MAXW, write_every=k)
+        assert res == eager and total == len(eager), k                      # the engine: one stream, whatever the timing
+    assert differ == [3, 4, 6, 8]                                             # the reference: timing-dependent from k = 3 on
+    assert all(len(bytes.fromhex(recs[k]["out_hex"])) == 1262 for k in differ) and len(eager) == 1260
+
+
+def test_compress_side_of_the_output_memory():
+    """VERDICT r2 #5b: a reader that lags a STARTC.  The reference has no hold on the compress side: with a byte read every 12th
+    iteration it runs 654 bytes ahead of its 512-byte oram and the reader does not get a stream (fixture lagging_reader);
+    every 6th iteration it stays within the memory and the stream is intact.  The port: compress_hold=True (default) never runs
+    ahead of the memory and always delivers the stream; compress_hold=False behaves like the reference -- it overruns and the
+    reader gets overwritten bytes (byte-exact equality with the reference's corrupted read is not defined: its progress is a
+    byte per clock, the engine's a window per launch)."""
+    g = load_golden("streaming_r3_vectors.json")
+    recs = {v["read_every"]: v for v in g["lagging_reader"]}
+    payload = bytes.fromhex(recs[12]["in_hex"])
+    eng = OracleEngine()
+    eager = eng.compress_bytes(payload)[1]
+    assert recs[6]["what_the_reader_got_is_a_valid_stream"] and bytes.fromhex(recs[6]["read_hex"]) == eager
+    assert recs[6]["stats"]["max_ahead_of_reader"] <= recs[6]["obsize"]
+    assert not recs[12]["what_the_reader_got_is_a_valid_stream"] and recs[12]["stats"]["max_ahead_of_reader"] > recs[12]["obsize"]
+    for k in (6, 12):
+        dut, s = make_dut(eng, streaming=True, stream_obsize=512)          # hold: the stream, never more than OBSIZE ahead
+        res, total, _, st = port_harness.stream_leg(dut, s, payload, STARTC, maxw=MAXW, read_every=k)
+        assert res == eager and total == len(eager) and st["max_ahead_of_reader"] <= 512
+    dut, s = make_dut(eng, streaming=True, stream_obsize=512, compress_hold=False)
+    res, total, _, st = port_harness.stream_leg(dut, s, payload, STARTC, maxw=MAXW, read_every=12)
+    assert total == len(eager) and st["max_ahead_of_reader"] > 512 and res != eager      # overwritten, as in the reference
+    dut, s = make_dut(eng, streaming=True, stream_obsize=512, compress_hold=False)
+    res, total, _, st = port_harness.stream_leg(dut, s, payload, STARTC, maxw=MAXW)       # an eager reader is never lapped
+    assert res == eager
+
+
 def test_streaming_ring_overrun_and_lmax():
     """bounded memories behave like the hardware's: addresses wrap at LMAX bits; an output that outgrows the progress
     counters raises where MyHDL raises "intbv value out of range" (LOWLUT build, LMAX = 16: deflate.py:73-76; fixture
