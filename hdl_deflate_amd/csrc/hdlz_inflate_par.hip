@@ -38,8 +38,9 @@ constexpr uint32_t CH_BITS_MAX = 8192;        // a piece: 1 KiB of the stream --
 constexpr uint32_t WIN_DW = CH_BITS_MAX / 32 + 8; // its staged window: the piece, the 31 + 64 bits a token starting at its end may read
 constexpr uint32_t FIRST_BIT = 19;            // 2 zlib header bytes, BFINAL, BTYPE
 constexpr uint32_t X_EOB = 0x40, X_BAD = 0x80;
+constexpr uint32_t SUB = 4;                   // sub-pieces per piece: the granularity of the real decode and the emit (k_par_spec)
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-enum { C_FALLBACK = 0, C_NUSED = 1, C_TOTAL = 2, C_OK = 3, C_MARK = 4, C_PASS0 = 8, C_WORDS = 64 };
+enum { C_FALLBACK = 0, C_NUSED = 1, C_TOTAL = 2, C_OK = 3, C_MARK = 4, C_FNUSED = 5, C_PASS0 = 8, C_WORDS = 64 };
 
 struct ParArgs {
     const uint8_t* z;
@@ -66,6 +67,10 @@ struct ParArgs {
     uint32_t* ntok;             // [nchunks]
     uint32_t* srcA;             // [srcn]  marker of every output byte (NONE = the byte is there), double-buffered for the jumps
     uint32_t* srcB;
+    uint32_t sub;               // k_par_spec: sub-pieces per piece (SUB), whose boundaries get maps of their own
+    uint8_t* mexit8;            // [nchunks][SUB-1][32]  offset behind sub-boundary s for entry offset e (X_EOB: the chain ended in front of it)
+    uint32_t* mnb32;            // [nchunks][SUB-1][32]  bytes of the tokens that start in front of that boundary
+    uint32_t cnu;               // the control word that holds the number of pieces in use at THIS granularity (C_NUSED / C_FNUSED)
 };
 
 __device__ __forceinline__ void fill_tables(uint32_t* lit, uint32_t* dst, uint32_t tid, uint32_t nthreads) {
@@ -87,6 +92,7 @@ __device__ __forceinline__ uint64_t bits_at(const uint32_t* win, uint32_t b_c, u
 }
 
 // ---- 1. speculative decode: lane (piece, offset)
+template <bool SUBMAPS>
 __global__ __launch_bounds__(64) void k_par_spec(ParArgs a) {
     __shared__ uint32_t lit[512], dst[32], win[2][WIN_DW];
     const uint32_t lane = threadIdx.x, half = lane >> 5, e = lane & 31u;
@@ -98,24 +104,50 @@ __global__ __launch_bounds__(64) void k_par_spec(ParArgs a) {
     __syncthreads();
     uint32_t pos = b_c + e, nbytes = 0, exitc = 0;
     bool run = have;
-    while (__ballot(run) != 0ull) {
-        if (run) {
-            const uint64_t x = bits_at(win[half], b_c, pos);
-            const uint32_t e0 = lit[(uint32_t)x & 511u];
-            const uint32_t nb = e0 & 15u, type = (e0 >> 13) & 3u;
-            if (nb == 0u || type == (uint32_t)T_BAD) { exitc = X_BAD; run = false; }
-            else if (type == (uint32_t)T_EOB) { exitc = X_EOB; run = false; }
-            else if (type == (uint32_t)T_LIT) { pos += nb; nbytes += 1u; }
-            else {
-                const uint32_t leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
-                uint64_t y = x >> nb;
-                const uint32_t tl = lbase + ((uint32_t)y & ((1u << leb) - 1u));
-                y >>= leb;
-                const uint32_t de = dst[(uint32_t)y & 31u];
-                if (de == 0xFFFFFFFFu) { exitc = X_BAD; run = false; }
-                else { pos += nb + leb + 5u + ((de >> 16) & 15u); nbytes += tl; }
+    // one token of the chain (lengths and byte counts only)
+    auto token = [&]() {
+        const uint64_t x = bits_at(win[half], b_c, pos);
+        const uint32_t e0 = lit[(uint32_t)x & 511u];
+        const uint32_t nb = e0 & 15u, type = (e0 >> 13) & 3u;
+        if (nb == 0u || type == (uint32_t)T_BAD) { exitc = X_BAD; run = false; }
+        else if (type == (uint32_t)T_EOB) { exitc = X_EOB; run = false; }
+        else if (type == (uint32_t)T_LIT) { pos += nb; nbytes += 1u; }
+        else {
+            const uint32_t leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
+            uint64_t y = x >> nb;
+            const uint32_t tl = lbase + ((uint32_t)y & ((1u << leb) - 1u));
+            y >>= leb;
+            const uint32_t de = dst[(uint32_t)y & 31u];
+            if (de == 0xFFFFFFFFu) { exitc = X_BAD; run = false; }
+            else { pos += nb + leb + 5u + ((de >> 16) & 15u); nbytes += tl; }
+        }
+    };
+    if constexpr (SUBMAPS) {
+        // The real decode (k_par_tokens) is ONE lane's serial chain per piece, ~1000 cycles per token at one wave per SIMD: for streams
+        // that do not fill the GPU it runs on pieces SUB times shorter than these -- the entry offsets and output positions at the
+        // sub-boundaries are read off here, where every chain passes them anyway (the decode work of this kernel does not depend on
+        // the piece size; its maps do not get finer).  One loop per sub-piece: the chains of the 32 offsets pass a boundary within
+        // one token of each other.  It still costs 25 % of this kernel (315 -> 393 us at 16 MiB, against -237 us in k_par_tokens);
+        // a per-token test with the stores under it cost 14 %, a shifting 64-bit bit buffer in place of bits_at 27 %.
+        const uint32_t nsub = a.sub, fb = a.chbits / nsub;
+        for (uint32_t sb = 1u; sb <= nsub; sb++) {
+            const uint32_t bound = b_c + sb * fb;            // (the last one: the end of the piece)
+            while (__ballot(run && pos < bound) != 0ull) {
+                if (run && pos < bound) token();
             }
-            if (run && pos >= end) { exitc = pos - end; run = false; }
+            if (have && sb < nsub) {
+                const uint32_t m = (c * (nsub - 1u) + (sb - 1u)) * 32u + e;
+                a.mexit8[m] = run ? (uint8_t)(pos - bound) : (uint8_t)X_EOB;      // (X_EOB: the chain ended in front of this boundary)
+                a.mnb32[m] = nbytes;
+            }
+        }
+        if (run) exitc = pos - end;
+    } else {
+        while (__ballot(run) != 0ull) {
+            if (run) {
+                token();
+                if (run && pos >= end) { exitc = pos - end; run = false; }
+            }
         }
     }
     if (have) { a.exit8[c * 32u + e] = (uint8_t)exitc; a.nb32[c * 32u + e] = nbytes; }
@@ -157,9 +189,10 @@ __global__ __launch_bounds__(64) void k_par_scan_groups(ParArgs a) {
 }
 __global__ __launch_bounds__(64) void k_par_scan_top(ParArgs a) {
     __shared__ GroupLds L;                                 // (the maps of 64 GROUPS at a time, staged like a group's pieces)
-    __shared__ uint8_t stp[GROUP * 32], ent[GROUP];
+    __shared__ __attribute__((aligned(16))) uint8_t stp[GROUP * 32];
+    __shared__ uint8_t ent[GROUP];
     __shared__ uint32_t op[GROUP];
-    __shared__ uint32_t sh_stop, sh_e, sh_bad, sh_nused;
+    __shared__ uint32_t sh_stop, sh_e, sh_bad, sh_nused, sh_cnt;
     __shared__ uint64_t sh_acc;
     const uint32_t lane = threadIdx.x;
     // the stream must be one fixed block (or be read as one: the DYNAMIC=False / ONEBLOCK builds)
@@ -172,22 +205,41 @@ __global__ __launch_bounds__(64) void k_par_scan_top(ParArgs a) {
     __syncthreads();
     for (uint32_t base = 0; base < ngroups && sh_stop == 0u; base += GROUP) {
         const uint32_t cnt = min(GROUP, ngroups - base);
-        for (uint32_t k = lane; k < cnt * 32u; k += 64u) {
-            L.ex[k] = a.gexit8[(size_t)base * 32u + k]; stp[k] = a.gstop8[(size_t)base * 32u + k]; L.nb[k] = a.gnb32[(size_t)base * 32u + k];
+        for (uint32_t k = lane; k < cnt * 8u; k += 64u) {                  // (dwords: byte loads made the staging the longest part of this kernel)
+            reinterpret_cast<uint32_t*>(L.ex)[k] = reinterpret_cast<const uint32_t*>(a.gexit8 + (size_t)base * 32u)[k];
+            reinterpret_cast<uint32_t*>(stp)[k] = reinterpret_cast<const uint32_t*>(a.gstop8 + (size_t)base * 32u)[k];
+        }
+        for (uint32_t k = lane; k < cnt * 32u; k += 64u) L.nb[k] = a.gnb32[(size_t)base * 32u + k];
+        __syncthreads();
+        // the chain through the groups is serial, so ONLY the offset look-up is on it (one dependent LDS read per group; with the
+        // byte counts on the same chain it was 250 ns per group: 74 of 1107 us at 16 MiB, 587 us at 256 MiB); the output positions
+        // are a prefix sum of the counts the chain picked -- one group per lane, a wave scan
+        if (lane == 0u) {
+            uint32_t e = sh_e, j = 0;
+            for (; j < cnt; j++) {
+                const uint32_t x = L.ex[j * 32u + e];
+                ent[j] = (uint8_t)e;
+                if (x & (X_EOB | X_BAD)) { sh_stop = 1u; sh_bad = x & X_BAD; sh_nused = (base + j) * GROUP + stp[j * 32u + e] + 1u; j++; break; }
+                e = x;
+            }
+            sh_e = e; sh_cnt = j;                           // groups walked in this batch (the one the chain ends in included)
         }
         __syncthreads();
-        if (lane == 0u) {
-            uint32_t e = sh_e;
-            uint64_t acc = sh_acc;
-            for (uint32_t j = 0; j < cnt; j++) {
-                const uint32_t x = L.ex[j * 32u + e];
-                ent[j] = (uint8_t)e; op[j] = (uint32_t)acc;
-                acc += L.nb[j * 32u + e];
-                if (x & (X_EOB | X_BAD)) { sh_stop = 1u; sh_bad = x & X_BAD; sh_nused = (base + j) * GROUP + stp[j * 32u + e] + 1u; break; }
-                e = x;
-                if (acc > 0xFFFFFFFFull) { sh_stop = 1u; sh_bad = 1u; break; }
+        {
+            const uint32_t walked = sh_cnt;
+            const uint64_t mine = lane < walked ? (uint64_t)L.nb[lane * 32u + ent[lane]] : 0ull;
+            uint64_t incl = mine;
+#pragma unroll
+            for (int ofs = 1; ofs < 64; ofs <<= 1) {
+                const uint64_t o = ((uint64_t)(uint32_t)__shfl_up((int)(incl >> 32), ofs, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)incl, ofs, 64);
+                if (lane >= (uint32_t)ofs) incl += o;
             }
-            sh_e = e; sh_acc = acc;
+            const uint64_t before = sh_acc + incl - mine;
+            if (lane < walked) op[lane] = (uint32_t)before;
+            const bool over = lane < walked && before + mine > 0xFFFFFFFFull;
+            __syncthreads();
+            if (__ballot(over) != 0ull && lane == 0u) { sh_stop = 1u; sh_bad = 1u; }
+            if (lane == 63u) sh_acc += incl;
         }
         __syncthreads();
         if (lane < cnt) { a.gentry8[base + lane] = ent[lane]; a.gopos[base + lane] = op[lane]; }
@@ -221,6 +273,25 @@ __global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a) {
     if (lane < cnt) { a.entry8[g * GROUP + lane] = ent[lane]; a.opos[g * GROUP + lane] = op[lane]; }
 }
 
+// ---- 2b. entry offsets and output positions of the SUB-pieces (what k_par_tokens and k_par_emit work on), from the maps k_par_spec
+// took at the sub-boundaries and the true entry offset of every piece
+__global__ __launch_bounds__(256) void k_par_refine(ParArgs a, uint8_t* fentry8, uint32_t* fopos) {
+    if (a.ctl[C_FALLBACK] != 0u) return;
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= a.ctl[C_NUSED]) return;
+    const uint32_t nsub = a.sub, e = a.entry8[c], P = a.opos[c], f = c * nsub;
+    fentry8[f] = (uint8_t)e; fopos[f] = P;
+    uint32_t reached = f;
+    for (uint32_t sb = 1; sb < nsub; sb++) {
+        const uint32_t m = (c * (nsub - 1u) + (sb - 1u)) * 32u + e;
+        const uint32_t x = a.mexit8[m];
+        if (x & (X_EOB | X_BAD)) break;                   // the chain ends in front of this boundary
+        fentry8[f + sb] = (uint8_t)x; fopos[f + sb] = P + a.mnb32[m];
+        reached = f + sb;
+    }
+    atomicMax(&a.ctl[C_FNUSED], reached + 1u);
+}
+
 // ---- 3a. the real decode, tokens only: one LANE per piece (64 pieces per wave), the reference's checks
 // in the reference's order, the tokens into a list per piece.  (One WAVE per piece decoding and copying kept the CU's one scalar unit
 // 89 % busy -- the token chain of a piece is wave-uniform, 115 scalar instructions per token: 8.2 of 13.7 ms at 256 MiB.)
@@ -230,7 +301,7 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
     __shared__ uint32_t lit[512], dst[32];
     const uint32_t lane = threadIdx.x;
     if (a.ctl[C_FALLBACK] != 0u) return;
-    const uint32_t nused = a.ctl[C_NUSED], c0 = blockIdx.x * 64u;
+    const uint32_t nused = a.ctl[a.cnu], c0 = blockIdx.x * 64u;
     if (c0 >= nused) return;
     fill_tables(lit, dst, lane, 64u);
     __syncthreads();
@@ -297,12 +368,18 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
     __shared__ uint32_t hm[HRING];
     const uint32_t lane = threadIdx.x, c = blockIdx.x;
     if (a.ctl[C_FALLBACK] != 0u || c >= a.ctl[C_NUSED]) return;
-    const uint32_t n = a.ntok[c];
-    const uint32_t* tk = a.tokens + (size_t)c * tmax_of(a.chbits);
+    // a piece's tokens are the lists of its sub-pieces, one behind the other (the decode runs on sub-pieces; the emit does not:
+    // the history in front of a wave's own output becomes markers, and with four times shorter pieces the marker passes doubled)
+    const uint32_t nsub = a.sub, fnused = a.ctl[C_FNUSED];
     const uint32_t cstart = a.opos[c];
     uint8_t* out = a.out;
     uint32_t* src = a.srcA;
     uint32_t Pb = cstart, nmark = 0;
+    for (uint32_t sbi = 0; sbi < nsub; sbi++) {
+    const uint32_t f = c * nsub + sbi;
+    if (f >= fnused) break;
+    const uint32_t n = a.ntok[f];
+    const uint32_t* tk = a.tokens + (size_t)f * tmax_of(a.chbits / nsub);
     for (uint32_t base = 0; base < n;) {
         const uint32_t k = base + lane;
         const uint32_t t = k < n ? tk[k] : 0u;
@@ -357,6 +434,7 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
         Pb += (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
         base += cnt;
     }
+    }
     if (nmark) atomicAdd(&a.ctl[C_MARK], nmark);
 }
 
@@ -410,13 +488,17 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     if (srcn > (1ull << 30)) return hipSuccess;            // (8 GiB of scratch: leave it to the serial decoder)
     const uint32_t chbits = zn < (3u << 20) ? CH_BITS_MAX / 4u : zn < (24u << 20) ? CH_BITS_MAX / 2u : CH_BITS_MAX;
     const uint32_t nchunks = (8u * zn - FIRST_BIT + chbits - 1u) / chbits;
+    // streams that do not fill the GPU with one lane per piece (the port's: LMAX = 24 bits = 16 MiB) decode sub-pieces
+    const uint32_t sub = zn < (24u << 20) ? SUB : 1u;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
     const uint32_t ngroups = (nchunks + GROUP - 1u) / GROUP;
     const size_t o_ctl = take(4u * C_WORDS), o_ex = take((size_t)nchunks * 32u), o_nb = take((size_t)nchunks * 128u),
                  o_en = take(nchunks), o_op = take((size_t)nchunks * 4u), o_gx = take((size_t)ngroups * 32u), o_gs = take((size_t)ngroups * 32u),
                  o_gn = take((size_t)ngroups * 128u), o_ge = take(ngroups), o_go = take((size_t)ngroups * 4u),
-                 o_tk = take((size_t)nchunks * tmax_of(chbits) * 4u), o_nt = take((size_t)nchunks * 4u), o_sa = take((size_t)srcn * 4u),
+                 o_mx = take((size_t)nchunks * (sub - 1u) * 32u), o_mn = take((size_t)nchunks * (sub - 1u) * 128u),
+                 o_fe = take((size_t)nchunks * sub), o_fo = take((size_t)nchunks * sub * 4u),
+                 o_tk = take((size_t)nchunks * sub * tmax_of(chbits / sub) * 4u), o_nt = take((size_t)nchunks * sub * 4u), o_sa = take((size_t)srcn * 4u),
                  o_sb = take((size_t)srcn * 4u);
     uint8_t* ws = nullptr;
     hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), off, stream);
@@ -427,16 +509,25 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                   reinterpret_cast<uint32_t*>(ws + o_ctl), ws + o_ex, reinterpret_cast<uint32_t*>(ws + o_nb), ws + o_en,
                   reinterpret_cast<uint32_t*>(ws + o_op), ws + o_gx, ws + o_gs, reinterpret_cast<uint32_t*>(ws + o_gn), ws + o_ge,
                   reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_tk), reinterpret_cast<uint32_t*>(ws + o_nt),
-                  reinterpret_cast<uint32_t*>(ws + o_sa), reinterpret_cast<uint32_t*>(ws + o_sb)};
+                  reinterpret_cast<uint32_t*>(ws + o_sa), reinterpret_cast<uint32_t*>(ws + o_sb), sub, ws + o_mx,
+                  reinterpret_cast<uint32_t*>(ws + o_mn), (uint32_t)C_NUSED};
+        // the same arguments at sub-piece granularity: what the real decode and the emit work on
+        ParArgs pf = p;
+        pf.nchunks = nchunks * sub; pf.chbits = chbits / sub; pf.cnu = C_FNUSED;
+        pf.entry8 = ws + o_fe; pf.opos = reinterpret_cast<uint32_t*>(ws + o_fo);
         uint32_t passes = 1;                                            // chains of up to `nchunks` hops, HOPS-fold shorter per pass
         for (uint64_t reach = 1; reach < (uint64_t)nchunks + 1u; reach *= HOPS) passes++;
         if (passes > C_WORDS - C_PASS0) passes = C_WORDS - C_PASS0;
-        hipLaunchKernelGGL(k_par_spec, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p);
+        if (sub > 1u) hipLaunchKernelGGL(k_par_spec<true>, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p);
+        else hipLaunchKernelGGL(k_par_spec<false>, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_groups, dim3(ngroups), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_top, dim3(1), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_pieces, dim3(ngroups), dim3(64), 0, stream, p);
-        hipLaunchKernelGGL(k_par_tokens, dim3((nchunks + 63u) / 64u), dim3(64), 0, stream, p);
-        hipLaunchKernelGGL(k_par_emit, dim3(nchunks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_par_refine, dim3((nchunks + 255u) / 256u), dim3(256), 0, stream, p, pf.entry8, pf.opos);
+        hipLaunchKernelGGL(k_par_tokens, dim3((pf.nchunks + 63u) / 64u), dim3(64), 0, stream, pf);
+        ParArgs pe = p;                                                 // the emit: pieces, reading the sub-pieces' token lists
+        pe.tokens = pf.tokens; pe.ntok = pf.ntok;
+        hipLaunchKernelGGL(k_par_emit, dim3(nchunks), dim3(64), 0, stream, pe);
         const uint32_t jgrid = (uint32_t)((srcn + 255u) / 256u < 8192u ? (srcn + 255u) / 256u : 8192u);
         for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(jgrid), dim3(256), 0, stream, p, j);
         hipLaunchKernelGGL(k_par_finish, dim3(1), dim3(64), 0, stream, p, passes);
