@@ -458,18 +458,20 @@ __device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NC
             PHASE_FENCE();
         });
     }
-    // round layout -> run layout
+    // round layout -> run layout.  res2[k] holds rounds 2k (low half) and 2k+1 of this lane: written as ONE dword at [k][lane]
+    // (16 conflict-free ds_write_b32 instead of 32 ds_write_b16); position p = 64 r + j sits in dword (r >> 1) * 64 + j, half r & 1,
+    // so the run of lane l -- positions 32 l .. 32 l + 31, all of round l >> 1 -- is 32 consecutive dwords and one half of each
     __syncthreads();
+    uint32_t* D32 = reinterpret_cast<uint32_t*>(hl.D);
 #pragma unroll
-    for (int r = 0; r < RUN; r++) hl.D[64 * r + lane] = (uint16_t)(res2[r >> 1] >> (16 * (r & 1)));
+    for (int k = 0; k < RUN / 2; k++) D32[64 * k + lane] = res2[k];
     __syncthreads();
+    const uint32_t dbase = (lane >> 2) * 64u + 32u * (lane & 1u), hsh = 16u * ((lane >> 1) & 1u);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint4 v = *reinterpret_cast<const uint4*>(&hl.D[32u * lane + 8u * q]);
-        best[8 * q + 0] = v.x & 0xFFFFu; best[8 * q + 1] = v.x >> 16;
-        best[8 * q + 2] = v.y & 0xFFFFu; best[8 * q + 3] = v.y >> 16;
-        best[8 * q + 4] = v.z & 0xFFFFu; best[8 * q + 5] = v.z >> 16;
-        best[8 * q + 6] = v.w & 0xFFFFu; best[8 * q + 7] = v.w >> 16;
+    for (int q = 0; q < 8; q++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&D32[dbase + 4u * q]);
+        best[4 * q + 0] = __builtin_amdgcn_ubfe(v.x, hsh, 16u); best[4 * q + 1] = __builtin_amdgcn_ubfe(v.y, hsh, 16u);
+        best[4 * q + 2] = __builtin_amdgcn_ubfe(v.z, hsh, 16u); best[4 * q + 3] = __builtin_amdgcn_ubfe(v.w, hsh, 16u);
     }
     __syncthreads();
 }

@@ -31,6 +31,7 @@ namespace par {
 using tok::T_BAD;
 using tok::T_EOB;
 using tok::T_LIT;
+using tok::T_LEN;
 
 constexpr uint32_t CH_BITS_MAX = 8192;        // a piece: 1 KiB of the stream -- 512 bytes for streams below 24 MiB, 256 below 3 MiB: a piece is ONE
                                               // wave's (lane's) serial chain in k_par_spec and k_par_tokens, and 16 MiB in 1 KiB pieces do not fill the
@@ -104,23 +105,30 @@ __global__ __launch_bounds__(64) void k_par_spec(ParArgs a) {
     __syncthreads();
     uint32_t pos = b_c + e, nbytes = 0, exitc = 0;
     bool run = have;
-    // one token of the chain (lengths and byte counts only)
+    // one token of the chain (lengths and byte counts only), branch-free: the 32 chains of a piece stand at different kinds of tokens
+    // at any moment, so a ladder of branches runs every path anyway and pays the exec-mask bookkeeping on top (the kernel is
+    // issue-bound: 9 waves per SIMD of ~450 token steps).  A token needs at most 9 + 5 + 5 bits here: a 32-bit window (two LDS
+    // dwords, one funnel shift) instead of bits_at's 64.
+    const uint32_t bit0 = 8u * ((b_c >> 3) & ~3u);
+    const uint32_t* w_ = win[half];
     auto token = [&]() {
-        const uint64_t x = bits_at(win[half], b_c, pos);
-        const uint32_t e0 = lit[(uint32_t)x & 511u];
-        const uint32_t nb = e0 & 15u, type = (e0 >> 13) & 3u;
-        if (nb == 0u || type == (uint32_t)T_BAD) { exitc = X_BAD; run = false; }
-        else if (type == (uint32_t)T_EOB) { exitc = X_EOB; run = false; }
-        else if (type == (uint32_t)T_LIT) { pos += nb; nbytes += 1u; }
-        else {
-            const uint32_t leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
-            uint64_t y = x >> nb;
-            const uint32_t tl = lbase + ((uint32_t)y & ((1u << leb) - 1u));
-            y >>= leb;
-            const uint32_t de = dst[(uint32_t)y & 31u];
-            if (de == 0xFFFFFFFFu) { exitc = X_BAD; run = false; }
-            else { pos += nb + leb + 5u + ((de >> 16) & 15u); nbytes += tl; }
-        }
+        const uint32_t rel = pos - bit0;
+        const uint32_t x = __builtin_amdgcn_alignbit(w_[(rel >> 5) + 1u], w_[rel >> 5], rel);       // (the shift is taken modulo 32)
+        const uint32_t e0 = lit[x & 511u];
+        const uint32_t nb = e0 & 15u, type = (e0 >> 13) & 3u, leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
+        const uint32_t y = x >> nb;
+        const uint32_t tl = lbase + __builtin_amdgcn_ubfe(y, 0u, leb);
+        const uint32_t de = dst[__builtin_amdgcn_ubfe(y, leb, 5u)];
+        const bool islit = type == (uint32_t)T_LIT;
+        const bool bad = (nb == 0u) | (type == (uint32_t)T_BAD) | ((type == (uint32_t)T_LEN) & (de == 0xFFFFFFFFu));
+        const bool eob = type == (uint32_t)T_EOB;
+        const uint32_t used = islit ? nb : nb + leb + 5u + ((de >> 16) & 15u);
+        const uint32_t made = islit ? 1u : tl;
+        const bool adv = !(bad | eob);
+        exitc = bad ? X_BAD : eob ? X_EOB : exitc;
+        pos += adv ? used : 0u;
+        nbytes += adv ? made : 0u;
+        run = adv;
     };
     if constexpr (SUBMAPS) {
         // The real decode (k_par_tokens) is ONE lane's serial chain per piece, ~1000 cycles per token at one wave per SIMD: for streams
@@ -355,17 +363,23 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
     if (__ballot(bad) != 0ull && lane == 0u) atomicExch(&a.ctl[C_FALLBACK], 1u);
 }
 
-// ---- 3b. the bytes: one wave per piece, 64 tokens at a time -- a wave scan gives every token its output position, the literals are
-// written in parallel, the copies in stream order (lane-parallel inside each copy).  The history in front of the piece's own output is
-// not there yet: a byte copied from there becomes a MARKER (src[p] = the absolute position it comes from), and a marker is copied like
-// a byte.  The piece's newest output lives in an LDS ring of bytes and markers too: the copies are a chain of round trips now.
+// ---- 3b. the bytes: one wave per piece, 64 tokens at a time.  A wave scan gives every token its output position; then the batch is
+// resolved BYTE-parallel: every output byte of the batch finds its token (binary search over the 64 start positions), a literal is
+// a value, a copied byte is a POINTER to its source distance bytes back -- inside the batch an index into the LDS ring, in front of
+// it a byte (or marker) the ring already holds -- and pointer jumping in LDS (ptr <- ptr[ptr], log2 of the longest in-batch chain
+// rounds; an overlapping copy is simply a chain through its own bytes) turns every pointer into a value.  The history in front of
+// the piece's own output is not there yet: a byte copied from there is a MARKER (src[p] = the absolute position it comes from), and
+// markers travel like bytes.  (Round 2 walked the copies of a batch one after the other, lane-parallel inside a copy: ~500 cycles per
+// copy, 257 of 879 us at 16 MiB, 3.4 of 10.7 ms at 256 MiB.)
 constexpr uint32_t HRING = 2048;
-constexpr uint32_t SPAN = 768;                // a batch ends with the token that takes its output beyond this many bytes (literals are
-                                              // written ahead of the copies in front of them)
-constexpr uint32_t HREACH = HRING - SPAN - 258u - 128u;   // distances served from the ring: nothing written ahead may alias them
+constexpr uint32_t SPAN = 768;                // a batch ends with the token that takes its output beyond this many bytes
+constexpr uint32_t HREACH = HRING - SPAN - 258u - 128u;   // distances served from the ring: a batch's own bytes may not alias them
+constexpr uint32_t P_RES = 0xFFFFu;           // pa[]: the slot holds its byte / marker
 __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
-    __shared__ uint8_t hb[HRING];
-    __shared__ uint32_t hm[HRING];
+    __shared__ uint8_t hb[HRING];             // ring over the piece's output positions: byte ...
+    __shared__ uint32_t hm[HRING];            // ... marker (NONE = the byte is there) ...
+    __shared__ uint16_t pa[HRING];            // ... or, while a batch is being resolved, the ring slot of its source
+    __shared__ uint32_t tP[64], tI[64];       // the batch's tokens: start (relative to the batch), token word
     const uint32_t lane = threadIdx.x, c = blockIdx.x;
     if (a.ctl[C_FALLBACK] != 0u || c >= a.ctl[C_NUSED]) return;
     // a piece's tokens are the lists of its sub-pieces, one behind the other (the decode runs on sub-pieces; the emit does not:
@@ -376,64 +390,97 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
     uint32_t* src = a.srcA;
     uint32_t Pb = cstart, nmark = 0;
     for (uint32_t sbi = 0; sbi < nsub; sbi++) {
-    const uint32_t f = c * nsub + sbi;
-    if (f >= fnused) break;
-    const uint32_t n = a.ntok[f];
-    const uint32_t* tk = a.tokens + (size_t)f * tmax_of(a.chbits / nsub);
-    for (uint32_t base = 0; base < n;) {
-        const uint32_t k = base + lane;
-        const uint32_t t = k < n ? tk[k] : 0u;
-        const bool islit = (t >> 31) != 0u;
-        const uint32_t len = k < n ? (islit ? 1u : (t & 511u)) : 0u;
-        uint32_t incl = len;
+        const uint32_t f = c * nsub + sbi;
+        if (f >= fnused) break;
+        const uint32_t n = a.ntok[f];
+        const uint32_t* tk = a.tokens + (size_t)f * tmax_of(a.chbits / nsub);
+        // (the piece's tokens staged in LDS first -- no global load in front of a batch -- cost more in occupancy than it saved: 245 -> 301 us)
+        for (uint32_t base = 0; base < n;) {
+            const uint32_t k = base + lane;
+            const uint32_t t = k < n ? tk[k] : 0u;
+            const bool islit = (t >> 31) != 0u;
+            const uint32_t len = k < n ? (islit ? 1u : (t & 511u)) : 0u;
+            uint32_t incl = len;
 #pragma unroll
-        for (int ofs = 1; ofs < 64; ofs <<= 1) {
-            const uint32_t o = __shfl_up(incl, ofs, 64);
-            if (lane >= (uint32_t)ofs) incl += o;
-        }
-        // the batch: the leading tokens up to the first one that ends beyond SPAN bytes (that one included)
-        const uint64_t over = __ballot(k < n && incl > SPAN);
-        const uint32_t cnt = min(over != 0ull ? (uint32_t)__builtin_ctzll(over) + 1u : 64u, n - base);
-        const bool mine = lane < cnt;
-        const uint32_t P = Pb + incl - len;
-        if (mine && islit) {
-            out[P] = (uint8_t)t; src[P] = NONE;
-            hb[P & (HRING - 1u)] = (uint8_t)t; hm[P & (HRING - 1u)] = NONE;
-        }
-        uint64_t mm = __ballot(mine && !islit);
-        while (mm != 0ull) {
-            const int j = __builtin_ctzll(mm);
-            mm &= mm - 1ull;
-            const uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, j);
-            const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)t, j);
-            const uint32_t tl = tj & 511u, D = tj >> 9;
-            // COPY (deflate.py:1627-1659): out[Pj+i] = out[Pj - D + (i mod D)]
-            const bool near = D <= HREACH && Pj - cstart >= D;            // the whole source is this piece's own, recent output
-            if (!near) {
-                // in-piece sources beyond the LDS ring were stored to out[] / src[] by OTHER lanes of this wave in earlier
-                // iterations: order those stores before the loads below (same-wave VMEM is ordered on gfx950,
-                // the fences make it a rule instead of an observation -- wave-uniform branch)
+            for (int ofs = 1; ofs < 64; ofs <<= 1) {
+                const uint32_t o = __shfl_up(incl, ofs, 64);
+                if (lane >= (uint32_t)ofs) incl += o;
+            }
+            // the batch: the leading tokens up to the first one that ends beyond SPAN bytes (that one included)
+            const uint64_t over = __ballot(k < n && incl > SPAN);
+            const uint32_t cnt = min(over != 0ull ? (uint32_t)__builtin_ctzll(over) + 1u : 64u, n - base);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));      // bytes of the batch (<= SPAN + 258)
+            __syncthreads();
+            tP[lane] = lane < cnt ? incl - len : 0xFFFFFFFFu;         // (sorted; the unused tail never compares <=)
+            tI[lane] = t;
+            __syncthreads();
+            // ---- every byte: its token, then value / marker / pointer
+            bool farin = false;
+            for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
+                const uint32_t q = q0 + lane;
+                if (q < total) {
+                    uint32_t lo = 0;
+#pragma unroll
+                    for (uint32_t st = 32u; st != 0u; st >>= 1) if (tP[lo + st] <= q) lo += st;      // (lo + st <= 63)
+                    const uint32_t tw = tI[lo];
+                    const uint32_t pabs = Pb + q, slot = pabs & (HRING - 1u);
+                    uint32_t v = tw & 255u, m = NONE, p = P_RES;
+                    if ((tw >> 31) == 0u) {
+                        const uint32_t D = tw >> 9, s = pabs - D;            // COPY (deflate.py:1627-1659): out[p] = out[p - D]
+                        if (s >= Pb) p = s & (HRING - 1u);                   // inside the batch: resolved by the jumps below
+                        else if (s < cstart) { v = 0u; m = s; }              // in front of the piece: a marker
+                        else if (Pb - s <= HREACH) { v = hb[s & (HRING - 1u)]; m = hm[s & (HRING - 1u)]; }      // the ring has it
+                        else { farin = true; p = 0xFFFEu; }                  // the piece's own output beyond the ring: below
+                    }
+                    hb[slot] = (uint8_t)v; hm[slot] = m; pa[slot] = (uint16_t)p;
+                }
+            }
+            if (__ballot(farin) != 0ull) {
+                // (rare: distances beyond HREACH into the piece's own output) those bytes were stored to out[] / src[] by this wave in
+                // earlier batches: order the stores before the loads (workgroup-scope release / acquire; wave-uniform branch)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
+                    const uint32_t q = q0 + lane, slot = (Pb + q) & (HRING - 1u);
+                    if (q < total && pa[slot] == 0xFFFEu) {
+                        uint32_t lo = 0;
+#pragma unroll
+                        for (uint32_t st = 32u; st != 0u; st >>= 1) if (tP[lo + st] <= q) lo += st;
+                        const uint32_t s = Pb + q - (tI[lo] >> 9);
+                        hb[slot] = out[s]; hm[slot] = src[s]; pa[slot] = (uint16_t)P_RES;
+                    }
+                }
             }
-            for (uint32_t i0 = 0; i0 < tl; i0 += 64u) {
-                const uint32_t i = i0 + lane;
-                if (i < tl) {
-                    uint32_t s = Pj - D + i;
-                    if (D < tl) s = Pj - D + i % D;                        // (an overlapping copy -- wave-uniform branch: a division)
-                    uint32_t m = s, v = 0;
-                    if (near) { m = hm[s & (HRING - 1u)]; v = hb[s & (HRING - 1u)]; }
-                    else if (s >= cstart) { m = src[s]; v = out[s]; }
-                    out[Pj + i] = (uint8_t)v;
-                    src[Pj + i] = m;
-                    hb[(Pj + i) & (HRING - 1u)] = (uint8_t)v; hm[(Pj + i) & (HRING - 1u)] = m;
+            __syncthreads();
+            // ---- pointer jumping inside the batch (reads of a round see the state the previous instruction left: one wave)
+            for (;;) {
+                bool open = false;
+                for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
+                    const uint32_t q = q0 + lane, slot = (Pb + q) & (HRING - 1u);
+                    if (q < total) {
+                        const uint32_t p = pa[slot];
+                        if (p != P_RES) {
+                            const uint32_t pp = pa[p];
+                            const uint32_t v = hb[p], m = hm[p];
+                            if (pp == P_RES) { hb[slot] = (uint8_t)v; hm[slot] = m; pa[slot] = (uint16_t)P_RES; }
+                            else { pa[slot] = (uint16_t)pp; open = true; }
+                        }
+                    }
+                }
+                if (__ballot(open) == 0ull) break;
+            }
+            // ---- the batch's bytes and markers to HBM
+            for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
+                const uint32_t q = q0 + lane, slot = (Pb + q) & (HRING - 1u);
+                if (q < total) {
+                    const uint32_t m = hm[slot];
+                    out[Pb + q] = hb[slot]; src[Pb + q] = m;
                     nmark += m != NONE ? 1u : 0u;
                 }
             }
+            Pb += total;
+            base += cnt;
         }
-        Pb += (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
-        base += cnt;
-    }
     }
     if (nmark) atomicAdd(&a.ctl[C_MARK], nmark);
 }
