@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) void k_par_scan_top(ParArgs a) {
         if (!good) a.ctl[C_FALLBACK] = 1u;
     }
 }
-__global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a) {
+__global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a, uint8_t* fentry8, uint32_t* fopos) {
     __shared__ GroupLds L;
     __shared__ uint8_t ent[GROUP];
     __shared__ uint32_t op[GROUP];
@@ -279,25 +279,22 @@ __global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a) {
     }
     __syncthreads();
     if (lane < cnt) { a.entry8[g * GROUP + lane] = ent[lane]; a.opos[g * GROUP + lane] = op[lane]; }
-}
-
-// ---- 2b. entry offsets and output positions of the SUB-pieces (what k_par_tokens and k_par_emit work on), from the maps k_par_spec
-// took at the sub-boundaries and the true entry offset of every piece
-__global__ __launch_bounds__(256) void k_par_refine(ParArgs a, uint8_t* fentry8, uint32_t* fopos) {
-    if (a.ctl[C_FALLBACK] != 0u) return;
-    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
-    if (c >= a.ctl[C_NUSED]) return;
-    const uint32_t nsub = a.sub, e = a.entry8[c], P = a.opos[c], f = c * nsub;
-    fentry8[f] = (uint8_t)e; fopos[f] = P;
-    uint32_t reached = f;
-    for (uint32_t sb = 1; sb < nsub; sb++) {
-        const uint32_t m = (c * (nsub - 1u) + (sb - 1u)) * 32u + e;
-        const uint32_t x = a.mexit8[m];
-        if (x & (X_EOB | X_BAD)) break;                   // the chain ends in front of this boundary
-        fentry8[f + sb] = (uint8_t)x; fopos[f + sb] = P + a.mnb32[m];
-        reached = f + sb;
+    // ---- 2b. entry offsets and output positions of the SUB-pieces (what k_par_tokens works on), from the maps k_par_spec took at the
+    // sub-boundaries and the true entry offset of the piece (one lane per piece; a launch of its own cost 9 us)
+    const uint32_t c = g * GROUP + lane;
+    if (lane < cnt && c < a.ctl[C_NUSED]) {
+        const uint32_t nsub = a.sub, e = ent[lane], P = op[lane], f = c * nsub;
+        fentry8[f] = (uint8_t)e; fopos[f] = P;
+        uint32_t reached = f;
+        for (uint32_t sb = 1; sb < nsub; sb++) {
+            const uint32_t m = (c * (nsub - 1u) + (sb - 1u)) * 32u + e;
+            const uint32_t x = a.mexit8[m];
+            if (x & (X_EOB | X_BAD)) break;               // the chain ends in front of this boundary
+            fentry8[f + sb] = (uint8_t)x; fopos[f + sb] = P + a.mnb32[m];
+            reached = f + sb;
+        }
+        atomicMax(&a.ctl[C_FNUSED], reached + 1u);
     }
-    atomicMax(&a.ctl[C_FNUSED], reached + 1u);
 }
 
 // ---- 3a. the real decode, tokens only: one LANE per piece (64 pieces per wave), the reference's checks
@@ -486,7 +483,7 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
 }
 
 // ---- 4. one pass of pointer jumping over the markers
-constexpr uint32_t HOPS = 8;
+constexpr uint32_t HOPS = 32;                 // (8 until round 3: the passes that find nothing left still cost a launch, 4.5 us each)
 __global__ __launch_bounds__(256) void k_par_jump(ParArgs a, uint32_t pass) {
     if (a.ctl[C_FALLBACK] != 0u) return;
     if (a.ctl[pass == 0u ? (uint32_t)C_MARK : C_PASS0 + pass - 1u] == 0u) return;            // nothing left
@@ -569,8 +566,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         else hipLaunchKernelGGL(k_par_spec<false>, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_groups, dim3(ngroups), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_top, dim3(1), dim3(64), 0, stream, p);
-        hipLaunchKernelGGL(k_par_scan_pieces, dim3(ngroups), dim3(64), 0, stream, p);
-        hipLaunchKernelGGL(k_par_refine, dim3((nchunks + 255u) / 256u), dim3(256), 0, stream, p, pf.entry8, pf.opos);
+        hipLaunchKernelGGL(k_par_scan_pieces, dim3(ngroups), dim3(64), 0, stream, p, pf.entry8, pf.opos);
         hipLaunchKernelGGL(k_par_tokens, dim3((pf.nchunks + 63u) / 64u), dim3(64), 0, stream, pf);
         ParArgs pe = p;                                                 // the emit: pieces, reading the sub-pieces' token lists
         pe.tokens = pf.tokens; pe.ntok = pf.ntok;
