@@ -161,6 +161,145 @@ __global__ __launch_bounds__(64) void k_par_spec(ParArgs a) {
     if (have) { a.exit8[c * 32u + e] = (uint8_t)exitc; a.nb32[c * 32u + e] = nbytes; }
 }
 
+// ---- 1'. the same maps with the 32-fold work only where it is needed (round 3).  Chains that start at different offsets of a piece fall
+// into step at the first token boundary they share -- about one chance in nine per token -- and are ONE chain from there on.  So:
+//   k_par_head     all 32 offsets of a piece decode its first HEAD_BITS bits only (6 % of k_par_spec's work at 512-byte pieces); the
+//                  lanes that stand at the same bit afterwards are one chain: its first lane appends it to a global chain list;
+//   k_par_tail     one LANE per listed chain decodes the rest of its piece (exit offset, byte counts, the sub-boundary maps);
+//   k_par_resolve  every (piece, offset) takes its chain's results (+ its own bytes of the head) -- the arrays k_par_scan_* read.
+// Nothing is assumed about the data: a stream whose chains never merge (a period of a few tokens) lists 32 chains per piece and costs
+// what k_par_spec cost, plus the head.  Ordinary data lists two or three.
+constexpr uint32_t HEAD_BITS = 256;
+struct Chains {
+    uint32_t* rep;              // [nchunks][32]  the chain of (piece, offset); NONE: ended inside the head (its maps are final)
+    uint32_t* cpos;             // [chains]  bit position at which the chain stands behind the head
+    uint8_t* cexit;             // [chains]  exit offset of the piece / X_EOB / X_BAD
+    uint32_t* cnb;              // [chains]  bytes from cpos to the end of the piece
+    uint8_t* cmx;               // [chains][SUB-1]  the sub-boundary maps, as in ParArgs::mexit8 / mnb32 (bytes from cpos on)
+    uint32_t* cmn;
+};
+enum { C_NCHAIN = 6 };
+
+// one token of a chain, lengths and byte counts only, branch-free (see k_par_spec); x = the next 32 stream bits
+__device__ __forceinline__ void spec_token(uint32_t x, const uint32_t* lit, const uint32_t* dst, uint32_t& pos, uint32_t& nbytes,
+                                           uint32_t& exitc, bool& run, uint32_t& used_out) {
+    const uint32_t e0 = lit[x & 511u];
+    const uint32_t nb = e0 & 15u, type = (e0 >> 13) & 3u, leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
+    const uint32_t y = x >> nb;
+    const uint32_t tl = lbase + __builtin_amdgcn_ubfe(y, 0u, leb);
+    const uint32_t de = dst[__builtin_amdgcn_ubfe(y, leb, 5u)];
+    const bool islit = type == (uint32_t)T_LIT;
+    const bool bad = (nb == 0u) | (type == (uint32_t)T_BAD) | ((type == (uint32_t)T_LEN) & (de == 0xFFFFFFFFu));
+    const bool eob = type == (uint32_t)T_EOB;
+    const uint32_t used = islit ? nb : nb + leb + 5u + ((de >> 16) & 15u);
+    const uint32_t made = islit ? 1u : tl;
+    const bool adv = !(bad | eob);
+    exitc = bad ? X_BAD : eob ? X_EOB : exitc;
+    used_out = adv ? used : 0u;
+    pos += used_out;
+    nbytes += adv ? made : 0u;
+    run = adv;
+}
+
+__global__ __launch_bounds__(64) void k_par_head(ParArgs a, Chains ch) {
+    __shared__ uint32_t lit[512], dst[32], win[2][HEAD_BITS / 32 + 8], first[2][32], slotof[2][32];
+    const uint32_t lane = threadIdx.x, half = lane >> 5, e = lane & 31u;
+    fill_tables(lit, dst, lane, 64u);
+    first[half][e] = 0xFFFFFFFFu;
+    const uint32_t c = blockIdx.x * 2u + half;
+    const bool have = c < a.nchunks;
+    const uint32_t b_c = FIRST_BIT + c * a.chbits, hb = b_c + HEAD_BITS;
+    if (have) stage_window(win[half], a.z, a.zn, b_c, HEAD_BITS, e, 32u);
+    __syncthreads();
+    uint32_t pos = b_c + e, nbytes = 0, exitc = 0, used;
+    bool run = have;
+    const uint32_t bit0 = 8u * ((b_c >> 3) & ~3u);
+    const uint32_t* w_ = win[half];
+    while (__ballot(run && pos < hb) != 0ull) {
+        if (run && pos < hb) {
+            const uint32_t rel = pos - bit0;
+            spec_token(__builtin_amdgcn_alignbit(w_[(rel >> 5) + 1u], w_[rel >> 5], rel), lit, dst, pos, nbytes, exitc, run, used);
+        }
+    }
+    const uint32_t key = (pos - hb) & 31u;                 // (a token is at most 32 bits long)
+    if (run) atomicMin(&first[half][key], e);
+    __syncthreads();
+    const bool leader = run && first[half][key] == e;
+    const uint64_t lm = __ballot(leader);
+    uint32_t base = 0;
+    if (lm != 0ull) {
+        if (lane == 0u) base = atomicAdd(&a.ctl[C_NCHAIN], (uint32_t)__popcll(lm));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    }
+    if (leader) {
+        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+        slotof[half][key] = slot;
+        ch.cpos[slot] = pos;
+    }
+    __syncthreads();
+    if (have) {
+        const uint32_t t = c * 32u + e;
+        a.nb32[t] = nbytes;                                // the bytes of the head; k_par_resolve adds the chain's
+        if (run) ch.rep[t] = slotof[half][key];
+        else {
+            ch.rep[t] = NONE;
+            a.exit8[t] = (uint8_t)exitc;
+            for (uint32_t sb = 1u; sb < a.sub; sb++) a.mexit8[(c * (a.sub - 1u) + (sb - 1u)) * 32u + e] = (uint8_t)X_EOB;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_par_tail(ParArgs a, Chains ch) {
+    __shared__ uint32_t lit[512], dst[32];
+    const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
+    const uint32_t nchain = a.ctl[C_NCHAIN];
+    if (blockIdx.x * 64u >= nchain) return;
+    fill_tables(lit, dst, lane, 64u);
+    __syncthreads();
+    const bool have = i < nchain;
+    uint32_t pos = have ? ch.cpos[i] : FIRST_BIT;
+    const uint32_t c = (pos - FIRST_BIT) / a.chbits;
+    const uint32_t b_c = FIRST_BIT + c * a.chbits, end = b_c + a.chbits;
+    const uint32_t nsub = a.sub, fb = a.chbits / nsub;
+    // bit reader straight from the stream, as in k_par_tokens (the lanes of a wave stand in different pieces)
+    uint32_t ip = (pos >> 3) & ~3u, bc = 64u - (pos - 8u * ip);
+    uint64_t bb = have ? (((uint64_t)tok::load32(a.z, ip + 4u, a.zn) << 32) | tok::load32(a.z, ip, a.zn)) >> (pos - 8u * ip) : 0ull;
+    ip += 8u;
+    uint32_t nxt = have ? tok::load32(a.z, ip, a.zn) : 0u;
+    uint32_t nbytes = 0, exitc = 0, used;
+    bool run = have;
+    for (uint32_t sb = 1u; sb <= nsub; sb++) {
+        const uint32_t bound = b_c + sb * fb;
+        while (__ballot(run && pos < bound) != 0ull) {
+            if (run && pos < bound) {
+                if (bc <= 32u) { bb |= (uint64_t)nxt << bc; bc += 32u; ip += 4u; nxt = tok::load32(a.z, ip, a.zn); }
+                spec_token((uint32_t)bb, lit, dst, pos, nbytes, exitc, run, used);
+                bb >>= used; bc -= used;
+            }
+        }
+        if (have && sb < nsub) {
+            ch.cmx[i * (nsub - 1u) + (sb - 1u)] = run ? (uint8_t)(pos - bound) : (uint8_t)X_EOB;
+            ch.cmn[i * (nsub - 1u) + (sb - 1u)] = nbytes;
+        }
+    }
+    if (have) { ch.cexit[i] = run ? (uint8_t)(pos - end) : (uint8_t)exitc; ch.cnb[i] = nbytes; }
+}
+
+__global__ __launch_bounds__(256) void k_par_resolve(ParArgs a, Chains ch) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= a.nchunks * 32u) return;
+    const uint32_t r = ch.rep[t];
+    if (r == NONE) return;
+    const uint32_t c = t >> 5, e = t & 31u, nsub = a.sub, hnb = a.nb32[t];
+    a.exit8[t] = ch.cexit[r];
+    a.nb32[t] = hnb + ch.cnb[r];
+    for (uint32_t sb = 1u; sb < nsub; sb++) {
+        const uint32_t m = (c * (nsub - 1u) + (sb - 1u)) * 32u + e;
+        a.mexit8[m] = ch.cmx[r * (nsub - 1u) + (sb - 1u)];
+        a.mnb32[m] = hnb + ch.cmn[r * (nsub - 1u) + (sb - 1u)];
+    }
+}
+
 // ---- 2. the true chain through the pieces.  The maps compose: (a) every group of 64 pieces is walked from all 32 entry offsets at
 // once, (b) one wave walks the groups from the stream's first token on, (c) every group walks its pieces again from its true
 // entry offset and writes their entry offsets and output positions.  (One wave over all the pieces: 115 ns per piece, more than
@@ -370,13 +509,15 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
 // copy, 257 of 879 us at 16 MiB, 3.4 of 10.7 ms at 256 MiB.)
 constexpr uint32_t HRING = 2048;
 constexpr uint32_t SPAN = 768;                // a batch ends with the token that takes its output beyond this many bytes
-constexpr uint32_t HREACH = HRING - SPAN - 258u - 128u;   // distances served from the ring: a batch's own bytes may not alias them
+constexpr uint32_t HREACH = HRING - 128u;     // distances served from the ring (it is written a 64-byte slice at a time)
 constexpr uint32_t P_RES = 0xFFFFu;           // pa[]: the slot holds its byte / marker
 __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
     __shared__ uint8_t hb[HRING];             // ring over the piece's output positions: byte ...
     __shared__ uint32_t hm[HRING];            // ... marker (NONE = the byte is there) ...
     __shared__ uint16_t pa[HRING];            // ... or, while a batch is being resolved, the ring slot of its source
-    __shared__ uint32_t tP[64], tI[64];       // the batch's tokens: start (relative to the batch), token word
+    __shared__ uint32_t tI[64];               // the batch's token words
+    __shared__ uint64_t bmw[17];              // token starts, one bit per byte of the batch
+    __shared__ uint32_t bpre[17];             // token starts in front of each 64-byte slice
     const uint32_t lane = threadIdx.x, c = blockIdx.x;
     if (a.ctl[C_FALLBACK] != 0u || c >= a.ctl[C_NUSED]) return;
     // a piece's tokens are the lists of its sub-pieces, one behind the other (the decode runs on sub-pieces; the emit does not:
@@ -407,71 +548,65 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
             const uint64_t over = __ballot(k < n && incl > SPAN);
             const uint32_t cnt = min(over != 0ull ? (uint32_t)__builtin_ctzll(over) + 1u : 64u, n - base);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));      // bytes of the batch (<= SPAN + 258)
+            // the token of a byte: token starts as a bitmap over the batch's bytes (one 64-bit word per 64-byte slice) + the
+            // number of starts in front of each word -- two broadcast reads and a bit count per slice (a binary search over the 64
+            // start positions was six DEPENDENT LDS reads per slice)
             __syncthreads();
-            tP[lane] = lane < cnt ? incl - len : 0xFFFFFFFFu;         // (sorted; the unused tail never compares <=)
+            if (lane < 17u) bmw[lane] = 0ull;
             tI[lane] = t;
             __syncthreads();
-            // ---- every byte: its token, then value / marker / pointer
-            bool farin = false;
-            for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
-                const uint32_t q = q0 + lane;
-                if (q < total) {
-                    uint32_t lo = 0;
+            if (lane < cnt) atomicOr(&bmw[(incl - len) >> 6], 1ull << ((incl - len) & 63u));
+            __syncthreads();
+            {
+                const uint32_t cw = lane < 17u ? (uint32_t)__popcll(bmw[lane]) : 0u;
+                uint32_t ci = cw;
 #pragma unroll
-                    for (uint32_t st = 32u; st != 0u; st >>= 1) if (tP[lo + st] <= q) lo += st;      // (lo + st <= 63)
-                    const uint32_t tw = tI[lo];
-                    const uint32_t pabs = Pb + q, slot = pabs & (HRING - 1u);
-                    uint32_t v = tw & 255u, m = NONE, p = P_RES;
-                    if ((tw >> 31) == 0u) {
-                        const uint32_t D = tw >> 9, s = pabs - D;            // COPY (deflate.py:1627-1659): out[p] = out[p - D]
-                        if (s >= Pb) p = s & (HRING - 1u);                   // inside the batch: resolved by the jumps below
-                        else if (s < cstart) { v = 0u; m = s; }              // in front of the piece: a marker
-                        else if (Pb - s <= HREACH) { v = hb[s & (HRING - 1u)]; m = hm[s & (HRING - 1u)]; }      // the ring has it
-                        else { farin = true; p = 0xFFFEu; }                  // the piece's own output beyond the ring: below
-                    }
-                    hb[slot] = (uint8_t)v; hm[slot] = m; pa[slot] = (uint16_t)p;
+                for (int ofs = 1; ofs < 32; ofs <<= 1) {
+                    const uint32_t o = __shfl_up(ci, ofs, 64);
+                    if (lane >= (uint32_t)ofs) ci += o;
                 }
-            }
-            if (__ballot(farin) != 0ull) {
-                // (rare: distances beyond HREACH into the piece's own output) those bytes were stored to out[] / src[] by this wave in
-                // earlier batches: order the stores before the loads (workgroup-scope release / acquire; wave-uniform branch)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
-                    const uint32_t q = q0 + lane, slot = (Pb + q) & (HRING - 1u);
-                    if (q < total && pa[slot] == 0xFFFEu) {
-                        uint32_t lo = 0;
-#pragma unroll
-                        for (uint32_t st = 32u; st != 0u; st >>= 1) if (tP[lo + st] <= q) lo += st;
-                        const uint32_t s = Pb + q - (tI[lo] >> 9);
-                        hb[slot] = out[s]; hm[slot] = src[s]; pa[slot] = (uint16_t)P_RES;
-                    }
-                }
+                if (lane < 17u) bpre[lane] = ci - cw;
             }
             __syncthreads();
-            // ---- pointer jumping inside the batch (reads of a round see the state the previous instruction left: one wave)
-            for (;;) {
-                bool open = false;
-                for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
-                    const uint32_t q = q0 + lane, slot = (Pb + q) & (HRING - 1u);
-                    if (q < total) {
-                        const uint32_t p = pa[slot];
-                        if (p != P_RES) {
-                            const uint32_t pp = pa[p];
-                            const uint32_t v = hb[p], m = hm[p];
-                            if (pp == P_RES) { hb[slot] = (uint8_t)v; hm[slot] = m; pa[slot] = (uint16_t)P_RES; }
-                            else { pa[slot] = (uint16_t)pp; open = true; }
-                        }
+            // ---- ONE ascending sweep over the slices: a copied byte is a POINTER to its source `distance` back.  Sources in earlier
+            // slices (or in front of the batch) are final by now and are read as values; only chains INSIDE the slice -- distances
+            // below 64 -- are followed (ptr <- ptr[ptr], log2 of the longest such chain rounds; an overlapping copy is a chain
+            // through its own bytes).  (All slices per round, every round: 107 of the emit's 247 us.)
+            for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
+                const uint32_t q = q0 + lane;
+                const bool in = q < total;
+                const uint64_t wbits = bmw[q0 >> 6];
+                const uint32_t ti = bpre[q0 >> 6] + __builtin_amdgcn_mbcnt_hi((uint32_t)(wbits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wbits, 0u)) +
+                                    (uint32_t)((wbits >> lane) & 1ull) - 1u;
+                const uint32_t tw = tI[in ? ti : 0u];
+                const uint32_t pabs = Pb + q, slot = pabs & (HRING - 1u);
+                uint32_t v = tw & 255u, m = NONE, p = P_RES;
+                bool farin = false;
+                if (in && (tw >> 31) == 0u) {
+                    const uint32_t D = tw >> 9, s = pabs - D;                // COPY (deflate.py:1627-1659): out[p] = out[p - D]
+                    if (s >= Pb + q0) p = s & (HRING - 1u);                  // inside this slice: followed below
+                    else if (s < cstart) { v = 0u; m = s; }                  // in front of the piece: a marker
+                    else if (pabs - s <= HREACH) { v = hb[s & (HRING - 1u)]; m = hm[s & (HRING - 1u)]; }      // the ring has it (final)
+                    else farin = true;                                       // the piece's own output beyond the ring
+                }
+                if (__ballot(farin) != 0ull) {
+                    // (rare) those bytes were stored to out[] / src[] by this wave in earlier batches: order the stores before the
+                    // loads (workgroup-scope release / acquire; wave-uniform branch)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (farin) { const uint32_t s = pabs - (tw >> 9); v = out[s]; m = src[s]; }
+                }
+                if (in) { hb[slot] = (uint8_t)v; hm[slot] = m; pa[slot] = (uint16_t)p; }
+                while (__ballot(p != P_RES) != 0ull) {
+                    if (p != P_RES) {
+                        const uint32_t pp = pa[p];
+                        const uint32_t vv = hb[p], mm = hm[p];
+                        if (pp == P_RES) { v = vv; m = mm; p = P_RES; hb[slot] = (uint8_t)v; hm[slot] = m; pa[slot] = (uint16_t)P_RES; }
+                        else { p = pp; pa[slot] = (uint16_t)pp; }
                     }
                 }
-                if (__ballot(open) == 0ull) break;
-            }
-            // ---- the batch's bytes and markers to HBM
-            for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
-                const uint32_t q = q0 + lane, slot = (Pb + q) & (HRING - 1u);
-                if (q < total) {
-                    const uint32_t m = hm[slot];
-                    out[Pb + q] = hb[slot]; src[Pb + q] = m;
+                if (in) {
+                    out[pabs] = (uint8_t)v; src[pabs] = m;
                     nmark += m != NONE ? 1u : 0u;
                 }
             }
@@ -543,7 +678,9 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                  o_mx = take((size_t)nchunks * (sub - 1u) * 32u), o_mn = take((size_t)nchunks * (sub - 1u) * 128u),
                  o_fe = take((size_t)nchunks * sub), o_fo = take((size_t)nchunks * sub * 4u),
                  o_tk = take((size_t)nchunks * sub * tmax_of(chbits / sub) * 4u), o_nt = take((size_t)nchunks * sub * 4u), o_sa = take((size_t)srcn * 4u),
-                 o_sb = take((size_t)srcn * 4u);
+                 o_sb = take((size_t)srcn * 4u),
+                 o_rp = take((size_t)nchunks * 128u), o_cp = take((size_t)nchunks * 128u), o_cx = take((size_t)nchunks * 32u),
+                 o_cn = take((size_t)nchunks * 128u), o_cmx = take((size_t)nchunks * 32u * (sub - 1u)), o_cmn = take((size_t)nchunks * 128u * (sub - 1u));
     uint8_t* ws = nullptr;
     hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), off, stream);
     if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // no scratch: the caller goes on with the serial decoder
@@ -562,8 +699,16 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         uint32_t passes = 1;                                            // chains of up to `nchunks` hops, HOPS-fold shorter per pass
         for (uint64_t reach = 1; reach < (uint64_t)nchunks + 1u; reach *= HOPS) passes++;
         if (passes > C_WORDS - C_PASS0) passes = C_WORDS - C_PASS0;
+#ifdef HDLZ_PAR_SPEC32
         if (sub > 1u) hipLaunchKernelGGL(k_par_spec<true>, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p);
         else hipLaunchKernelGGL(k_par_spec<false>, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p);
+#else
+        Chains ch{reinterpret_cast<uint32_t*>(ws + o_rp), reinterpret_cast<uint32_t*>(ws + o_cp), ws + o_cx, reinterpret_cast<uint32_t*>(ws + o_cn),
+                  ws + o_cmx, reinterpret_cast<uint32_t*>(ws + o_cmn)};
+        hipLaunchKernelGGL(k_par_head, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p, ch);
+        hipLaunchKernelGGL(k_par_tail, dim3((nchunks * 32u + 63u) / 64u), dim3(64), 0, stream, p, ch);
+        hipLaunchKernelGGL(k_par_resolve, dim3((nchunks * 32u + 255u) / 256u), dim3(256), 0, stream, p, ch);
+#endif
         hipLaunchKernelGGL(k_par_scan_groups, dim3(ngroups), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_top, dim3(1), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_pieces, dim3(ngroups), dim3(64), 0, stream, p, pf.entry8, pf.opos);

@@ -6,4 +6,4 @@ for cw in 256; do
 done
 python tools/bench_single_stream.py 1 4 16 64 256 2>&1 | tail -5
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for m in 16; do rm -rf gpurun_out/tl$m; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl$m -o t -- python tools/bench_single_stream.py $m > /dev/null 2>&1; echo "== $m MiB"; python tools/par_timeline.py gpurun_out/tl$m | head -9; rm -rf gpurun_out/tl$m; done
+for m in 1 16; do rm -rf gpurun_out/tl$m; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl$m -o t -- python tools/bench_single_stream.py $m > /dev/null 2>&1; echo "== $m MiB"; python tools/par_timeline.py gpurun_out/tl$m | head -12; rm -rf gpurun_out/tl$m; done
