@@ -269,7 +269,12 @@ def main_single(a):
                                       "sample_blocks": nb32, "throughput": "see the configs[4]-shape entry (same kernel, data-independent)"}
         del o32, l32, s32
         sec.append(e64)
-        del r64, dt_, d_out_t, d_out5
+        # -- the reference's own non-FAST window (CWINDOW = 256, deflate.py:58-59) on the same text blocks: the window-independent finder
+        r256 = run_compress(torch, eng, dt_, 256, 10, a.steps, a.warmup, 16, d_out=d_out_t)
+        sec.append(compress_entry("cwindow=256", "CWINDOW=256 + MATCH10 (the reference's non-FAST build, deflate.py:58-59) on the configs[2] blocks: "
+                                  "%d x 64 KiB of Zipf pseudo-English" % a.text_blocks, r256, 256, 10, a.steps, a.warmup,
+                                  "k_compress<8>|blocks=%d|block=65536|data=text" % a.text_blocks))
+        del r64, r256, dt_, d_out_t, d_out5
         torch.cuda.empty_cache()
         # -- configs[3]: inflate
         sec.append(bench_inflate(a, eng, cpu=False))

@@ -4,13 +4,17 @@
 // One wave decoding one stream is a serial chain: ~9 MB/s (k_inflate_dyn), a fifth of what the FPGA does at 100 MHz.  A stream of ONE
 // fixed-Huffman block -- what STARTC writes (deflate.py:429-466: 78 9C, BFINAL = 1, BTYPE = 1) and all the reference's DYNAMIC=False
 // build reads -- can be cut anywhere, because a token is at most 32 bits long (9 + 5 + 5 + 13):
-//   1. k_par_spec    every piece of the stream (1 KiB; less for small streams) is decoded from all 32 bit offsets a token can start at behind its first bit
-//                    (one lane per offset, two pieces per wave): per offset, where the chain leaves the piece (offset into the next
-//                    one, or EOB, or an undecodable symbol) and how many bytes it produces;
+//   1. k_par_head    every piece of the stream (1 KiB; 512 / 256 bytes for smaller streams) is decoded from all 32 bit offsets a token can start
+//                    at behind its first bit -- for its first 256 bits only: chains from different offsets fall into step at the first token
+//                    boundary they share, so the lanes that stand at the same bit afterwards are ONE chain (listed once);
+//      k_par_tail    one lane per listed chain decodes the rest of its piece: where the chain leaves the piece (offset into the next one,
+//                    or EOB, or an undecodable symbol), how many bytes it produces, and the same at three sub-boundaries of the piece;
+//      k_par_resolve every (piece, offset) takes its chain's results -- a 32-entry map per piece (k_par_spec: the 32-fold decode of whole
+//                    pieces these three replace; kept for A/B with -DHDLZ_PAR_SPEC32);
 //   2. k_par_scan_*  the 32-entry maps are walked from the stream's first token on (per group of 64 pieces for all 32 offsets, one
 //                    wave over the groups, the pieces of every group again): the true entry offset and the output position of every
 //                    piece, the total length;
-//   3. k_par_tokens  one LANE per piece decodes it for real, with the reference's checks in the reference's order, into a token list;
+//   3. k_par_tokens  one LANE per SUB-piece (a quarter of a piece; entry offsets from the sub-boundary maps) decodes it for real, with the reference's checks in the reference's order, into a token list;
 //      k_par_emit    one wave per piece writes the bytes, 64 tokens at a time -- except that the history before the piece's own output
 //                    is not there yet.  A byte copied from there becomes a MARKER: src[p] = the absolute position it comes from
 //                    (markers are copied like bytes);
@@ -201,20 +205,23 @@ __device__ __forceinline__ void spec_token(uint32_t x, const uint32_t* lit, cons
     run = adv;
 }
 
-__global__ __launch_bounds__(64) void k_par_head(ParArgs a, Chains ch) {
-    __shared__ uint32_t lit[512], dst[32], win[2][HEAD_BITS / 32 + 8], first[2][32], slotof[2][32];
-    const uint32_t lane = threadIdx.x, half = lane >> 5, e = lane & 31u;
-    fill_tables(lit, dst, lane, 64u);
-    first[half][e] = 0xFFFFFFFFu;
-    const uint32_t c = blockIdx.x * 2u + half;
+constexpr uint32_t HEAD_WAVES = 8;            // waves per workgroup of k_par_head: ONE atomic on the chain counter per workgroup (one per
+                                              // wave -- 9.4 k same-address atomics at 16 MiB -- serialised in L2: 121 us for 25 us of work)
+__global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a, Chains ch) {
+    __shared__ uint32_t lit[512], dst[32], win[HEAD_WAVES][2][HEAD_BITS / 32 + 8], first[HEAD_WAVES][2][32], slotof[HEAD_WAVES][2][32];
+    __shared__ uint32_t wcount[HEAD_WAVES], wbase[HEAD_WAVES];
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u, half = lane >> 5, e = lane & 31u;
+    fill_tables(lit, dst, tid, 64u * HEAD_WAVES);
+    first[wv][half][e] = 0xFFFFFFFFu;
+    const uint32_t c = (blockIdx.x * HEAD_WAVES + wv) * 2u + half;
     const bool have = c < a.nchunks;
     const uint32_t b_c = FIRST_BIT + c * a.chbits, hb = b_c + HEAD_BITS;
-    if (have) stage_window(win[half], a.z, a.zn, b_c, HEAD_BITS, e, 32u);
+    if (have) stage_window(win[wv][half], a.z, a.zn, b_c, HEAD_BITS, e, 32u);
     __syncthreads();
     uint32_t pos = b_c + e, nbytes = 0, exitc = 0, used;
     bool run = have;
     const uint32_t bit0 = 8u * ((b_c >> 3) & ~3u);
-    const uint32_t* w_ = win[half];
+    const uint32_t* w_ = win[wv][half];
     while (__ballot(run && pos < hb) != 0ull) {
         if (run && pos < hb) {
             const uint32_t rel = pos - bit0;
@@ -222,25 +229,29 @@ __global__ __launch_bounds__(64) void k_par_head(ParArgs a, Chains ch) {
         }
     }
     const uint32_t key = (pos - hb) & 31u;                 // (a token is at most 32 bits long)
-    if (run) atomicMin(&first[half][key], e);
+    if (run) atomicMin(&first[wv][half][key], e);
     __syncthreads();
-    const bool leader = run && first[half][key] == e;
+    const bool leader = run && first[wv][half][key] == e;
     const uint64_t lm = __ballot(leader);
-    uint32_t base = 0;
-    if (lm != 0ull) {
-        if (lane == 0u) base = atomicAdd(&a.ctl[C_NCHAIN], (uint32_t)__popcll(lm));
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (lane == 0u) wcount[wv] = (uint32_t)__popcll(lm);
+    __syncthreads();
+    if (tid == 0u) {
+        uint32_t tot = 0;
+        for (uint32_t k = 0; k < HEAD_WAVES; k++) { wbase[k] = tot; tot += wcount[k]; }
+        const uint32_t base = tot ? atomicAdd(&a.ctl[C_NCHAIN], tot) : 0u;
+        for (uint32_t k = 0; k < HEAD_WAVES; k++) wbase[k] += base;
     }
+    __syncthreads();
     if (leader) {
-        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-        slotof[half][key] = slot;
+        const uint32_t slot = wbase[wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+        slotof[wv][half][key] = slot;
         ch.cpos[slot] = pos;
     }
     __syncthreads();
     if (have) {
         const uint32_t t = c * 32u + e;
         a.nb32[t] = nbytes;                                // the bytes of the head; k_par_resolve adds the chain's
-        if (run) ch.rep[t] = slotof[half][key];
+        if (run) ch.rep[t] = slotof[wv][half][key];
         else {
             ch.rep[t] = NONE;
             a.exit8[t] = (uint8_t)exitc;
@@ -334,14 +345,15 @@ __global__ __launch_bounds__(64) void k_par_scan_groups(ParArgs a) {
         a.gnb32[g * 32u + lane] = acc;                     // (a group makes < 64 * 175 KB)
     }
 }
-__global__ __launch_bounds__(64) void k_par_scan_top(ParArgs a) {
+__global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a) {
     __shared__ GroupLds L;                                 // (the maps of 64 GROUPS at a time, staged like a group's pieces)
     __shared__ __attribute__((aligned(16))) uint8_t stp[GROUP * 32];
     __shared__ uint8_t ent[GROUP];
     __shared__ uint32_t op[GROUP];
     __shared__ uint32_t sh_stop, sh_e, sh_bad, sh_nused, sh_cnt;
     __shared__ uint64_t sh_acc;
-    const uint32_t lane = threadIdx.x;
+    __shared__ uint8_t pathb[8][32][8], segmap[8][32], segstop[8][32], segent[8];
+    const uint32_t lane = threadIdx.x;                     // (256 threads: staging, and 8 segments x 32 entry offsets for the walk)
     // the stream must be one fixed block (or be read as one: the DYNAMIC=False / ONEBLOCK builds)
     const uint32_t hdr = a.zn >= 5u ? (uint32_t)a.z[2] : 0u;
     const bool fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) || ((hdr >> 1) & 3u) == 1u;
@@ -352,26 +364,50 @@ __global__ __launch_bounds__(64) void k_par_scan_top(ParArgs a) {
     __syncthreads();
     for (uint32_t base = 0; base < ngroups && sh_stop == 0u; base += GROUP) {
         const uint32_t cnt = min(GROUP, ngroups - base);
-        for (uint32_t k = lane; k < cnt * 8u; k += 64u) {                  // (dwords: byte loads made the staging the longest part of this kernel)
+        for (uint32_t k = lane; k < cnt * 8u; k += 256u) {                 // (dwords: byte loads made the staging the longest part of this kernel)
             reinterpret_cast<uint32_t*>(L.ex)[k] = reinterpret_cast<const uint32_t*>(a.gexit8 + (size_t)base * 32u)[k];
             reinterpret_cast<uint32_t*>(stp)[k] = reinterpret_cast<const uint32_t*>(a.gstop8 + (size_t)base * 32u)[k];
         }
-        for (uint32_t k = lane; k < cnt * 32u; k += 64u) L.nb[k] = a.gnb32[(size_t)base * 32u + k];
+        for (uint32_t k = lane; k < cnt * 32u; k += 256u) L.nb[k] = a.gnb32[(size_t)base * 32u + k];
+        if (lane < 8u) segent[lane] = 0;
         __syncthreads();
         // the chain through the groups is serial, so ONLY the offset look-up is on it (one dependent LDS read per group; with the
         // byte counts on the same chain it was 250 ns per group: 74 of 1107 us at 16 MiB, 587 us at 256 MiB); the output positions
         // are a prefix sum of the counts the chain picked -- one group per lane, a wave scan
-        if (lane == 0u) {
-            uint32_t e = sh_e, j = 0;
-            for (; j < cnt; j++) {
-                const uint32_t x = L.ex[j * 32u + e];
-                ent[j] = (uint8_t)e;
-                if (x & (X_EOB | X_BAD)) { sh_stop = 1u; sh_bad = x & X_BAD; sh_nused = (base + j) * GROUP + stp[j * 32u + e] + 1u; j++; break; }
+        // ... and it is walked in 8 segments of 8 groups from ALL 32 entry offsets at once (the maps compose), then one thread
+        // goes through the 8 segment maps: 16 dependent steps per batch instead of 64 (round 3: 43 -> 20 us at 16 MiB)
+        {
+            const uint32_t sg = lane >> 5, e0 = lane & 31u, g0 = sg * 8u;
+            uint32_t e = e0, stopk = 0xFFu;
+            for (uint32_t k = 0; k < 8u && g0 + k < cnt; k++) {
+                const uint32_t x = L.ex[(g0 + k) * 32u + e];
+                pathb[sg][e0][k] = (uint8_t)e;
+                if (x & (X_EOB | X_BAD)) { stopk = k; e = x; break; }
                 e = x;
             }
-            sh_e = e; sh_cnt = j;                           // groups walked in this batch (the one the chain ends in included)
+            segmap[sg][e0] = (uint8_t)e; segstop[sg][e0] = (uint8_t)stopk;
         }
         __syncthreads();
+        if (lane == 0u) {
+            uint32_t e = sh_e, walked = 0;
+            for (uint32_t sg = 0; sg < 8u && sg * 8u < cnt; sg++) {
+                segent[sg] = (uint8_t)e;
+                const uint32_t m = segmap[sg][e], sk = segstop[sg][e];
+                if (sk != 0xFFu) {
+                    const uint32_t j = sg * 8u + sk;
+                    sh_stop = 1u; sh_bad = m & X_BAD; sh_nused = (base + j) * GROUP + stp[j * 32u + pathb[sg][e][sk]] + 1u;
+                    walked = j + 1u;
+                    break;
+                }
+                e = m;
+                walked = min(cnt, sg * 8u + 8u);
+            }
+            sh_e = e; sh_cnt = walked;                      // groups walked in this batch (the one the chain ends in included)
+        }
+        __syncthreads();
+        if (lane < 64u) ent[lane] = pathb[lane >> 3][segent[lane >> 3]][lane & 7u];
+        __syncthreads();
+        if (lane < 64u)
         {
             const uint32_t walked = sh_cnt;
             const uint64_t mine = lane < walked ? (uint64_t)L.nb[lane * 32u + ent[lane]] : 0ull;
@@ -384,7 +420,6 @@ __global__ __launch_bounds__(64) void k_par_scan_top(ParArgs a) {
             const uint64_t before = sh_acc + incl - mine;
             if (lane < walked) op[lane] = (uint32_t)before;
             const bool over = lane < walked && before + mine > 0xFFFFFFFFull;
-            __syncthreads();
             if (__ballot(over) != 0ull && lane == 0u) { sh_stop = 1u; sh_bad = 1u; }
             if (lane == 63u) sh_acc += incl;
         }
@@ -665,6 +700,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     uint64_t srcn = (uint64_t)zn * 172u + 258u;            // a token of 13 bits makes at most 258 bytes
     if (srcn > cap64) srcn = cap64;
     if (srcn > (1ull << 30)) return hipSuccess;            // (8 GiB of scratch: leave it to the serial decoder)
+    // (with the de-duplicated speculation: 1024-bit pieces 1.10 ms at 16 MiB -- markers, scans --, 4096 bits with 8 sub-pieces 0.67, these 0.64)
     const uint32_t chbits = zn < (3u << 20) ? CH_BITS_MAX / 4u : zn < (24u << 20) ? CH_BITS_MAX / 2u : CH_BITS_MAX;
     const uint32_t nchunks = (8u * zn - FIRST_BIT + chbits - 1u) / chbits;
     // streams that do not fill the GPU with one lane per piece (the port's: LMAX = 24 bits = 16 MiB) decode sub-pieces
@@ -705,12 +741,12 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
 #else
         Chains ch{reinterpret_cast<uint32_t*>(ws + o_rp), reinterpret_cast<uint32_t*>(ws + o_cp), ws + o_cx, reinterpret_cast<uint32_t*>(ws + o_cn),
                   ws + o_cmx, reinterpret_cast<uint32_t*>(ws + o_cmn)};
-        hipLaunchKernelGGL(k_par_head, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p, ch);
+        hipLaunchKernelGGL(k_par_head, dim3((nchunks + 2u * HEAD_WAVES - 1u) / (2u * HEAD_WAVES)), dim3(64 * HEAD_WAVES), 0, stream, p, ch);
         hipLaunchKernelGGL(k_par_tail, dim3((nchunks * 32u + 63u) / 64u), dim3(64), 0, stream, p, ch);
         hipLaunchKernelGGL(k_par_resolve, dim3((nchunks * 32u + 255u) / 256u), dim3(256), 0, stream, p, ch);
 #endif
         hipLaunchKernelGGL(k_par_scan_groups, dim3(ngroups), dim3(64), 0, stream, p);
-        hipLaunchKernelGGL(k_par_scan_top, dim3(1), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_par_scan_top, dim3(1), dim3(256), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_pieces, dim3(ngroups), dim3(64), 0, stream, p, pf.entry8, pf.opos);
         hipLaunchKernelGGL(k_par_tokens, dim3((pf.nchunks + 63u) / 64u), dim3(64), 0, stream, pf);
         ParArgs pe = p;                                                 // the emit: pieces, reading the sub-pieces' token lists
