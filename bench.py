@@ -234,6 +234,30 @@ def main_single(a):
         "compression_ratio_out_over_in": round(r["out_bytes"] / r["in_bytes"], 4),
         "roofline": rl,
     }
+    # SURVEY 8(f) rank 2 beside the pitched-row figure: the same job delivered as ONE contiguous archive + offset index
+    # (exclusive scan of the lengths + hdlz_compact_batch behind the compress launch; a fused compress -> archive would save the
+    # compaction's read + write of N_out, at most the compact_ms below)
+    if a.archive:
+        offs = torch.empty(B, dtype=torch.int64, device=dev)
+        arch = torch.empty(r["out_bytes"], dtype=torch.uint8, device=dev)
+
+        def to_archive():
+            l64 = r["ol"].to(torch.int64)
+            torch.cumsum(l64, 0, out=offs)
+            offs.sub_(l64)
+            eng.compact(r["d_out"], r["ol"], offsets=offs, archive=arch)
+
+        def both():
+            eng.compress_batch(d_in, cwindow=a.cwindow, maxmatch=a.maxmatch, out=r["d_out"], out_pitch=r["d_out"].shape[1])
+            to_archive()
+
+        to_archive()
+        c_ms = kernel_ms(torch, to_archive, 10)
+        b_ms = kernel_ms(torch, both, 10)
+        res["archive"] = {"scan_plus_compact_ms": round(median(c_ms), 4), "compress_scan_compact_ms": round(median(b_ms), 4),
+                          "input_MBps": round(r["in_bytes"] / median(b_ms) / 1e3, 1), "archive_bytes": r["out_bytes"],
+                          "note": "the job as one contiguous archive + int64 offset index: compress into pitched rows, exclusive scan of "
+                                  "the lengths, hdlz_compact_batch (HIP events around the three steps)"}
     if a.end_to_end:
         res["end_to_end"] = end_to_end(torch, eng, d_in, r, a.cwindow, a.maxmatch)
     if a.cpu_seconds > 0:
@@ -591,6 +615,8 @@ def main():
                     help="inflate: lane-per-stream kernel variant (token = k_inflate_tok, byte = k_inflate)")
     ap.add_argument("--mode", default="compress", choices=["compress", "inflate"],
                     help="compress = BASELINE metric (default); inflate = only the configs[3] side metric (1 GPU)")
+    ap.add_argument("--no-archive", dest="archive", action="store_false",
+                    help="N=1: skip the archive figure (compress + scan + hdlz_compact_batch) of the headline job")
     ap.add_argument("--no-end-to-end", dest="end_to_end", action="store_false",
                     help="N=1: skip the PCIe-inclusive measurement of the headline job (SURVEY 8(d) Timing)")
     ap.add_argument("--no-t1", dest="t1", action="store_false",
