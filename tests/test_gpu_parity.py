@@ -149,6 +149,31 @@ def test_compress_wide_windows_large_blocks_every_block(engine, oracle):
         assert zlib.decompress(ho[0, :hl[0]].tobytes()) == h[0].tobytes()
 
 
+def test_compress_hashed_finder_adversarial_inputs(engine, oracle):
+    """the window-independent match finder (CWINDOW > 64, hdlz_compress_common.h: match_search_hash) on the inputs that stress its
+    tables: all positions in ONE hash class (zeros, short periods: 64 lanes on one table address and one leader slot), periods
+    around the round length 64 and the window, two-symbol noise (eight keys), random bytes (no class twice), keys that differ in
+    one byte only; windows that are not multiples of 32 (the per-position window compare) and the full 256; sizes around tile
+    multiples -- every block against the oracle, as one ragged batch per window"""
+    import torch
+    r = random.Random(41)
+    pats = []
+    for n in (2049, 4096 + 17, 6000, 65536):
+        pats += [bytes(n), bytes([65 + (i % 2) for i in range(n)]), bytes([65 + (i % 7) for i in range(n)]),
+                 bytes([(i % 63) for i in range(n)]), bytes([(i % 64) for i in range(n)]), bytes([(i % 65) for i in range(n)]),
+                 bytes([(i % 255) for i in range(n)]), bytes([(i % 256) for i in range(n)]), bytes([((i % 257) * 7) & 255 for i in range(n)]),
+                 bytes(r.choice(b"01") for _ in range(n)), bytes(r.randrange(256) for _ in range(n)),
+                 bytes((97 if (i // 3) % 2 else 98) if i % 3 else r.randrange(4) for i in range(n)),
+                 (b"abcdefghij" * 30 + bytes(r.randrange(256) for _ in range(40))) * (n // 340 + 1)]
+    pats = [p[:n] for p in pats for n in (len(p),)]
+    for cw in (65, 100, 128, 200, 255, 256):
+        for mm in ((10,) if cw != 256 else (10, 5)):
+            got, st = _ragged(torch, engine, pats, cwindow=cw, maxmatch=mm)
+            for k, (p_, g_) in enumerate(zip(pats, got)):
+                rc, ref = oracle.compress(p_, cw, mm)
+                assert st[k] == rc == 0 and g_ == ref, (cw, mm, k, len(p_))
+
+
 def test_compress_stream_multiwave_vs_oracle(engine, oracle):
     """hdlz_compress_stream: ONE stream spread over the GPU (three passes) must give the oracle's bytes --
     sizes around tile multiples (2048), match-dense alphabets (matches straddle every tile boundary, all entry
