@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include "hdlz_device.h"
 
 namespace {
@@ -38,9 +39,11 @@ namespace hdlz {
 hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t stream) {
     static hipMemPool_t pools[64] = {nullptr};
     static bool tried[64] = {false};
+    static std::mutex mu;                                // (callers may drive several streams / devices from several threads)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
-    if (dev >= 0 && dev < 64 && !tried[dev]) {          // (a benign race at worst creates a pool twice)
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && !tried[dev]) {
         tried[dev] = true;
         hipMemPoolProps props;
         memset(&props, 0, sizeof(props));

@@ -23,7 +23,8 @@
 // Anything else -- another block type, more than one block, a failed check (NO EOF, bad symbol, bad distance, capacity) -- sets
 // a fallback flag on the device and k_inflate_dyn redoes the stream from its first byte (it is launched behind the chain and
 // returns at once otherwise): status words and bytes are those of the serial decoder by construction, the parallel path
-// only ever reports HDLZ_OK.  Scratch (stream-ordered): 160 bytes per piece and 8 bytes per possible output byte.
+// only ever reports HDLZ_OK.  Scratch (stream-ordered, from the library's own pool): ~1.6 KB per piece (the maps of the 32 offsets, of the sub-boundaries and of the
+// listed chains, the token lists) and 8 bytes per possible output byte (markers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
@@ -76,6 +77,7 @@ struct ParArgs {
     uint8_t* mexit8;            // [nchunks][SUB-1][32]  offset behind sub-boundary s for entry offset e (X_EOB: the chain ended in front of it)
     uint32_t* mnb32;            // [nchunks][SUB-1][32]  bytes of the tokens that start in front of that boundary
     uint32_t cnu;               // the control word that holds the number of pieces in use at THIS granularity (C_NUSED / C_FNUSED)
+    uint32_t* mext;             // [nchunks]  bytes from a piece's first output byte to behind its LAST marker (0: it has none)
 };
 
 __device__ __forceinline__ void fill_tables(uint32_t* lit, uint32_t* dst, uint32_t tid, uint32_t nthreads) {
@@ -561,7 +563,8 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
     const uint32_t cstart = a.opos[c];
     uint8_t* out = a.out;
     uint32_t* src = a.srcA;
-    uint32_t Pb = cstart, nmark = 0;
+    uint32_t* src2 = a.srcB;
+    uint32_t Pb = cstart, nmark = 0, mlast = 0;
     for (uint32_t sbi = 0; sbi < nsub; sbi++) {
         const uint32_t f = c * nsub + sbi;
         if (f >= fnused) break;
@@ -641,27 +644,39 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
                     }
                 }
                 if (in) {
-                    out[pabs] = (uint8_t)v; src[pabs] = m;
+                    out[pabs] = (uint8_t)v; src[pabs] = m; src2[pabs] = NONE;      // (the second buffer of the marker passes: see k_par_jump)
                     nmark += m != NONE ? 1u : 0u;
+                    mlast = m != NONE ? pabs + 1u : mlast;
                 }
             }
             Pb += total;
             base += cnt;
         }
     }
+    // how far into the piece its markers reach: the marker passes look at these bytes only
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) mlast = max(mlast, (uint32_t)__shfl_xor((int)mlast, ofs, 64));
+    if (lane == 0u) a.mext[c] = mlast > cstart ? mlast - cstart : 0u;
     if (nmark) atomicAdd(&a.ctl[C_MARK], nmark);
 }
 
-// ---- 4. one pass of pointer jumping over the markers
-constexpr uint32_t HOPS = 32;                 // (8 until round 3: the passes that find nothing left still cost a launch, 4.5 us each)
-__global__ __launch_bounds__(256) void k_par_jump(ParArgs a, uint32_t pass) {
+// ---- 4. one pass of pointer jumping over the markers.  One workgroup per piece, over the bytes up to the piece's last marker only:
+// a stream with short distances (what STARTC writes: CWINDOW bytes) has its markers in the first CWINDOW bytes of every piece, and a
+// sweep over ALL output positions per pass read and wrote 4 bytes per output byte (64 + 64 MB at 16 MiB: 64 us).  Positions outside
+// the extents are no markers in EITHER buffer (the emit writes NONE to both), so a chain that leads there ends there.
+constexpr uint32_t HOPS = 256;                // (8 in round 2: a pass that finds nothing left still costs a launch, 4.5 us -- three passes cover 65536 pieces)
+__global__ __launch_bounds__(64) void k_par_jump(ParArgs a, uint32_t pass) {
     if (a.ctl[C_FALLBACK] != 0u) return;
     if (a.ctl[pass == 0u ? (uint32_t)C_MARK : C_PASS0 + pass - 1u] == 0u) return;            // nothing left
-    const uint32_t n = a.ctl[C_TOTAL];
+    const uint32_t c = blockIdx.x;
+    if (c >= a.ctl[C_NUSED]) return;
+    const uint32_t ext = a.mext[c];
+    if (ext == 0u) return;
+    const uint32_t p0 = a.opos[c];
     const uint32_t* sin = (pass & 1u) ? a.srcB : a.srcA;
     uint32_t* sout = (pass & 1u) ? a.srcA : a.srcB;
     uint32_t left = 0;
-    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    for (uint32_t p = p0 + threadIdx.x; p < p0 + ext; p += 64u) {
         uint32_t m = sin[p];
         uint32_t r = NONE;
         if (m != NONE) {
@@ -677,7 +692,9 @@ __global__ __launch_bounds__(256) void k_par_jump(ParArgs a, uint32_t pass) {
         }
         sout[p] = r;
     }
-    if (left) atomicAdd(&a.ctl[C_PASS0 + pass], left);
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) left += (uint32_t)__shfl_xor((int)left, ofs, 64);
+    if (left && threadIdx.x == 0u) atomicAdd(&a.ctl[C_PASS0 + pass], left);
 }
 
 // ---- 5. the verdict: HDLZ_OK and the length, or the serial decoder's turn
@@ -714,7 +731,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                  o_mx = take((size_t)nchunks * (sub - 1u) * 32u), o_mn = take((size_t)nchunks * (sub - 1u) * 128u),
                  o_fe = take((size_t)nchunks * sub), o_fo = take((size_t)nchunks * sub * 4u),
                  o_tk = take((size_t)nchunks * sub * tmax_of(chbits / sub) * 4u), o_nt = take((size_t)nchunks * sub * 4u), o_sa = take((size_t)srcn * 4u),
-                 o_sb = take((size_t)srcn * 4u),
+                 o_sb = take((size_t)srcn * 4u), o_me = take((size_t)nchunks * 4u),
                  o_rp = take((size_t)nchunks * 128u), o_cp = take((size_t)nchunks * 128u), o_cx = take((size_t)nchunks * 32u),
                  o_cn = take((size_t)nchunks * 128u), o_cmx = take((size_t)nchunks * 32u * (sub - 1u)), o_cmn = take((size_t)nchunks * 128u * (sub - 1u));
     uint8_t* ws = nullptr;
@@ -727,7 +744,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                   reinterpret_cast<uint32_t*>(ws + o_op), ws + o_gx, ws + o_gs, reinterpret_cast<uint32_t*>(ws + o_gn), ws + o_ge,
                   reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_tk), reinterpret_cast<uint32_t*>(ws + o_nt),
                   reinterpret_cast<uint32_t*>(ws + o_sa), reinterpret_cast<uint32_t*>(ws + o_sb), sub, ws + o_mx,
-                  reinterpret_cast<uint32_t*>(ws + o_mn), (uint32_t)C_NUSED};
+                  reinterpret_cast<uint32_t*>(ws + o_mn), (uint32_t)C_NUSED, reinterpret_cast<uint32_t*>(ws + o_me)};
         // the same arguments at sub-piece granularity: what the real decode and the emit work on
         ParArgs pf = p;
         pf.nchunks = nchunks * sub; pf.chbits = chbits / sub; pf.cnu = C_FNUSED;
@@ -752,8 +769,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         ParArgs pe = p;                                                 // the emit: pieces, reading the sub-pieces' token lists
         pe.tokens = pf.tokens; pe.ntok = pf.ntok;
         hipLaunchKernelGGL(k_par_emit, dim3(nchunks), dim3(64), 0, stream, pe);
-        const uint32_t jgrid = (uint32_t)((srcn + 255u) / 256u < 8192u ? (srcn + 255u) / 256u : 8192u);
-        for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(jgrid), dim3(256), 0, stream, p, j);
+        for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(nchunks), dim3(64), 0, stream, p, j);
         hipLaunchKernelGGL(k_par_finish, dim3(1), dim3(64), 0, stream, p, passes);
         e = hipGetLastError();
         // the serial decoder returns at once when ctl[C_OK] >= 1
