@@ -193,11 +193,14 @@ __device__ __forceinline__ void spec_token(uint32_t x, const uint32_t* lit, cons
     const uint32_t nb = e0 & 15u, type = (e0 >> 13) & 3u, leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
     const uint32_t y = x >> nb;
     const uint32_t tl = lbase + __builtin_amdgcn_ubfe(y, 0u, leb);
-    const uint32_t de = dst[__builtin_amdgcn_ubfe(y, leb, 5u)];
+    // the distance code's extra bits in closed form (RFC1951: codes 0..3 none, then (code >> 1) - 1; 30 and 31 do not exist) instead of
+    // the dst[] look-up: a second DEPENDENT LDS round trip on every token of a chain that is one lane's serial latency
+    const uint32_t dc = __builtin_bitreverse32(__builtin_amdgcn_ubfe(y, leb, 5u)) >> 27;
+    const uint32_t deb = max(dc >> 1, 1u) - 1u;
     const bool islit = type == (uint32_t)T_LIT;
-    const bool bad = (nb == 0u) | (type == (uint32_t)T_BAD) | ((type == (uint32_t)T_LEN) & (de == 0xFFFFFFFFu));
+    const bool bad = (nb == 0u) | (type == (uint32_t)T_BAD) | ((type == (uint32_t)T_LEN) & (dc >= 30u));
     const bool eob = type == (uint32_t)T_EOB;
-    const uint32_t used = islit ? nb : nb + leb + 5u + ((de >> 16) & 15u);
+    const uint32_t used = islit ? nb : nb + leb + 5u + deb;
     const uint32_t made = islit ? 1u : tl;
     const bool adv = !(bad | eob);
     exitc = bad ? X_BAD : eob ? X_EOB : exitc;
@@ -499,37 +502,34 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
     uint64_t bb = have ? (((uint64_t)tok::load32(a.z, ip + 4u, a.zn) << 32) | tok::load32(a.z, ip, a.zn)) >> (pos - 8u * ip) : 0ull;
     ip += 8u;
     uint32_t nxt = have ? tok::load32(a.z, ip, a.zn) : 0u;
+    // One token per iteration, branch-free: the 64 pieces of a wave stand at different kinds of tokens, so a ladder of branches runs
+    // every path anyway.  The reference's checks (deflate.py:1409-1445, :1519-1591, :1600) are all evaluated; WHICH of them failed does
+    // not matter here -- any failure hands the stream to the serial decoder, which reports the reference's status in the reference's
+    // order.  A token is at most 32 bits long: the low dword of the bit buffer is all a step looks at.
     bool run = have, bad = false;
     while (__ballot(run) != 0ull) {
         if (run) {
-            if (bc <= 32u) { bb |= (uint64_t)nxt << bc; bc += 32u; ip += 4u; nxt = tok::load32(a.z, ip, a.zn); }    // (a token: <= 32 bits)
-            const uint32_t e0 = lit[(uint32_t)bb & 511u];
-            const uint32_t nb = e0 & 15u, code = (e0 >> 4) & 0x1FFu;
-            uint32_t used = nb;
-            if (nb < 1u) { bad = true; run = false; }                                            // zero leaf: BAD_SYMBOL
-            else if ((int32_t)((pos + nb) >> 3) > isize - 3) { bad = true; run = false; }        // NO EOF, deflate.py:1535-1539
-            else if (code == 256u) run = false;                                                  // D6: the stream ends here
-            else if (code < 256u) {
-                if (P >= a.cap) { bad = true; run = false; }
-                else { tk[n++] = TOK_LIT | code; P++; }
-            } else if (code - 257u >= 29u) { bad = true; run = false; }                          // BAD_SYMBOL
-            else {
-                const uint32_t leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
-                uint64_t y = bb >> nb;
-                const uint32_t tl = lbase + ((uint32_t)y & ((1u << leb) - 1u));
-                y >>= leb;
-                const uint32_t de = dst[(uint32_t)y & 31u];
-                const uint32_t deb = (de >> 16) & 15u;
-                const uint32_t D = (de & 0xFFFFu) + ((uint32_t)(y >> 5) & ((1u << deb) - 1u));
-                used = nb + leb + 5u + deb;
-                if (de == 0xFFFFFFFFu) { bad = true; run = false; }                              // BAD_DISTANCE (codes 30, 31)
-                else if (D > P || D > obsize) { bad = true; run = false; }                       // D8
-                else if ((int32_t)((pos + used) >> 3) >= isize - 2) { bad = true; run = false; } // COPY hold, deflate.py:1600
-                else if ((uint64_t)P + tl > a.cap) { bad = true; run = false; }
-                else { tk[n++] = tl | (D << 9); P += tl; }
-            }
-            pos += used; bb >>= used; bc -= used;
-            if (pos >= end) run = false;
+            if (bc <= 32u) { bb |= (uint64_t)nxt << bc; bc += 32u; ip += 4u; nxt = tok::load32(a.z, ip, a.zn); }
+            const uint32_t x = (uint32_t)bb;
+            const uint32_t e0 = lit[x & 511u];
+            const uint32_t nb = e0 & 15u, code = (e0 >> 4) & 0x1FFu, leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
+            const uint32_t y = x >> nb;
+            const uint32_t tl = lbase + __builtin_amdgcn_ubfe(y, 0u, leb);
+            // (the distance table in closed form, RFC1951 3.2.5: no second dependent LDS look-up on the lane's serial chain)
+            const uint32_t dc = __builtin_bitreverse32(__builtin_amdgcn_ubfe(y, leb, 5u)) >> 27;
+            const uint32_t deb = max(dc >> 1, 1u) - 1u;
+            const uint32_t D = (dc < 4u ? dc + 1u : 1u + ((2u + (dc & 1u)) << deb)) + __builtin_amdgcn_ubfe(y, leb + 5u, deb);
+            const bool islit = code < 256u, iseob = code == 256u, islen = code > 256u;
+            const uint32_t used = islen ? nb + leb + 5u + deb : nb;
+            const uint32_t made = islit ? 1u : tl;
+            bool f = (nb < 1u) | ((int32_t)((pos + nb) >> 3) > isize - 3);                        // zero leaf; NO EOF (deflate.py:1535-1539)
+            f |= !iseob & ((uint64_t)P + made > a.cap);                                           // capacity
+            f |= islen & ((code - 257u >= 29u) | (dc >= 30u) | (D > P) | (D > obsize) |           // BAD_SYMBOL, BAD_DISTANCE, D8
+                          ((int32_t)((pos + used) >> 3) >= isize - 2));                           // COPY hold (deflate.py:1600)
+            const bool go = !(f | iseob);                                                         // (D6: EOB ends the stream)
+            if (go) { tk[n] = islit ? (TOK_LIT | code) : (tl | (D << 9)); n++; P += made; pos += used; bb >>= used; bc -= used; }
+            bad |= f;
+            run = go && pos < end;
         }
     }
     if (have) a.ntok[c] = n;
@@ -609,7 +609,8 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
             // ---- ONE ascending sweep over the slices: a copied byte is a POINTER to its source `distance` back.  Sources in earlier
             // slices (or in front of the batch) are final by now and are read as values; only chains INSIDE the slice -- distances
             // below 64 -- are followed (ptr <- ptr[ptr], log2 of the longest such chain rounds; an overlapping copy is a chain
-            // through its own bytes).  (All slices per round, every round: 107 of the emit's 247 us.)
+            // through its own bytes).  (All slices per round, every round: 107 of the emit's 247 us.  The tokens of all slices looked up
+            // in front of the sweep -- 17 register slots, independent reads -- made it slower: 212 -> 263 us.)
             for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
                 const uint32_t q = q0 + lane;
                 const bool in = q < total;
