@@ -38,7 +38,7 @@ using tok::T_EOB;
 using tok::T_LIT;
 using tok::T_LEN;
 
-constexpr uint32_t CH_BITS_MAX = 8192;        // a piece: 1 KiB of the stream -- 512 bytes for streams below 24 MiB, 256 below 3 MiB: a piece is ONE
+constexpr uint32_t CH_BITS_MAX = 8192;        // a piece: 1 KiB of the stream -- 512 bytes for streams below 24 MiB, 256 below 3 MiB, 128 below 1.25 MiB: a piece is ONE
                                               // wave's (lane's) serial chain in k_par_spec and k_par_tokens, and 16 MiB in 1 KiB pieces do not fill the
                                               // GPU twice (16 MiB: 1.37 -> 1.24 ms, 1 MiB: 0.76 -> 0.45 ms with 512-byte pieces)
 constexpr uint32_t WIN_DW = CH_BITS_MAX / 32 + 8; // its staged window: the piece, the 31 + 64 bits a token starting at its end may read
@@ -719,7 +719,8 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     if (srcn > cap64) srcn = cap64;
     if (srcn > (1ull << 30)) return hipSuccess;            // (8 GiB of scratch: leave it to the serial decoder)
     // (with the de-duplicated speculation: 1024-bit pieces 1.10 ms at 16 MiB -- markers, scans --, 4096 bits with 8 sub-pieces 0.67, these 0.64)
-    const uint32_t chbits = zn < (3u << 20) ? CH_BITS_MAX / 4u : zn < (24u << 20) ? CH_BITS_MAX / 2u : CH_BITS_MAX;
+    // measured with the final kernels, 1 / 4 / 16 MiB of output: 1024-bit pieces 0.191 / 0.328 / 1.00 ms, 2048 bits 0.241 / 0.286 / 0.65, 4096 bits 0.317 / 0.361 / 0.571
+    const uint32_t chbits = zn < (5u << 18) ? CH_BITS_MAX / 8u : zn < (3u << 20) ? CH_BITS_MAX / 4u : zn < (24u << 20) ? CH_BITS_MAX / 2u : CH_BITS_MAX;
     const uint32_t nchunks = (8u * zn - FIRST_BIT + chbits - 1u) / chbits;
     // streams that do not fill the GPU with one lane per piece (the port's: LMAX = 24 bits = 16 MiB) decode sub-pieces
     const uint32_t sub = zn < (24u << 20) ? SUB : 1u;
