@@ -544,14 +544,14 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
 // the piece's own output is not there yet: a byte copied from there is a MARKER (src[p] = the absolute position it comes from), and
 // markers travel like bytes.  (Round 2 walked the copies of a batch one after the other, lane-parallel inside a copy: ~500 cycles per
 // copy, 257 of 879 us at 16 MiB, 3.4 of 10.7 ms at 256 MiB.)
-constexpr uint32_t HRING = 2048;
+constexpr uint32_t HRING = 1024;              // (2048 with a pointer array beside it: 14.8 KB of LDS per wave, 11 waves per CU, for a kernel that is one
+                                              //  serial chain of LDS round trips per 64-byte slice)
 constexpr uint32_t SPAN = 768;                // a batch ends with the token that takes its output beyond this many bytes
 constexpr uint32_t HREACH = HRING - 128u;     // distances served from the ring (it is written a 64-byte slice at a time)
-constexpr uint32_t P_RES = 0xFFFFu;           // pa[]: the slot holds its byte / marker
+constexpr uint32_t P_RES = 0xFFu;             // in-slice pointer: the byte / marker is there
 __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
     __shared__ uint8_t hb[HRING];             // ring over the piece's output positions: byte ...
     __shared__ uint32_t hm[HRING];            // ... marker (NONE = the byte is there) ...
-    __shared__ uint16_t pa[HRING];            // ... or, while a batch is being resolved, the ring slot of its source
     __shared__ uint32_t tI[64];               // the batch's token words
     __shared__ uint64_t bmw[17];              // token starts, one bit per byte of the batch
     __shared__ uint32_t bpre[17];             // token starts in front of each 64-byte slice
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
                 bool farin = false;
                 if (in && (tw >> 31) == 0u) {
                     const uint32_t D = tw >> 9, s = pabs - D;                // COPY (deflate.py:1627-1659): out[p] = out[p - D]
-                    if (s >= Pb + q0) p = s & (HRING - 1u);                  // inside this slice: followed below
+                    if (s >= Pb + q0) p = s - (Pb + q0);                     // inside this slice: the LANE that holds it, followed below
                     else if (s < cstart) { v = 0u; m = s; }                  // in front of the piece: a marker
                     else if (pabs - s <= HREACH) { v = hb[s & (HRING - 1u)]; m = hm[s & (HRING - 1u)]; }      // the ring has it (final)
                     else farin = true;                                       // the piece's own output beyond the ring
@@ -635,15 +635,18 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     if (farin) { const uint32_t s = pabs - (tw >> 9); v = out[s]; m = src[s]; }
                 }
-                if (in) { hb[slot] = (uint8_t)v; hm[slot] = m; pa[slot] = (uint16_t)p; }
+                // chains inside the slice: registers and the LDS crossbar (ds_bpermute), no memory -- a lane takes over its source
+                // lane's byte and marker once that lane is resolved, its pointer otherwise
                 while (__ballot(p != P_RES) != 0ull) {
+                    const uint32_t sl = p != P_RES ? p : lane;
+                    const uint32_t pp = (uint32_t)__shfl((int)p, (int)sl, 64), vv = (uint32_t)__shfl((int)v, (int)sl, 64),
+                                   mm = (uint32_t)__shfl((int)m, (int)sl, 64);
                     if (p != P_RES) {
-                        const uint32_t pp = pa[p];
-                        const uint32_t vv = hb[p], mm = hm[p];
-                        if (pp == P_RES) { v = vv; m = mm; p = P_RES; hb[slot] = (uint8_t)v; hm[slot] = m; pa[slot] = (uint16_t)P_RES; }
-                        else { p = pp; pa[slot] = (uint16_t)pp; }
+                        if (pp == P_RES) { v = vv; m = mm; p = P_RES; }
+                        else p = pp;
                     }
                 }
+                if (in) { hb[slot] = (uint8_t)v; hm[slot] = m; }
                 if (in) {
                     out[pabs] = (uint8_t)v; src[pabs] = m; src2[pabs] = NONE;      // (the second buffer of the marker passes: see k_par_jump)
                     nmark += m != NONE ? 1u : 0u;
