@@ -265,6 +265,9 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a, Chains 
     }
 }
 
+// (The lane's bits copied into an LDS row of its own first -- no global load, hence no `s_waitcnt vmcnt` in the loop -- changed nothing
+// here: 138 -> 143 us at 16 MiB.  The ~800 cycles per token of a wave that is alone on its SIMD are the DEPENDENT issue of ~35
+// instructions and two LDS round trips, not memory; k_par_tokens, which also stores, gained 10 % from the same rows and keeps them.)
 __global__ __launch_bounds__(64) void k_par_tail(ParArgs a, Chains ch) {
     __shared__ uint32_t lit[512], dst[32];
     const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(64) void k_par_tail(ParArgs a, Chains ch) {
     const uint32_t c = (pos - FIRST_BIT) / a.chbits;
     const uint32_t b_c = FIRST_BIT + c * a.chbits, end = b_c + a.chbits;
     const uint32_t nsub = a.sub, fb = a.chbits / nsub;
-    // bit reader straight from the stream, as in k_par_tokens (the lanes of a wave stand in different pieces)
+    // bit reader straight from the stream, as in k_par_tokens<false> (the lanes of a wave stand in different pieces)
     uint32_t ip = (pos >> 3) & ~3u, bc = 64u - (pos - 8u * ip);
     uint64_t bb = have ? (((uint64_t)tok::load32(a.z, ip + 4u, a.zn) << 32) | tok::load32(a.z, ip, a.zn)) >> (pos - 8u * ip) : 0ull;
     ip += 8u;
@@ -481,8 +484,11 @@ __global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a, uint8_t* fent
 // 89 % busy -- the token chain of a piece is wave-uniform, 115 scalar instructions per token: 8.2 of 13.7 ms at 256 MiB.)
 constexpr uint32_t TOK_LIT = 0x80000000u;     // a token: TOK_LIT | byte, or length | distance << 9
 __host__ __device__ inline uint32_t tmax_of(uint32_t chbits) { return chbits / 8u + 2u; }      // the shortest token is 8 bits long
+template <bool ROWS>
 __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
     __shared__ uint32_t lit[512], dst[32];
+    extern __shared__ uint32_t rows_[];              // ROWS: the stream bits a lane will read, copied into an LDS row of its own first (dword j of lane l
+                                                     // at j * 64 + l: every lane in its own bank) -- no global load and no `s_waitcnt vmcnt` in the loop
     const uint32_t lane = threadIdx.x;
     if (a.ctl[C_FALLBACK] != 0u) return;
     const uint32_t nused = a.ctl[a.cnu], c0 = blockIdx.x * 64u;
@@ -498,10 +504,20 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
     uint32_t* tk = a.tokens + (size_t)c * tmax_of(a.chbits);
     // bit reader straight from the stream (64 KB of LDS windows per wave left two waves per CU and every LDS / store round trip
     // exposed: 2.9 ms at 256 MiB): bb holds bc valid bits from `pos` on, `nxt` is the dword behind them, requested a refill ahead
-    uint32_t ip = (pos >> 3) & ~3u, bc = 64u - (pos - 8u * ip), n = 0;
-    uint64_t bb = have ? (((uint64_t)tok::load32(a.z, ip + 4u, a.zn) << 32) | tok::load32(a.z, ip, a.zn)) >> (pos - 8u * ip) : 0ull;
-    ip += 8u;
-    uint32_t nxt = have ? tok::load32(a.z, ip, a.zn) : 0u;
+    uint32_t ip = (pos >> 3) & ~3u, bc = 64u - (pos - 8u * ip), n = 0, jn = 2u;
+    if (ROWS) {
+        const uint32_t ndw = have ? ((end + 64u - 8u * ip) >> 5) + 2u : 0u;
+        for (uint32_t j = 0; j < ndw; j++) rows_[j * 64u + lane] = tok::load32(a.z, ip + 4u * j, a.zn);
+        __syncthreads();
+    }
+    uint64_t bb;
+    uint32_t nxt = 0;
+    if (ROWS) bb = have ? (((uint64_t)rows_[64u + lane] << 32) | rows_[lane]) >> (pos - 8u * ip) : 0ull;
+    else {
+        bb = have ? (((uint64_t)tok::load32(a.z, ip + 4u, a.zn) << 32) | tok::load32(a.z, ip, a.zn)) >> (pos - 8u * ip) : 0ull;
+        ip += 8u;
+        nxt = have ? tok::load32(a.z, ip, a.zn) : 0u;
+    }
     // One token per iteration, branch-free: the 64 pieces of a wave stand at different kinds of tokens, so a ladder of branches runs
     // every path anyway.  The reference's checks (deflate.py:1409-1445, :1519-1591, :1600) are all evaluated; WHICH of them failed does
     // not matter here -- any failure hands the stream to the serial decoder, which reports the reference's status in the reference's
@@ -509,7 +525,11 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
     bool run = have, bad = false;
     while (__ballot(run) != 0ull) {
         if (run) {
-            if (bc <= 32u) { bb |= (uint64_t)nxt << bc; bc += 32u; ip += 4u; nxt = tok::load32(a.z, ip, a.zn); }
+            if (bc <= 32u) {
+                if (ROWS) { bb |= (uint64_t)rows_[jn * 64u + lane] << bc; jn++; }
+                else { bb |= (uint64_t)nxt << bc; ip += 4u; nxt = tok::load32(a.z, ip, a.zn); }
+                bc += 32u;
+            }
             const uint32_t x = (uint32_t)bb;
             const uint32_t e0 = lit[x & 511u];
             const uint32_t nb = e0 & 15u, code = (e0 >> 4) & 0x1FFu, leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
@@ -770,7 +790,9 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         hipLaunchKernelGGL(k_par_scan_groups, dim3(ngroups), dim3(64), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_top, dim3(1), dim3(256), 0, stream, p);
         hipLaunchKernelGGL(k_par_scan_pieces, dim3(ngroups), dim3(64), 0, stream, p, pf.entry8, pf.opos);
-        hipLaunchKernelGGL(k_par_tokens, dim3((pf.nchunks + 63u) / 64u), dim3(64), 0, stream, pf);
+        if (pf.chbits <= CH_BITS_MAX / 2u)
+            hipLaunchKernelGGL(k_par_tokens<true>, dim3((pf.nchunks + 63u) / 64u), dim3(64), 256u * (pf.chbits / 32u + 6u), stream, pf);
+        else hipLaunchKernelGGL(k_par_tokens<false>, dim3((pf.nchunks + 63u) / 64u), dim3(64), 0, stream, pf);
         ParArgs pe = p;                                                 // the emit: pieces, reading the sub-pieces' token lists
         pe.tokens = pf.tokens; pe.ntok = pf.ntok;
         hipLaunchKernelGGL(k_par_emit, dim3(nchunks), dim3(64), 0, stream, pe);
