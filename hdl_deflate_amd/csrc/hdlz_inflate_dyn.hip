@@ -159,7 +159,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // second pass of the lane mapping: this kernel takes the flagged streams only when they are few (*few_n of them, counted by
     // k_collect_dyn) -- from `lane_min` (HDLZ_INFLATE_DYN_LANE_MIN; 0 with the explicit lane hint) on one lane per stream is
     // faster (k_inflate_tok<true>)
-    if (!STREAM && few_n && *few_n >= lane_min) return;
+    // (a second pass with nothing left to do -- the stage behind k_inflate_tok<true, CAP_SMALL> -- does not scan the statuses at all)
+    if (!STREAM && few_n && (*few_n >= lane_min || (*few_n == 0u && !(a.flags & DYN_ALL)))) return;
     for (uint64_t sid = blockIdx.x; sid < a.nstreams; sid += gridDim.x) {
         if (!STREAM && !(a.flags & DYN_ALL) && a.status[sid] != HDLZ_E_DYNAMIC_UNSUPPORTED) continue;   // pass 1 finished this stream
         uint64_t off;

@@ -59,22 +59,67 @@ constexpr uint32_t MOVES = HDLZ_TOK_MOVES;    // move iterations (up to 8 bytes 
 #define TOK_MARK(name) do {} while (0)
 #endif
 
-// DYN: per-lane tables, rows of 64 dwords (row j of lane l = dword j * 64 + l: every lane stays in its own bank)
-constexpr uint32_t T_LS8 = 0;                 // 288 bytes: the low 8 bits of the literal/length symbols, sorted by (code length, value)
-constexpr uint32_t T_LBIT = 72;               // 288 bits: their ninth bit
-constexpr uint32_t T_DS8 = 81;                // 32 bytes: the distance symbols, sorted
-constexpr uint32_t T_CNT = 89;                // 2 x 16 u16: symbols per code length (pass 1), then the next free slot per length (pass 2)
-constexpr uint32_t T_CS8 = 105;               // 19 bytes: the symbols of the code-length code, sorted
-constexpr uint32_t T_ROWS = 110;
+// DYN: per-lane tables in LDS, rows of 64 dwords (row j of lane l = dword j * 64 + l: every lane stays in its own bank): only the
+// literal/length symbols, sorted by (code length, value) -- CAP low bytes and CAP ninth bits.  Everything else a lane needs of its
+// codes is in registers: the X words, the sorted distance symbols (30 x 5 bits), and during the build the code-length code and the
+// per-length counters.  CAP = 144 (41 rows = 10.25 KB, 19.3 KB per wave with ring and input slot: EIGHT waves per CU) holds the codes
+// of small blocks; a stream whose block codes more symbols stays flagged and goes through the CAP = 288 build (81 rows, 5 per CU).
+constexpr uint32_t CAP_SMALL = 144, CAP_FULL = 288;
+template <uint32_t CAP> struct Tab {
+    static constexpr uint32_t LS8 = 0;                         // CAP bytes: the low 8 bits of the symbols
+    static constexpr uint32_t LBIT = CAP / 4;                  // CAP bits: their ninth bit
+    static constexpr uint32_t ROWS = CAP / 4 + (CAP + 31) / 32;
+};
 
-template <bool DYN>
-struct __attribute__((aligned(16))) Lds {
-    static constexpr uint32_t WAVES = DYN ? 1u : 4u;
+template <bool DYN, uint32_t CAP> struct Lds;
+template <uint32_t CAP>
+struct __attribute__((aligned(16))) Lds<false, CAP> {
+    static constexpr uint32_t WAVES = 4u;
     uint32_t ring[WAVES][RING_DW * 64];   // per wave: [dword][lane]
     uint32_t inq[WAVES][64 * SLOT_DW];    // per lane: SLOT_DW stream dwords from byte `sbase` on (LDS-DMA)
-    uint32_t lit[DYN ? 1 : 512];
-    uint32_t dst[DYN ? 1 : 32];
-    uint32_t tab[DYN ? T_ROWS * 64 : 1];
+    uint32_t lit[512];
+    uint32_t dst[32];
+};
+template <uint32_t CAP>
+struct __attribute__((aligned(16))) Lds<true, CAP> {
+    static constexpr uint32_t WAVES = 1u;
+    uint32_t ring[WAVES][RING_DW * 64];
+    uint32_t inq[WAVES][64 * SLOT_DW];
+    uint32_t tab[Tab<CAP>::ROWS * 64];
+};
+
+// sixteen counters in registers, addressed per lane: 16-bit fields in four 64-bit words
+struct F16 {
+    uint64_t w[4];
+    __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = w[3] = 0ull; }
+    __device__ __forceinline__ void add(uint32_t i, uint32_t v) {
+        const uint64_t a = (uint64_t)v << ((i & 3u) * 16u);
+        const uint32_t j = i >> 2;
+        w[0] += j == 0u ? a : 0ull; w[1] += j == 1u ? a : 0ull; w[2] += j == 2u ? a : 0ull; w[3] += j == 3u ? a : 0ull;
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t i) const {
+        const uint32_t j = i >> 2;
+        const uint64_t x = j == 0u ? w[0] : j == 1u ? w[1] : j == 2u ? w[2] : w[3];
+        return (uint32_t)(x >> ((i & 3u) * 16u)) & 0xFFFFu;
+    }
+    // (compile-time index)
+    __device__ __forceinline__ uint32_t at(int i) const { return (uint32_t)(w[i >> 2] >> ((i & 3) * 16)) & 0xFFFFu; }
+    __device__ __forceinline__ void put(int i, uint32_t v) { w[i >> 2] |= (uint64_t)v << ((i & 3) * 16); }
+};
+// up to 36 five-bit symbols in three 64-bit words (twelve each), addressed per lane
+struct S5 {
+    uint64_t w[3];
+    __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = 0ull; }
+    __device__ __forceinline__ void put(uint32_t q, uint32_t sym) {
+        const uint32_t j = (q * 43u) >> 9;                      // q / 12 for q < 36
+        const uint64_t a = (uint64_t)sym << ((q - 12u * j) * 5u);
+        w[0] |= j == 0u ? a : 0ull; w[1] |= j == 1u ? a : 0ull; w[2] |= j == 2u ? a : 0ull;
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t q) const {
+        const uint32_t j = (q * 43u) >> 9;
+        const uint64_t x = j == 0u ? w[0] : j == 1u ? w[1] : w[2];
+        return (uint32_t)(x >> ((q - 12u * j) * 5u)) & 31u;
+    }
 };
 
 __device__ __forceinline__ void lds_dma_load16(const uint8_t* gptr, uint32_t lds_base) {
@@ -120,11 +165,11 @@ __device__ __forceinline__ void x_decode(const uint32_t (&X)[NL], uint32_t bits,
     idx = (m & 511u) - ((m >> 16) >> (15u - len));
 }
 
-template <bool DYN>
+template <bool DYN, uint32_t CAP>
 __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, const uint32_t* __restrict__ list,
                                                                 const uint32_t* __restrict__ list_n, uint32_t lane_min) {
-    constexpr uint32_t WAVES = Lds<DYN>::WAVES;
-    __shared__ Lds<DYN> lds;
+    constexpr uint32_t WAVES = Lds<DYN, CAP>::WAVES;
+    __shared__ Lds<DYN, CAP> lds;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     if constexpr (!DYN) {
@@ -235,17 +280,20 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     // behind a length: dbase | deb << 16 and the bits of the code; NO_DCODE / BAD_DCODE = no such code / symbols 30, 31
     constexpr uint32_t NO_DCODE = 0xFFFFFFFEu, BAD_DCODE = 0xFFFFFFFFu;
     [[maybe_unused]] uint32_t XL[15], XD[15];       // DYN: the X words of this lane's literal/length and distance code
+    [[maybe_unused]] S5 DS;                         // DYN: its distance symbols, sorted by (code length, value)
     [[maybe_unused]] bool fixedblk = false;         // DYN: the current block is a fixed one (its symbol 287 is the reference's zero leaf)
-    [[maybe_unused]] uint8_t* tab8 = reinterpret_cast<uint8_t*>(lds.tab);
+    typedef Tab<CAP> T;
 #define TROW(j) lds.tab[(j) * 64u + lane]
-#define TBYTE(base, i) tab8[(((base) + ((i) >> 2)) << 8) | lane4 | ((i) & 3u)]
+#define TBYTE(base, i) reinterpret_cast<uint8_t*>(lds.tab)[(((base) + ((i) >> 2)) << 8) | lane4 | ((i) & 3u)]
+    // the idx-th literal/length symbol of the sorted list
+#define TOK_LSYM(idx) ((uint32_t)TBYTE(T::LS8, (idx)) | (((TROW(T::LBIT + ((idx) >> 5)) >> ((idx) & 31u)) & 1u) << 8))
     auto lit_at = [&](const uint32_t bits) -> uint32_t {
         if constexpr (!DYN) return lds.lit[bits & 511u];
         else {
             uint32_t len, idx; bool valid;
             x_decode<15>(XL, bits, len, idx, valid);
-            idx = min(idx, 287u);
-            const uint32_t sym = (uint32_t)TBYTE(T_LS8, idx) | (((TROW(T_LBIT + (idx >> 5)) >> (idx & 31u)) & 1u) << 8);
+            idx = min(idx, CAP - 1u);
+            const uint32_t sym = TOK_LSYM(idx);
             const uint32_t type = sym < 256u ? T_LIT : sym == 256u ? T_EOB : sym <= 285u ? T_LEN : T_BAD;
             uint32_t lbase, leb;
             length_info(sym - 257u, lbase, leb);
@@ -258,7 +306,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         else {
             uint32_t idx; bool valid;
             x_decode<15>(XD, bits, nbits, idx, valid);
-            const uint32_t ds = TBYTE(T_DS8, min(idx, 31u));
+            const uint32_t ds = DS.get(min(idx, 31u));
             uint32_t dbase, deb;
             dist_info(ds, dbase, deb);
             return !valid ? NO_DCODE : ds >= 30u ? BAD_DCODE : (dbase | (deb << 16));
@@ -275,14 +323,17 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         bb >>= ((bitp) & 7u); bc -= ((bitp) & 7u);                                                         \
     } while (0)
     // ---- DYN: the tables of a block, fixed (hm = 1: deflate.py:1066-1073) or dynamic (hm = 2: BL/READBL/REPEAT deflate.py:1084-1202,
-    // the canonical codes :1204-1400).  Returns the status; the acceptance rules are k_inflate_dyn's (zlib's).
+    // the canonical codes :1204-1400).  Returns the status; the acceptance rules are k_inflate_dyn's (zlib's).  A block whose
+    // literal/length code has more than CAP symbols is HDLZ_E_DYNAMIC_UNSUPPORTED here: the stream stays flagged for the next pass.
     auto build_tables = [&](const uint32_t hm) -> uint32_t {
         if constexpr (!DYN) return HDLZ_E_DYNAMIC_UNSUPPORTED;
         else {
-            for (uint32_t k = 0; k < 9u; k++) TROW(T_LBIT + k) = 0u;
-            for (uint32_t k = 0; k < 16u; k++) TROW(T_CNT + k) = 0u;
+            for (uint32_t k = 0; k < (CAP + 31u) / 32u; k++) TROW(T::LBIT + k) = 0u;
             uint32_t nlen = 288u, ndist = 32u, p0 = 0u;
             uint32_t XC[7];
+            F16 nL, nD;                       // symbols per code length (pass 1), then the next free slot per length (pass 2)
+            S5 CS;                            // the symbols of the code-length code, sorted
+            nL.clear(); nD.clear(); CS.clear(); DS.clear();
             // pass 1 (place = false) counts the symbols per code length, pass 2 puts every symbol into its slot of the sorted lists
             auto lens_pass = [&](auto place) -> uint32_t {
                 const uint32_t total = nlen + ndist;
@@ -293,7 +344,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                     uint32_t len, ci; bool valid;
                     x_decode<7>(XC, (uint32_t)bb, len, ci, valid);
                     if (!valid) return HDLZ_E_BAD_TREE;
-                    const uint32_t sym = TBYTE(T_CS8, min(ci, 18u));
+                    const uint32_t sym = CS.get(min(ci, 18u));
                     const uint32_t eb = sym < 16u ? 0u : sym == 16u ? 2u : sym == 17u ? 3u : 7u;
                     const uint32_t ev = (uint32_t)(bb >> len) & ((1u << eb) - 1u);
                     const uint32_t rep = sym < 16u ? 1u : sym == 18u ? 11u + ev : 3u + ev;
@@ -303,23 +354,24 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                     const uint32_t val = sym < 16u ? sym : sym == 16u ? prev : 0u;
                     // (a repeat may run from the literal/length lengths into the distance lengths)
                     const uint32_t nl = idx < nlen ? min(rep, nlen - idx) : 0u, nd = rep - nl;
-                    const uint32_t sh = 16u * (val & 1u);
                     if constexpr (!decltype(place)::value) {
-                        if (nl) atomicAdd(&TROW(T_CNT + (val >> 1)), nl << sh);
-                        if (nd) atomicAdd(&TROW(T_CNT + 8u + (val >> 1)), nd << sh);
+                        nL.add(val, nl);
+                        nD.add(val, nd);
                         has256 = has256 || (val != 0u && idx <= 256u && idx + rep > 256u);
                     } else if (val != 0u) {
                         if (nl) {
-                            const uint32_t pos = (atomicAdd(&TROW(T_CNT + (val >> 1)), nl << sh) >> sh) & 0xFFFFu;
+                            const uint32_t pos = nL.get(val);
+                            nL.add(val, nl);
                             for (uint32_t k = 0; k < nl; k++) {
                                 const uint32_t s_ = idx + k, q = pos + k;
-                                TBYTE(T_LS8, q) = (uint8_t)s_;
-                                if (s_ >= 256u) atomicOr(&TROW(T_LBIT + (q >> 5)), 1u << (q & 31u));
+                                TBYTE(T::LS8, q) = (uint8_t)s_;
+                                if (s_ >= 256u) atomicOr(&TROW(T::LBIT + (q >> 5)), 1u << (q & 31u));
                             }
                         }
                         if (nd) {
-                            const uint32_t pos = (atomicAdd(&TROW(T_CNT + 8u + (val >> 1)), nd << sh) >> sh) & 0xFFFFu;
-                            for (uint32_t k = 0; k < nd; k++) TBYTE(T_DS8, pos + k) = (uint8_t)(idx + nl + k - nlen);
+                            const uint32_t pos = nD.get(val);
+                            nD.add(val, nd);
+                            for (uint32_t k = 0; k < nd; k++) DS.put(pos + k, idx + nl + k - nlen);
                         }
                     }
                     prev = val;
@@ -329,14 +381,16 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 return HDLZ_OK;
             };
             if (hm == 1u) {
+                if constexpr (CAP < 288u) return HDLZ_E_DYNAMIC_UNSUPPORTED;
                 // 24 codes of 7 bits (256..279), 152 of 8 (0..143, 280..287), 112 of 9 (144..255); 32 distance codes of 5 bits
-                TROW(T_CNT + 3u) = 24u << 16; TROW(T_CNT + 4u) = 152u | (112u << 16); TROW(T_CNT + 8u + 2u) = 32u << 16;
+                nL.put(7, 24u); nL.put(8, 152u); nL.put(9, 112u); nD.put(5, 32u);
                 for (uint32_t q = 0; q < 288u; q++) {
                     const uint32_t s_ = q < 24u ? 256u + q : q < 168u ? q - 24u : q < 176u ? q + 112u : q - 32u;
-                    TBYTE(T_LS8, q) = (uint8_t)s_;
-                    if (s_ >= 256u) atomicOr(&TROW(T_LBIT + (q >> 5)), 1u << (q & 31u));
+                    TBYTE(T::LS8, q) = (uint8_t)s_;
+                    if (s_ >= 256u) atomicOr(&TROW(T::LBIT + (q >> 5)), 1u << (q & 31u));
                 }
-                for (uint32_t q = 0; q < 32u; q++) TBYTE(T_DS8, q) = (uint8_t)q;
+#pragma unroll
+                for (uint32_t q = 0; q < 32u; q++) DS.w[q / 12u] |= (uint64_t)q << ((q % 12u) * 5u);
             } else {
                 // BL (deflate.py:1090-1114)
                 TOK_REFILL();
@@ -368,29 +422,27 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
 #pragma unroll
                 for (int s_ = 0; s_ < 19; s_++) {
                     const uint32_t l5 = 5u * ((uint32_t)(cl >> (3 * s_)) & 7u);
-                    if (l5) { TBYTE(T_CS8, (uint32_t)(ow >> l5) & 31u) = (uint8_t)s_; ow += 1ull << l5; }
+                    if (l5) { CS.put((uint32_t)(ow >> l5) & 31u, (uint32_t)s_); ow += 1ull << l5; }
                 }
                 p0 = TOK_BITPOS();
                 const uint32_t st1 = lens_pass(std::false_type{});
                 if (st1 != HDLZ_OK) return st1;
             }
             int32_t l1, l2; uint32_t c1, c2;
-            x_build<15>(XL, [&](int l) { return (TROW(T_CNT + (uint32_t)(l >> 1)) >> (16 * (l & 1))) & 0xFFFFu; }, l1, c1);
-            x_build<15>(XD, [&](int l) { return (TROW(T_CNT + 8u + (uint32_t)(l >> 1)) >> (16 * (l & 1))) & 0xFFFFu; }, l2, c2);
+            x_build<15>(XL, [&](int l) { return nL.at(l); }, l1, c1);
+            x_build<15>(XD, [&](int l) { return nD.at(l); }, l2, c2);
             if (hm == 2u) {
                 // incomplete sets only with a single code -- or, for the distance code, with none at all (RFC1951 3.2.7)
                 if (l1 < 0 || (l1 > 0 && c1 != 1u)) return HDLZ_E_BAD_TREE;
                 if (l2 < 0 || (l2 > 0 && c2 > 1u)) return HDLZ_E_BAD_TREE;
+                if (c1 > CAP) return HDLZ_E_DYNAMIC_UNSUPPORTED;       // (only CAP_SMALL: at most 286 symbols are coded)
+                {                                      // counts -> first slot per length
+                    F16 fL, fD;
+                    fL.clear(); fD.clear();
+                    uint32_t oL = 0, oD = 0;
 #pragma unroll
-                for (uint32_t w = 0; w < 2u; w++) {    // counts -> first slot per length
-                    uint32_t off = 0, row = 0;
-#pragma unroll
-                    for (uint32_t l = 1; l < 16u; l++) {
-                        const uint32_t c = (TROW(T_CNT + 8u * w + (l >> 1)) >> (16u * (l & 1u))) & 0xFFFFu;
-                        if (l & 1u) { TROW(T_CNT + 8u * w + (l >> 1)) = row | (off << 16); row = 0; }
-                        else row = off;
-                        off += c;
-                    }
+                    for (int l = 1; l < 16; l++) { fL.put(l, oL); fD.put(l, oD); oL += nL.at(l); oD += nD.at(l); }
+                    nL = fL; nD = fD;
                 }
                 TOK_RESYNC(p0);
                 lens_pass(std::true_type{});
@@ -505,8 +557,8 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t i_ = min(ix[k], 287u);
-                    sy[k] = (uint32_t)TBYTE(T_LS8, i_) | (((TROW(T_LBIT + (i_ >> 5)) >> (i_ & 31u)) & 1u) << 8);
+                    const uint32_t i_ = min(ix[k], CAP - 1u);
+                    sy[k] = TOK_LSYM(i_);
                 }
                 bool lt[3];                                        // a literal is taken while a buffered bit is left behind it
 #pragma unroll
@@ -528,7 +580,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 x >>= leb;
                 uint32_t dnb, dix; bool dvd;
                 x_decode<15>(XD, (uint32_t)x, dnb, dix, dvd);
-                const uint32_t ds = TBYTE(T_DS8, min(dix, 31u));
+                const uint32_t ds = DS.get(min(dix, 31u));
                 uint32_t dbase, deb;
                 dist_info(ds, dbase, deb);
                 deb &= 15u;
@@ -701,6 +753,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         flushed += CHUNK;
     }
 #undef TROW
+#undef TOK_LSYM
 #undef TBYTE
 #undef TOK_RESYNC
 #undef TOK_FAIL
@@ -739,36 +792,53 @@ __global__ __launch_bounds__(256) void k_collect_dyn(const uint32_t* __restrict_
 
 hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
     if (a.nstreams == 0) return hipSuccess;
-    const uint64_t per_wg = 64u * tok::Lds<false>::WAVES;
-    const dim3 grid((unsigned)((a.nstreams + per_wg - 1u) / per_wg)), block(64 * tok::Lds<false>::WAVES);
-    hipLaunchKernelGGL(tok::k_inflate_tok<false>, grid, block, 0, stream, a, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+    typedef tok::Lds<false, tok::CAP_FULL> L;
+    const uint64_t per_wg = 64u * L::WAVES;
+    const dim3 grid((unsigned)((a.nstreams + per_wg - 1u) / per_wg)), block(64 * L::WAVES);
+    hipLaunchKernelGGL((tok::k_inflate_tok<false, tok::CAP_FULL>), grid, block, 0, stream, a, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, 0u);
     return hipGetLastError();
 }
 
 // second pass of the lane-per-stream mapping: the streams with dynamic-tree blocks, one lane each again.  `all`: every stream
-// is decoded here (no first pass, no list).  The list lives in stream-ordered scratch memory (4 bytes per stream).
+// is decoded here (no first pass).  Two stages: the CAP_SMALL build of the kernel (eight waves per CU) takes every such stream;
+// the ones it leaves flagged -- a literal/length code of more than CAP_SMALL symbols, or a fixed block between dynamic ones --
+// are collected again and go through the CAP_FULL build.  Either stage hands its streams to k_inflate_dyn (one wave each) when
+// they are fewer than `lane_min`; the counts stay on the device.  The lists live in stream-ordered scratch (4 bytes per stream).
 hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool all) {
     if (a.nstreams == 0 || (a.flags & HDLZ_INFLATE_ASSUME_FIXED)) return hipSuccess;
     const dim3 grid((unsigned)((a.nstreams + 63u) / 64u)), block(64);
-    if (all) {
-        hipLaunchKernelGGL(tok::k_inflate_tok<true>, grid, block, 0, stream, a, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
-        return hipGetLastError();
-    }
+    const dim3 cgrid((unsigned)((a.nstreams + 255u) / 256u)), cblock(256);
     uint32_t* ws = nullptr;
-    // (the explicit lane hint keeps every such stream in the lane kernel)
+    // (the explicit lane hint keeps every such stream in the lane kernels)
     const uint32_t lane_min = (a.flags & HDLZ_INFLATE_LANE_PER_STREAM) ? 0u : HDLZ_INFLATE_DYN_LANE_MIN;
     hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * (a.nstreams + 1u), stream);
-    if (e != hipSuccess) {                      // no scratch: the wave-per-stream second pass needs none and finishes the job
+    if (e != hipSuccess) {                      // no scratch: the wave-per-stream pass needs none and finishes the job
         (void)hipGetLastError();
-        return launch_inflate_dyn(a, stream, false);
+        return launch_inflate_dyn(a, stream, all);
     }
-    e = hipMemsetAsync(ws, 0, sizeof(uint32_t), stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(tok::k_collect_dyn, dim3((unsigned)((a.nstreams + 255u) / 256u)), dim3(256), 0, stream, a.status, a.nstreams,
-                           ws + 1, ws);
-        hipLaunchKernelGGL(tok::k_inflate_tok<true>, grid, block, 0, stream, a, (const uint32_t*)(ws + 1), (const uint32_t*)ws, lane_min);
+    if (all) {
+        hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, 0u);
         e = hipGetLastError();
-        if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws, lane_min);   // (one of the two returns at once)
+    } else {
+        e = hipMemsetAsync(ws, 0, sizeof(uint32_t), stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, ws + 1, ws);
+            hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, (const uint32_t*)(ws + 1),
+                               (const uint32_t*)ws, lane_min);
+            e = hipGetLastError();
+            if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws, lane_min);   // (one of the two returns at once)
+        }
+    }
+    // stage 2: what is still flagged (the list memory is reused: the launches are ordered on the stream)
+    if (e == hipSuccess) e = hipMemsetAsync(ws, 0, sizeof(uint32_t), stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, ws + 1, ws);
+        hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_FULL>), grid, block, 0, stream, a, (const uint32_t*)(ws + 1),
+                           (const uint32_t*)ws, lane_min);
+        e = hipGetLastError();
+        if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws, lane_min);
     }
     const hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
