@@ -36,6 +36,13 @@ int check_device() {
 }  // namespace
 
 namespace hdlz {
+__global__ __launch_bounds__(64) void k_zero_words(uint32_t* p, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n; i += 64u) p[i] = 0u;
+}
+hipError_t zero_words(uint32_t* p, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, p, n);
+    return hipGetLastError();
+}
 hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t stream) {
     static hipMemPool_t pools[64] = {nullptr};
     static bool tried[64] = {false};

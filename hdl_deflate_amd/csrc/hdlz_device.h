@@ -68,6 +68,9 @@ hipError_t launch_inflate_chunk(const uint8_t* in, uint32_t in_len, int final_, 
 // stream-ordered scratch memory from the library's OWN per-device memory pool (release threshold: keep -- with the default
 // pool's threshold of 0 every call paid a fresh device allocation: 10..40 ms for the 8 MB of a 1 MiB single-stream inflate)
 hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t stream);
+// p[0 .. n) = 0 by a kernel.  (Not hipMemsetAsync: captured into a HIP graph, a memset node on memory that a mem-alloc node of the
+// same graph hands out was seen to leave the words unchanged on ROCm 7.2 -- the device-side counters then started from garbage.)
+hipError_t zero_words(uint32_t* p, uint32_t n, hipStream_t stream);
 
 hipError_t launch_compact(const uint8_t* rows, uint64_t pitch, const uint32_t* len, const uint64_t* off,
                           uint64_t nblocks, uint8_t* archive, hipStream_t stream);

@@ -43,6 +43,11 @@ struct __attribute__((aligned(16))) DynLds {
 };
 
 typedef uint32_t __attribute__((aligned(1))) u32u;
+#ifdef HDLZ_DYN_MARKS                         // tools/phase_count.py --src hdlz_inflate_dyn.hip -DHDLZ_DYN_MARKS --kernel k_inflate_dynILb0E
+#define DYN_MARK(name) asm volatile("; @@PHASE " name ::: "memory")
+#else
+#define DYN_MARK(name) do {} while (0)
+#endif
 
 __device__ __forceinline__ uint32_t dload32(const uint8_t* __restrict__ z, uint32_t ip, uint32_t zn) {
     if (ip + 4u <= zn) return *reinterpret_cast<const u32u*>(z + ip);
@@ -432,7 +437,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 build_x(XD, L.cnt[2]);
                 uint32_t bp = BITPOS();                             // absolute bit position of the next token
                 for (bool eob = false; !eob;) {
+                    DYN_MARK("window");
                     ensure_window(bp);
+                    DYN_MARK("decode");
                     // ---- every lane: the token that would start at bit bp + lane
                     const uint32_t bitpos = bp + lane;
                     uint32_t len, symi, sym, tlen = 0, distance = 0, total;
@@ -468,6 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     }
                     // ---- the real chain: token at bit 0, then at the end of each chained token, up to bit 63; it stops
                     // at anything that is not a plain literal / complete match (their bit count is not trusted)
+                    DYN_MARK("chain");
                     const bool plain = lit || (ismatch && mvalid);
                     uint64_t chain = 0;
                     uint32_t cur = 0;
@@ -486,6 +494,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                             cur += st_ & 255u;
                         }
                     }
+                    DYN_MARK("checks");
                     const bool inchain = (chain >> lane) & 1ull;
                     const uint32_t outlen = (inchain && plain) ? (lit ? 1u : tlen) : 0u;
                     const uint32_t pos = o + excl;
@@ -525,6 +534,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     // ---- commit.  All literals first, in parallel; then the copies in stream order.  Ring argument: a window
                     // adds at most WCAP < 512 bytes, a copy reads the ring only up to DRING - 512 back, so a literal written
                     // ahead of a copy can never land in a ring slot that copy still reads.
+                    DYN_MARK("commit");
                     const bool mine = (commit >> lane) & 1ull;
                     if (mine && lit) L.ring[pos & (DRING - 1u)] = (uint8_t)sym;
                     uint64_t mm = __ballot(mine && ismatch);
@@ -548,11 +558,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                             L.ring[(P + i) & (DRING - 1u)] = (uint8_t)byte;
                         }
                     }
+                    DYN_MARK("flush");
                     flush_lines(o, o_new);
                     o = o_new;
                     bp += consumed;
+                    DYN_MARK("loopend");
                     if (STREAM && need != 0u) { save_bit = bp; save_phase = 1; goto done; }   // parked between two tokens
                 }
+                DYN_MARK("after");
                 RESYNC(bp);                                         // back to the scalar bit reader (block headers)
             }
             if (final_) break;                                                   // D6

@@ -762,7 +762,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     uint8_t* ws = nullptr;
     hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), off, stream);
     if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // no scratch: the caller goes on with the serial decoder
-    e = hipMemsetAsync(ws + o_ctl, 0, 4u * C_WORDS, stream);
+    e = zero_words(reinterpret_cast<uint32_t*>(ws + o_ctl), C_WORDS, stream);
     if (e == hipSuccess) {
         ParArgs p{a.in, zn, a.flags, a.obsize, a.out, (uint32_t)cap64, (uint32_t)srcn, a.out_len, a.status, nchunks, chbits,
                   reinterpret_cast<uint32_t*>(ws + o_ctl), ws + o_ex, reinterpret_cast<uint32_t*>(ws + o_nb), ws + o_en,

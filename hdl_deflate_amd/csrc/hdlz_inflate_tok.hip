@@ -809,36 +809,35 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
     if (a.nstreams == 0 || (a.flags & HDLZ_INFLATE_ASSUME_FIXED)) return hipSuccess;
     const dim3 grid((unsigned)((a.nstreams + 63u) / 64u)), block(64);
     const dim3 cgrid((unsigned)((a.nstreams + 255u) / 256u)), cblock(256);
-    uint32_t* ws = nullptr;
+    uint32_t* ws = nullptr;                      // ws[0], ws[1]: the two counts; the list from ws + 2 on (both stages: the launches are ordered)
     // (the explicit lane hint keeps every such stream in the lane kernels)
     const uint32_t lane_min = (a.flags & HDLZ_INFLATE_LANE_PER_STREAM) ? 0u : HDLZ_INFLATE_DYN_LANE_MIN;
-    hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * (a.nstreams + 1u), stream);
+    hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * (a.nstreams + 2u), stream);
     if (e != hipSuccess) {                      // no scratch: the wave-per-stream pass needs none and finishes the job
         (void)hipGetLastError();
         return launch_inflate_dyn(a, stream, all);
     }
-    if (all) {
-        hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, 0u);
-        e = hipGetLastError();
-    } else {
-        e = hipMemsetAsync(ws, 0, sizeof(uint32_t), stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, ws + 1, ws);
-            hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, (const uint32_t*)(ws + 1),
+    e = zero_words(ws, 2u, stream);
+    if (e == hipSuccess) {
+        if (all) {
+            hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, (const uint32_t*)nullptr,
+                               (const uint32_t*)nullptr, 0u);
+            e = hipGetLastError();
+        } else {
+            hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, ws + 2, ws);
+            hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, (const uint32_t*)(ws + 2),
                                (const uint32_t*)ws, lane_min);
             e = hipGetLastError();
             if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws, lane_min);   // (one of the two returns at once)
         }
     }
-    // stage 2: what is still flagged (the list memory is reused: the launches are ordered on the stream)
-    if (e == hipSuccess) e = hipMemsetAsync(ws, 0, sizeof(uint32_t), stream);
+    // stage 2: what is still flagged
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, ws + 1, ws);
-        hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_FULL>), grid, block, 0, stream, a, (const uint32_t*)(ws + 1),
-                           (const uint32_t*)ws, lane_min);
+        hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, ws + 2, ws + 1);
+        hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_FULL>), grid, block, 0, stream, a, (const uint32_t*)(ws + 2),
+                           (const uint32_t*)(ws + 1), lane_min);
         e = hipGetLastError();
-        if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws, lane_min);
+        if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws + 1, lane_min);
     }
     const hipError_t e2 = hipFreeAsync(ws, stream);
     return e != hipSuccess ? e : e2;
