@@ -40,6 +40,7 @@ struct __attribute__((aligned(16))) DynLds {
     int32_t left[3];
     uint32_t cnt32[16];              // scratch of canon_build
     uint32_t next[16];
+    uint64_t mdesc[64];              // commit: the window's matches whose source lies before the window (position, length, distance)
 };
 
 typedef uint32_t __attribute__((aligned(1))) u32u;
@@ -436,7 +437,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 build_x(XL, L.cnt[1]);
                 build_x(XD, L.cnt[2]);
                 uint32_t bp = BITPOS();                             // absolute bit position of the next token
+#ifdef HDLZ_DYN_X_HDRONLY
+                for (bool eob = true; !eob;) {
+#else
                 for (bool eob = false; !eob;) {
+#endif
                     DYN_MARK("window");
                     ensure_window(bp);
                     DYN_MARK("decode");
@@ -500,21 +505,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     const uint32_t pos = o + excl;
                     // ---- the reference's checks, per token, in its order (deflate.py:1409-1445, :1519-1591, :1447-1517, :1600)
                     constexpr uint32_t ST_EOB = 100, ST_CUT = 101, ST_NEEDIN = 102, ST_NEEDOUT = 103;
-                    uint32_t st = 0;
-                    // STREAM, more input to come: a token is only decoded when its 64 bits are here; the end-of-input checks
-                    // (deflate.py:1535-1539, :1600) are the final call's business -- and hold for every token decoded earlier
-                    if (STREAM && !sfinal && bitpos + 64u > inbits) st = ST_NEEDIN;
-                    else if (!valid) st = HDLZ_E_BAD_SYMBOL;
-                    else if (hm == 1u && sym == 287u) st = HDLZ_E_BAD_SYMBOL;                        // zero leaf, deflate.py:212,:1437-1439
-                    else if (sfinal && (int32_t)((bitpos + len) >> 3) > isize - 3) st = HDLZ_E_NO_EOF;         // deflate.py:1535-1539
-                    else if (eobt) st = ST_EOB;
-                    else if (lit) { if (pos >= cap) st = STREAM ? ST_NEEDOUT : (uint32_t)HDLZ_E_OUT_CAPACITY; }
-                    else if (token >= 29u) st = HDLZ_E_BAD_SYMBOL;
-                    else if (dlen > 15u) st = HDLZ_E_BAD_SYMBOL;
-                    else if (ds >= 30u) st = HDLZ_E_BAD_DISTANCE;
-                    else if (distance > pos || distance > obsize) st = HDLZ_E_BAD_DISTANCE;          // deflate.py:1506-1508, D8
-                    else if (sfinal && (int32_t)((bitpos + total) >> 3) >= isize - 2) st = HDLZ_E_NO_EOF;      // COPY hold, :1600
-                    else if ((uint64_t)pos + tlen > cap) st = STREAM ? ST_NEEDOUT : (uint32_t)HDLZ_E_OUT_CAPACITY;
+                    // (evaluated as a chain of selects from the LAST check of the reference's order to the first -- an earlier check
+                    // overrides a later one; the same conditions as `if ... else if` cost ~90 scalar mask instructions per window)
+                    uint32_t st;
+                    {
+                        const uint32_t outcode = STREAM ? ST_NEEDOUT : (uint32_t)HDLZ_E_OUT_CAPACITY;
+                        uint32_t m = ((uint64_t)pos + tlen > cap) ? outcode : 0u;
+                        m = (sfinal && (int32_t)((bitpos + total) >> 3) >= isize - 2) ? (uint32_t)HDLZ_E_NO_EOF : m;      // COPY hold, :1600
+                        m = (distance > pos || distance > obsize) ? (uint32_t)HDLZ_E_BAD_DISTANCE : m;                    // deflate.py:1506-1508, D8
+                        m = ds >= 30u ? (uint32_t)HDLZ_E_BAD_DISTANCE : m;
+                        m = (dlen > 15u || token >= 29u) ? (uint32_t)HDLZ_E_BAD_SYMBOL : m;
+                        st = lit ? (pos >= cap ? outcode : 0u) : m;
+                        st = eobt ? ST_EOB : st;
+                        st = (sfinal && (int32_t)((bitpos + len) >> 3) > isize - 3) ? (uint32_t)HDLZ_E_NO_EOF : st;       // deflate.py:1535-1539
+                        st = (!valid || (hm == 1u && sym == 287u)) ? (uint32_t)HDLZ_E_BAD_SYMBOL : st;                    // zero leaf, deflate.py:212,:1437-1439
+                        // STREAM, more input to come: a token is only decoded when its 64 bits are here; the end-of-input checks
+                        // (deflate.py:1535-1539, :1600) are the final call's business -- and hold for every token decoded earlier
+                        if (STREAM) st = (!sfinal && bitpos + 64u > inbits) ? ST_NEEDIN : st;
+                    }
+#ifdef HDLZ_DYN_X_NOCHECK
+                    st = eobt ? ST_EOB : 0u;
+#endif
                     if (st == 0u && excl + outlen > WCAP) st = ST_CUT;                               // rest of the chain: next window
                     const uint64_t special = __ballot(inchain && st != 0u);
                     uint64_t commit = chain;
@@ -538,6 +549,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     const bool mine = (commit >> lane) & 1ull;
                     if (mine && lit) L.ring[pos & (DRING - 1u)] = (uint8_t)sym;
                     uint64_t mm = __ballot(mine && ismatch);
+#ifdef HDLZ_DYN_X_NOCOPY
+                    mm = 0ull;
+#endif
+                    {
+                        // matches whose source lies wholly BEFORE this window (distance >= bytes of the window in front of the
+                        // match + its length) and inside the ring depend on nothing the window produces: four at a time, sixteen
+                        // lanes each -- the serial loop below (~30 VALU + ~30 scalar instructions per match) keeps the others
+                        const bool par = mine && ismatch && distance >= excl + tlen && distance + tlen <= DRING - 512u;
+                        const uint64_t pm = __ballot(par);
+                        const uint32_t np = (uint32_t)__popcll(pm);
+                        if (np >= 2u) {
+                            mm &= ~pm;
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                            if (par) L.mdesc[rank] = (uint64_t)pos | ((uint64_t)(tlen | (distance << 16)) << 32);
+                            const uint32_t g = lane >> 4, sub = lane & 15u;
+                            for (uint32_t base = 0; base < np; base += 4u) {
+                                const uint32_t idx = base + g;
+                                const uint64_t dsc = L.mdesc[min(idx, 63u)];
+                                const uint32_t P = (uint32_t)dsc, tl = idx < np ? (uint32_t)(dsc >> 32) & 0xFFFFu : 0u, D = (uint32_t)(dsc >> 48);
+                                for (uint32_t i = sub; i < tl; i += 16u) L.ring[(P + i) & (DRING - 1u)] = L.ring[(P - D + i) & (DRING - 1u)];
+                            }
+                        }
+                    }
                     while (mm != 0ull) {
                         const uint32_t k = (uint32_t)__builtin_ctzll(mm);
                         mm &= mm - 1ull;
