@@ -27,6 +27,7 @@ constexpr uint32_t IWIN = 512;      // compressed-input window staged in LDS (by
 constexpr uint32_t DYN_ALL = 0x80000000u;   // internal flag bit: this kernel is the only pass, every stream is its
 constexpr uint32_t DYN_FINAL = 0x40000000u; // internal flag bit (STREAM): in_len is the final stream length
 constexpr uint32_t DYN_HDR_BYTES = 700;     // a dynamic block header is at most 14 + 19*3 + 316*(7+7) bits = 562 bytes
+constexpr uint32_t LUTL = 9, LUTD = 7;  // bits of the two look-up tables in front of the X-word decode
 constexpr uint32_t WCAP = 448;       // output bytes committed per decode window (< 512: see the ring argument at the commit)
 
 struct __attribute__((aligned(16))) DynLds {
@@ -40,6 +41,8 @@ struct __attribute__((aligned(16))) DynLds {
     int32_t left[3];
     uint32_t cnt32[16];              // scratch of canon_build
     uint32_t next[16];
+    uint16_t lutl[1u << 9];          // window decode: literal/length codes of up to LUTL bits, symbol | length << 9 by the next LUTL stream bits
+    uint16_t lutd[1u << 7];          // ... distance codes of up to LUTD bits, symbol | length << 5 (0 = no such short code: the X words decide)
     uint64_t mdesc[64];              // commit: the window's matches whose source lies before the window (position, length, distance)
 };
 
@@ -436,6 +439,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 XCode XL, XD;
                 build_x(XL, L.cnt[1]);
                 build_x(XD, L.cnt[2]);
+                // the two tables: entry e = the code that the stream bits e (LSB first) start with, if it is short enough
+                for (uint32_t e = lane; e < (1u << LUTL); e += 64u) {
+                    uint32_t l_, si_;
+                    xwalk(XL, e, l_, si_);
+                    L.lutl[e] = (uint16_t)(l_ <= LUTL ? (L.lsym[min(si_, 287u)] | (l_ << 9)) : 0u);
+                }
+                for (uint32_t e = lane; e < (1u << LUTD); e += 64u) {
+                    uint32_t l_, si_;
+                    xwalk(XD, e, l_, si_);
+                    L.lutd[e] = (uint16_t)(l_ <= LUTD ? (L.dsym[min(si_, 31u)] | (l_ << 5)) : 0u);
+                }
+                __syncthreads();
                 uint32_t bp = BITPOS();                             // absolute bit position of the next token
 #ifdef HDLZ_DYN_X_HDRONLY
                 for (bool eob = true; !eob;) {
@@ -447,36 +462,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     DYN_MARK("decode");
                     // ---- every lane: the token that would start at bit bp + lane
                     const uint32_t bitpos = bp + lane;
-                    uint32_t len, symi, sym, tlen = 0, distance = 0, total;
-                    bool lit, eobt, ismatch, valid, mvalid = false;
-                    uint32_t token, dlen = 16, ds = 0;
+                    uint32_t len, sym, tlen, distance, total, token, dlen, ds;
+                    bool lit, eobt, ismatch, valid, mvalid;
                     {
+                        // branch-free: every lane computes a match's fields, the flags say what they are worth.  Codes of up to
+                        // LUTL / LUTD bits -- all of them in most blocks -- come out of a table by the next stream bits; when a lane
+                        // that matters sees a longer one the whole wave takes the X-word decode (xwalk, ~38 VALU instructions)
                         const uint64_t x = bits64(bitpos);
-                        xwalk(XL, (uint32_t)x, len, symi);
+                        const uint32_t el = L.lutl[(uint32_t)x & ((1u << LUTL) - 1u)];
+                        len = el >> 9; sym = el & 511u;
+                        if (__ballot(el == 0u) != 0ull) {
+                            uint32_t symi;
+                            xwalk(XL, (uint32_t)x, len, symi);
+                            sym = L.lsym[min(symi, 287u)];
+                        }
                         valid = len <= 15u;
-                        sym = L.lsym[min(symi, 287u)];
                         lit = valid && sym < 256u;
                         eobt = valid && sym == 256u;
                         ismatch = valid && sym > 256u;
                         token = sym - 257u;
-                        total = len;
-                        if (ismatch && token < 29u) {
-                            uint32_t lbase, leb, dbase, deb, dsymi;
-                            d_length_info(token, lbase, leb);
-                            const uint64_t x1 = x >> len;
-                            tlen = lbase + ((uint32_t)x1 & ((1u << leb) - 1u));
-                            const uint64_t x2 = x1 >> leb;
+                        uint32_t lbase, leb, dbase, deb;
+                        d_length_info(min(token, 28u), lbase, leb);
+                        const uint64_t x1 = x >> len;
+                        tlen = lbase + ((uint32_t)x1 & ((1u << leb) - 1u));
+                        const uint64_t x2 = x1 >> leb;
+                        const uint32_t ed = L.lutd[(uint32_t)x2 & ((1u << LUTD) - 1u)];
+                        dlen = ed >> 5; ds = ed & 31u;
+                        if (__ballot(ismatch && token < 29u && ed == 0u) != 0ull) {
+                            uint32_t dsymi;
                             xwalk(XD, (uint32_t)x2, dlen, dsymi);
-                            if (dlen <= 15u) {
-                                ds = L.dsym[min(dsymi, 31u)];
-                                if (ds < 30u) {
-                                    d_dist_info(ds, dbase, deb);
-                                    distance = dbase + ((uint32_t)(x2 >> dlen) & ((1u << deb) - 1u));
-                                    total = len + leb + dlen + deb;
-                                    mvalid = true;
-                                }
-                            }
+                            ds = L.dsym[min(dsymi, 31u)];
                         }
+                        d_dist_info(min(ds, 29u), dbase, deb);
+                        distance = dbase + ((uint32_t)(x2 >> min(dlen, 15u)) & ((1u << deb) - 1u));
+                        mvalid = ismatch && token < 29u && dlen - 1u <= 14u && ds < 30u;
+                        total = mvalid ? len + leb + dlen + deb : len;
                     }
                     // ---- the real chain: token at bit 0, then at the end of each chained token, up to bit 63; it stops
                     // at anything that is not a plain literal / complete match (their bit count is not trusted)
