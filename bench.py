@@ -302,6 +302,9 @@ def main_single(a):
         torch.cuda.empty_cache()
         # -- configs[3]: inflate
         sec.append(bench_inflate(a, eng, cpu=False))
+        # -- streams with dynamic-tree blocks (stock zlib, default strategy): pass 1 flags them, k_inflate_tok<true>
+        #    decodes them one lane each; the same streams one wave each beside it
+        sec.append(bench_inflate(a, eng, cpu=False, streams=min(a.streams, 1 << 18), strategy="default"))
         # -- the reference's own use: ONE stream at a time.  STARTC then STARTD on one 16 MiB stream (the most a port with LMAX = 24
         #    holds), each on the whole GPU (k_stream_*, k_par_*)
         sec.append(bench_single_stream(torch, eng, dev, a))
@@ -450,7 +453,7 @@ def _zfixed_chunk(args):
     return b"".join(out), [len(z) for z in out]
 
 
-def bench_inflate(a, eng=None, cpu=True):
+def bench_inflate(a, eng=None, cpu=True, streams=None, strategy=None):
     """BASELINE configs[3]: B stock-zlib Z_FIXED streams (wbits=15) over 2 KiB blocks of families 1/2/4
     (family 3 would make zlib emit stored blocks, which the DYNAMIC=False reference mis-decodes), made on
     the host cores with stock zlib outside the timed region; DYNAMIC=False semantics
@@ -464,6 +467,11 @@ def bench_inflate(a, eng=None, cpu=True):
     dev = torch.device("cuda", 0)
     if eng is None:
         eng = hdl_deflate_amd.Engine(dev)
+    if streams is not None or strategy is not None:          # the dynamic-tree secondary entry: same flow, other streams
+        import copy
+        a = copy.copy(a)
+        a.streams = streams or a.streams
+        a.zlib_strategy = strategy or a.zlib_strategy
     B, n = a.streams, a.stream_block
     d_plain = make_blocks(B, n, dev, seed=4, families=(1, 2, 4))
     host = d_plain.cpu().numpy()
@@ -493,7 +501,7 @@ def bench_inflate(a, eng=None, cpu=True):
     z_bytes, u_bytes = int(off[-1]), B * n
     algo = z_bytes + u_bytes + 4 * B
     fixed = a.zlib_strategy == "fixed"
-    res = {"name": "configs[3]",
+    res = {"name": "configs[3]" if fixed else "dynamic trees",
            "metric": "inflate_output_throughput (zlib Z_FIXED streams, DYNAMIC=False)" if fixed
            else "inflate_output_throughput (stock zlib streams, dynamic trees, two passes)",
            "value": round(u_bytes / (dt / a.steps) / 1e6, 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps,
@@ -508,6 +516,20 @@ def bench_inflate(a, eng=None, cpu=True):
            "roofline": roofline(("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok<false>") +
                                 ("" if fixed else " + k_inflate_dyn" if a.inflate_kernel == "byte" else " + k_inflate_tok<true>"), algo, k_ms,
                                 "%s|streams=%d|block=%d" % ("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok", B, n))}
+    if not fixed:
+        # the same streams one WAVE each (k_inflate_dyn: what small batches and sessions run), half of them: the mapping's own figure
+        Bw = max(1, B // 2)
+        wflags = hdl_deflate_amd.INFLATE_WAVE_PER_STREAM
+
+        def step_w():
+            return eng.inflate_batch(d_in, in_off=d_off[:Bw + 1], out_pitch=n, flags=wflags, out=d_out[:Bw])
+
+        d_out.zero_()
+        _, olw, stw = step_w()
+        assert int((stw != 0).sum().item()) == 0 and torch.equal(d_out[:Bw], d_plain[:Bw]), "wave-per-stream inflate differs"
+        w_ms = kernel_ms(torch, step_w, max(3, a.steps))
+        res["wave_per_stream"] = {"streams": Bw, "MBps": round(Bw * n / (sum(w_ms) / len(w_ms)) / 1e3, 1),
+                                  "ms": round(sum(w_ms) / len(w_ms), 4), "kernel": "k_inflate_dyn<false>"}
     if cpu and a.cpu_seconds > 0:
         from oracle import oracle as O
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

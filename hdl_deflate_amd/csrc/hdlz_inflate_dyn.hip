@@ -578,8 +578,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         // lanes each -- the serial loop below (~30 VALU + ~30 scalar instructions per match) keeps the others
                         const bool par = mine && ismatch && distance >= excl + tlen && distance + tlen <= DRING - 512u;
                         const uint64_t pm = __ballot(par);
+#ifdef HDLZ_DYN_X_NOCOPY
+                        const uint32_t np = 0u;
+#else
                         const uint32_t np = (uint32_t)__popcll(pm);
-                        if (np >= 2u) {
+#endif
+                        if (np != 0u) {
                             mm &= ~pm;
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
                             if (par) L.mdesc[rank] = (uint64_t)pos | ((uint64_t)(tlen | (distance << 16)) << 32);
@@ -599,11 +603,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         const uint32_t tlength = (uint32_t)__builtin_amdgcn_readlane((int)tlen, (int)k);
                         const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)distance, (int)k);
                         // COPY (deflate.py:1627-1659), lane-parallel: out[P+i] = out[P - D + (i mod D)]
-                        if (D + tlength > DRING - 512u) {
-                            // far history is read back from HBM: only then must the earlier line flushes have landed
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        // (P, D, tlength are wave-uniform: the common cases get their own lean loops)
+                        if (D + tlength <= DRING - 512u) {                      // source and destination inside the ring
+                            if (D >= tlength) {
+                                for (uint32_t i = lane; i < tlength; i += 64u) L.ring[(P + i) & (DRING - 1u)] = L.ring[(P - D + i) & (DRING - 1u)];
+                            } else {
+                                for (uint32_t i = lane; i < tlength; i += 64u) L.ring[(P + i) & (DRING - 1u)] = L.ring[(P - D + i % D) & (DRING - 1u)];
+                            }
+                            continue;
                         }
+                        // far history is read back from HBM: only then must the earlier line flushes have landed
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         for (uint32_t i = lane; i < tlength; i += 64u) {
                             const uint32_t src = P - D + (D >= tlength ? i : i % D);
                             uint32_t byte;
