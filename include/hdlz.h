@@ -108,7 +108,8 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
  * STARTD for a batch of independent zlib streams: 2 header bytes skipped unvalidated, blocks
  * until BFINAL, stored (BTYPE 0), fixed-Huffman (BTYPE 1) and dynamic-tree (BTYPE 2, deflate.py:1084-1517;
  * handled by a second pass over the streams that hold such blocks -- see the mapping hints above; in the lane
- * mapping that pass keeps the list of these streams in stream-ordered scratch memory, hipMallocAsync /
+ * mapping that pass runs in two stages, the second one for the few streams whose block codes more than 144
+ * literal/length symbols, and keeps the list of its streams in stream-ordered scratch memory, hipMallocAsync /
  * hipFreeAsync on `stream`, 4 bytes per stream (if that allocation fails the wave mapping finishes the job); the
  * parallel path for ONE large stream or a few of them -- HDLZ_INFLATE_PAR_MIN below -- allocates 8 bytes per possible
  * output byte the same way, whatever the flags; no other case allocates, and every case stays capturable into a HIP
