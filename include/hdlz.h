@@ -67,8 +67,8 @@ enum {
  * wave per stream (measured crossovers on 2 KiB and 16 KiB streams, tools/bench_inflate_mapping.py) */
 #define HDLZ_INFLATE_LANE_PER_STREAM 2u
 #define HDLZ_INFLATE_WAVE_PER_STREAM 4u
-#define HDLZ_INFLATE_WAVE_THRESHOLD 14336u
-#define HDLZ_INFLATE_DYN_LANE_MIN 20480u
+#define HDLZ_INFLATE_WAVE_THRESHOLD 22528u
+#define HDLZ_INFLATE_DYN_LANE_MIN 28672u
 /* a batch of ONE stream of at least this many bytes (fixed-pitch form, no mapping hint) is cut into 1 KiB pieces and decoded by
  * the whole GPU when it is a single fixed-Huffman block -- the streams STARTC writes --, else by one wave as before (decided on
  * the device, same results); scratch: stream-ordered, 8 bytes per possible output byte (min(out_pitch, 172 * in_len)).

@@ -515,7 +515,7 @@ def test_inflate_dynamic_streams_vs_oracle(engine, oracle):
 def test_inflate_auto_mapping_second_pass(engine, oracle):
     """the DEFAULT mapping on batches above HDLZ_INFLATE_WAVE_THRESHOLD: pass 1 one lane per stream; the streams with
     dynamic-tree blocks are counted on the device and redone one lane each when they are at least
-    HDLZ_INFLATE_DYN_LANE_MIN (case 1: all 24576), else one wave each (case 2: every fourth).  Every stream against
+    HDLZ_INFLATE_DYN_LANE_MIN (case 1: all 32768), else one wave each (case 2: every fourth).  Every stream against
     the oracle (a small pool of distinct streams -- good, damaged, cut -- repeated)."""
     import torch
     r = random.Random(77)
@@ -532,7 +532,7 @@ def test_inflate_auto_mapping_second_pass(engine, oracle):
             z = bytes(zb)
         rc, ref = oracle.inflate(z, out_cap=6016)
         (pool_dyn if it % 2 else pool_fix).append((z, rc, ref))
-    B, cap = 24576, 6016
+    B, cap = 32768, 6016
     for case, pick in (("all dynamic", lambda k: pool_dyn[k % len(pool_dyn)]),
                        ("every fourth", lambda k: pool_dyn[(k // 4) % len(pool_dyn)] if k % 4 == 0 else pool_fix[k % len(pool_fix)])):
         sel = [pick(k) for k in range(B)]
