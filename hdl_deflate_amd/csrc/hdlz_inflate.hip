@@ -87,7 +87,7 @@ __device__ __forceinline__ void dist_info(uint32_t dc, uint32_t& base, uint32_t&
 //   type 0 literal, 1 length symbol 257..285, 2 end of block, 3 invalid (286: nbits 8; 287: nbits 0 =
 //   the reference's zero leaf at index 483 -> "< 1 bits")
 enum { T_LIT = 0, T_LEN = 1, T_EOB = 2, T_BAD = 3 };
-__device__ __forceinline__ uint32_t lit_entry(uint32_t c) {
+__device__ __forceinline__ uint32_t lit_entry(uint32_t c, bool zero_leaf) {
     uint32_t sym, nb;
     const uint32_t r7 = rev(c & 127u, 7), r8 = rev(c & 255u, 8), r9 = rev(c, 9);
     if (r7 < 24u) { sym = 256u + r7; nb = 7; }                        // 0000000..0010111
@@ -97,7 +97,7 @@ __device__ __forceinline__ uint32_t lit_entry(uint32_t c) {
     uint32_t type = sym < 256u ? T_LIT : sym == 256u ? T_EOB : sym <= 285u ? T_LEN : T_BAD;
     uint32_t lbase = 0, leb = 0;
     if (type == T_LEN) length_info(sym - 257u, lbase, leb);
-    if (sym == 287u) nb = 0;
+    if (c == 483u && zero_leaf) nb = 0;   // (DYNAMIC=False build only, see hdlz_inflate_tables.h; index 227 is an ordinary leaf)
     return nb | (sym << 4) | (type << 13) | (lbase << 16) | (leb << 25);
 }
 // distance table entry for the raw 5 bits: dbase[15:0] | deb[19:16], 0xFFFFFFFF for codes 30/31
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
     __shared__ InflateLds lds;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    for (uint32_t c = threadIdx.x; c < 512u; c += 64u * WAVES) lds.lit[c] = lit_entry(c);
+    for (uint32_t c = threadIdx.x; c < 512u; c += 64u * WAVES) lds.lit[c] = lit_entry(c, (a.flags & HDLZ_INFLATE_ASSUME_FIXED) != 0u);
     if (threadIdx.x < 32u) lds.dst[threadIdx.x] = dst_entry(threadIdx.x);
     __syncthreads();                 // the only workgroup barrier: the waves are independent from here on
 

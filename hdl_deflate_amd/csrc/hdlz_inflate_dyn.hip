@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     // ---- every lane: the token that would start at bit bp + lane
                     const uint32_t bitpos = bp + lane;
                     uint32_t len, sym, tlen, distance, total, token, dlen, ds;
-                    bool lit, eobt, ismatch, valid, mvalid;
+                    bool lit, eobt, ismatch, valid, mvalid, zleaf;
                     {
                         // branch-free: every lane computes a match's fields, the flags say what they are worth.  Codes of up to
                         // LUTL / LUTD bits -- all of them in most blocks -- come out of a table by the next stream bits; when a lane
@@ -477,6 +477,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                             sym = L.lsym[min(symi, 287u)];
                         }
                         valid = len <= 15u;
+                        // the reference's ONE zero leaf: stat_leaves[483] of the DYNAMIC=False build = symbol 287's 8-bit code followed by a 1
+                        // (deflate.py:212); its other slot (a 0 follows) is an ordinary leaf -- code 287 passes NEXT and fails in INFLATE, after
+                        // the end-of-input check --, and so are both in a DYNAMIC=True build (leaves built from the fixed lengths)
+                        zleaf = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) != 0u && sym == 287u && (((uint32_t)x >> 8) & 1u) != 0u;
                         lit = valid && sym < 256u;
                         eobt = valid && sym == 256u;
                         ismatch = valid && sym > 256u;
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         st = lit ? (pos >= cap ? outcode : 0u) : m;
                         st = eobt ? ST_EOB : st;
                         st = (sfinal && (int32_t)((bitpos + len) >> 3) > isize - 3) ? (uint32_t)HDLZ_E_NO_EOF : st;       // deflate.py:1535-1539
-                        st = (!valid || (hm == 1u && sym == 287u)) ? (uint32_t)HDLZ_E_BAD_SYMBOL : st;                    // zero leaf, deflate.py:212,:1437-1439
+                        st = (!valid || zleaf) ? (uint32_t)HDLZ_E_BAD_SYMBOL : st;                    // zero leaf, deflate.py:212,:1437-1439
                         // STREAM, more input to come: a token is only decoded when its 64 bits are here; the end-of-input checks
                         // (deflate.py:1535-1539, :1600) are the final call's business -- and hold for every token decoded earlier
                         if (STREAM) st = (!sfinal && bitpos + 64u > inbits) ? ST_NEEDIN : st;

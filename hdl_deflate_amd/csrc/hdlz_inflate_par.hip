@@ -81,7 +81,7 @@ struct ParArgs {
 };
 
 __device__ __forceinline__ void fill_tables(uint32_t* lit, uint32_t* dst, uint32_t tid, uint32_t nthreads) {
-    for (uint32_t c = tid; c < 512u; c += nthreads) lit[c] = tok::lit_entry(c);
+    for (uint32_t c = tid; c < 512u; c += nthreads) lit[c] = tok::lit_entry(c, true);      // (symbols 286 / 287 send the stream to the serial decoder whatever their leaf says)
     if (tid < 32u) dst[tid] = tok::dst_entry(tid);
 }
 // the window of piece c: stream dwords from byte B0 = (first bit of the piece / 8) & ~3 on

@@ -34,7 +34,7 @@ __device__ __forceinline__ void dist_info(uint32_t dc, uint32_t& base, uint32_t&
 }
 // the widened stat_leaves (deflate.py:151-216): nbits[3:0] | sym[12:4] | type[14:13] | lbase[24:16] | leb[27:25]
 enum { T_LIT = 0, T_LEN = 1, T_EOB = 2, T_BAD = 3 };
-__device__ __forceinline__ uint32_t lit_entry(uint32_t c) {
+__device__ __forceinline__ uint32_t lit_entry(uint32_t c, bool zero_leaf) {
     uint32_t sym, nb;
     const uint32_t r7 = rev(c & 127u, 7), r8 = rev(c & 255u, 8), r9 = rev(c, 9);
     if (r7 < 24u) { sym = 256u + r7; nb = 7; }
@@ -44,7 +44,10 @@ __device__ __forceinline__ uint32_t lit_entry(uint32_t c) {
     uint32_t type = sym < 256u ? T_LIT : sym == 256u ? T_EOB : sym <= 285u ? T_LEN : T_BAD;
     uint32_t lbase = 0, leb = 0;
     if (type == T_LEN) length_info(sym - 257u, lbase, leb);
-    if (sym == 287u) nb = 0;                                 // the reference's zero leaf at index 483 (deflate.py:212)
+    // the reference's ONE zero leaf, index 483 of the DYNAMIC=False build's stat_leaves (deflate.py:212; zero_leaf = ASSUME_FIXED):
+    // symbol 287's other slot (227) is an ordinary leaf -- its code fails in INFLATE --, and so are both in a DYNAMIC=True build,
+    // which decodes fixed blocks through leaves built from the fixed lengths (deflate.py:1066-1073)
+    if (c == 483u && zero_leaf) nb = 0;
     return nb | (sym << 4) | (type << 13) | (lbase << 16) | (leb << 25);
 }
 __device__ __forceinline__ uint32_t dst_entry(uint32_t raw5) {

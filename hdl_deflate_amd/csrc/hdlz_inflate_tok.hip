@@ -173,7 +173,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     if constexpr (!DYN) {
-        for (uint32_t c = threadIdx.x; c < 512u; c += 64u * WAVES) lds.lit[c] = lit_entry(c);
+        for (uint32_t c = threadIdx.x; c < 512u; c += 64u * WAVES) lds.lit[c] = lit_entry(c, (a.flags & HDLZ_INFLATE_ASSUME_FIXED) != 0u);
         if (threadIdx.x < 32u) lds.dst[threadIdx.x] = dst_entry(threadIdx.x);
         __syncthreads();             // the only workgroup barrier: the waves are independent from here on
     }
@@ -281,7 +281,6 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     constexpr uint32_t NO_DCODE = 0xFFFFFFFEu, BAD_DCODE = 0xFFFFFFFFu;
     [[maybe_unused]] uint32_t XL[15], XD[15];       // DYN: the X words of this lane's literal/length and distance code
     [[maybe_unused]] S5 DS;                         // DYN: its distance symbols, sorted by (code length, value)
-    [[maybe_unused]] bool fixedblk = false;         // DYN: the current block is a fixed one (its symbol 287 is the reference's zero leaf)
     typedef Tab<CAP> T;
 #define TROW(j) lds.tab[(j) * 64u + lane]
 #define TBYTE(base, i) reinterpret_cast<uint8_t*>(lds.tab)[(((base) + ((i) >> 2)) << 8) | lane4 | ((i) & 3u)]
@@ -297,7 +296,9 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
             const uint32_t type = sym < 256u ? T_LIT : sym == 256u ? T_EOB : sym <= 285u ? T_LEN : T_BAD;
             uint32_t lbase, leb;
             length_info(sym - 257u, lbase, leb);
-            const uint32_t nb = (!valid || (fixedblk && sym == 287u)) ? 0u : len;     // deflate.py:212,:1437-1439
+            // (no zero leaf here: this kernel never runs the DYNAMIC=False build, and a DYNAMIC=True build decodes a fixed block
+            // through leaves built from the fixed lengths, where symbol 287 is an ordinary 8-bit leaf -- deflate.py:1066-1073)
+            const uint32_t nb = !valid ? 0u : len;
             return nb | (sym << 4) | (type << 13) | ((lbase & 0x1FFu) << 16) | ((leb & 7u) << 25);
         }
     };
@@ -676,7 +677,6 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                         if constexpr (DYN) {
                             const uint32_t tst = build_tables(hm);
                             if (tst != HDLZ_OK) { TOK_FAIL(tst); break; }
-                            fixedblk = hm == 1u;
                         }
                     }
                     continue;

@@ -8,7 +8,8 @@ oracle/gen_golden.py; the reference source is read by path, never copied): tests
   * lagging_reader  -- the same leg with a reader that takes a byte only every k-th iteration (k = 6, 12): the reference's compress
                        side has NO output hold (put / do_flush, deflate.py:535-567, write oram[do & OBS] unconditionally; only the
                        inflate side holds, deflate.py:1531-1534), so a reader that lags by more than OBSIZE reads overwritten bytes.
-Usage: python oracle/gen_golden_r3.py"""
+Usage: python oracle/gen_golden_r3.py            (streaming_r3_vectors.json)
+       python oracle/gen_golden_r3.py zero_leaf  (inflate_r3_vectors.json: symbols 286 / 287 of a fixed block in both builds)"""
 import json
 import os
 import sys
@@ -55,5 +56,54 @@ def main():
     print("done in %.0fs" % (time.time() - t0))
 
 
+def _fixed_stream(symbols_bits, tail=12):
+    """a zlib stream with ONE final fixed block made of the given (value, nbits, msb_first) fields, zero padding, `tail` more bytes"""
+    acc, n = 0, 0
+
+    def put(v, k, msb):
+        nonlocal acc, n
+        for i in range(k):
+            b = (v >> (k - 1 - i)) & 1 if msb else (v >> i) & 1
+            acc |= b << n
+            n += 1
+    put(1, 1, False); put(1, 2, False)                       # BFINAL = 1, BTYPE = 01
+    for v, k, msb in symbols_bits:
+        put(v, k, msb)
+    body = acc.to_bytes((n + 7) // 8, "little")
+    return b"\x78\x9c" + body + bytes(tail)
+
+
+def zero_leaf():
+    """tests/golden/inflate_r3_vectors.json: what the executed reference does with literal/length symbols 286 and 287 of a FIXED block
+    in its two builds.  stat_leaves (DYNAMIC=False) holds ONE zero leaf, index 483 = symbol 287's 8-bit code followed by a 1
+    (deflate.py:212, "< 1 bits" at :1437-1439); a DYNAMIC=True build decodes fixed blocks through leaves built from the fixed lengths.
+    Also the 17-byte stream the round-3 damaged-stream fuzz found (symbol 287 where the input ends: the end-of-input check of
+    deflate.py:1535-1539 comes first unless the leaf is the zero leaf) and its sibling with the ninth bit set."""
+    out = {"provenance": G.PROVENANCE, "reference": "deflate.py STARTD path, NEXT / INFLATE (deflate.py:1402-1445, :1519-1591)", "vectors": []}
+    lit_a = (0x30 + 0x61, 8, True)
+    cases = [("fuzz_sym287_ninth0_at_end", bytes.fromhex("78dabbe9f8acad9ef167c05b081a17053d"))]
+    z2 = bytearray(cases[0][1]); z2[14] ^= 8
+    cases.append(("fuzz_sym287_ninth1_at_end", bytes(z2)))
+    for sym, code in ((286, 0b11000110), (287, 0b11000111)):
+        for ninth in (0, 1):
+            cases.append(("lit_a_sym%d_ninth%d" % (sym, ninth), _fixed_stream([lit_a, (code, 8, True), (ninth, 1, False)])))
+    for name, z in cases:
+        for dyn in (False, True):
+            try:
+                res, err, cyc = G.ref_inflate(z, dynamic=dyn, obsize=512, max_cycles=60000)
+            except Exception as e:                      # not a myhdl.Error: the reference itself crashed (e.g. CopyLength[token >= 29])
+                res, err = None, "%s: %s" % (type(e).__name__, e)
+            out["vectors"].append({"build": "DYNAMIC=%s,OBSIZE=512" % dyn, "name": name, "z_hex": z.hex(),
+                                   "out_hex": res.hex() if res is not None else None, "error": err})
+            print("%-28s DYNAMIC=%-5s -> %r" % (name, dyn, err if err else res), flush=True)
+    tmp = os.path.join(G.GOLD, "inflate_r3_vectors.json.tmp")
+    with open(tmp, "w") as f:
+        json.dump(out, f, indent=0)
+    os.replace(tmp, os.path.join(G.GOLD, "inflate_r3_vectors.json"))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "zero_leaf":
+        zero_leaf()
+    else:
+        main()

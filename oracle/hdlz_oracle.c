@@ -425,6 +425,10 @@ int hdlz_oracle_inflate(const uint8_t* z, size_t zn, unsigned flags, uint32_t ob
             } else {
                 unsigned cto = get4(&r, 0, 9);            /* deflate.py:1411 */
                 unsigned leaf = stat_leaves[cto & 511];  /* :1417 */
+                /* the zero leaf (index 483 = symbol 287's code followed by a 1) exists in the DYNAMIC=False build's stat_leaves only:
+                 * a DYNAMIC=True build decodes a fixed block through leaves BUILT from the fixed lengths (deflate.py:1066-1073, then
+                 * HF1..SPREAD), where 287 is an ordinary 8-bit leaf -- executed reference: tests/golden/inflate_r3_vectors.json */
+                if ((cto & 511) == 483 && !(flags & HDLZ_INFLATE_ASSUME_FIXED)) leaf = (287u << 4) | 8u;
                 unsigned nbits = leaf & 15;
                 code = leaf >> 4;
                 if (nbits < 1) return HDLZ_E_BAD_SYMBOL; /* :1437-1439 */

@@ -449,6 +449,21 @@ def test_inflate_golden_vectors(engine):
                 assert st == 5 and out == b"", (v["name"], mapping)
 
 
+def test_inflate_symbols_286_287_of_a_fixed_block(engine, oracle):
+    """the executed reference's behaviour for symbols 286 / 287 of a fixed block in both builds (inflate_r3_vectors.json: the
+    DYNAMIC=False build's single zero leaf, the end-of-input check in front of the length-symbol check): every mapping equals
+    the oracle, which equals the recorded reference (tests/test_oracle_golden.py)"""
+    g = load_golden("inflate_r3_vectors.json")
+    for v in g["vectors"]:
+        flags = 1 if "DYNAMIC=False" in v["build"] else 0
+        z = bytes.fromhex(v["z_hex"])
+        rc, ref = oracle.inflate(z, flags=flags, obsize=512)
+        assert rc == (5 if "NO EOF" in v["error"] else 7)
+        for mapping in MAPPINGS:
+            st, out = engine.inflate_bytes(z, flags=flags | mapping, obsize=512)
+            assert st == rc and out == ref, (v["name"], v["build"], mapping, st, rc)
+
+
 def test_inflate_random_vs_oracle_and_zlib(engine, oracle):
     import torch
     r = random.Random(99)
@@ -552,7 +567,10 @@ def test_inflate_auto_mapping_second_pass(engine, oracle):
 def test_inflate_error_statuses(engine, oracle):
     cases = [b"\x78\x9c" + bytes([0x07]) + bytes(8),                                  # BTYPE 3
              zlib.compress(DYN_TEXT, 9),               # dynamic block
-             b"\x78\x9c\x03"]                                                          # short
+             b"\x78\x9c\x03",                                                         # short
+             # symbol 287 of a fixed block followed by a 0 bit (NOT the zero leaf stat_leaves[483]) right where the input ends: the
+             # end-of-input check comes first (found by the damaged-stream fuzz, round 3)
+             bytes.fromhex("78dabbe9f8acad9ef167c05b081a17053d")]
     for z in cases:
         for mapping in MAPPINGS:
             st, out = engine.inflate_bytes(z, flags=mapping)

@@ -149,6 +149,20 @@ def test_inflate_golden(oracle):
             assert rc == oracle.E_NO_EOF and out == b"", v["name"]
 
 
+def test_inflate_symbols_286_287_of_a_fixed_block(oracle):
+    """tests/golden/inflate_r3_vectors.json (oracle/gen_golden_r3.py zero_leaf, executed reference): the ONE zero leaf of the
+    DYNAMIC=False build (stat_leaves[483], deflate.py:212 -> "< 1 bits") against the ordinary leaves of symbols 286 / 287 -- their
+    code passes NEXT and fails in INFLATE behind the end-of-input check (the reference's CopyLength tuple has 29 entries: IndexError)"""
+    g = load_golden("inflate_r3_vectors.json")
+    assert len(g["vectors"]) >= 12
+    for v in g["vectors"]:
+        flags = oracle.INFLATE_ASSUME_FIXED if "DYNAMIC=False" in v["build"] else 0
+        rc, out = oracle.inflate(bytes.fromhex(v["z_hex"]), flags=flags, obsize=512)
+        want = oracle.E_NO_EOF if "NO EOF" in v["error"] else oracle.E_BAD_SYMBOL
+        assert "NO EOF" in v["error"] or "< 1 bits" in v["error"] or v["error"].startswith("IndexError")
+        assert rc == want and out == b"", (v["name"], v["build"], rc)
+
+
 def test_inflate_stock_zlib_streams(oracle):
     r = random.Random(11)
     for it in range(200):

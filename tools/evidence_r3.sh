@@ -17,6 +17,9 @@ bash tools/profile.sh ev_cfg5 --no-end-to-end --block-size 65536 --blocks 131072
 bash tools/profile.sh ev_cfg2 --no-end-to-end --data text --block-size 65536 --blocks 16384 --cwindow 64 > "$out/pmc_cfg2.txt" 2>&1
 bash tools/profile.sh ev_cw256 --no-end-to-end --data text --block-size 65536 --blocks 16384 --cwindow 256 > "$out/pmc_cw256.txt" 2>&1
 bash tools/profile_inflate.sh ev_inflate > "$out/pmc_inflate.txt" 2>&1
+bash tools/profile_inflate.sh ev_inflate_dyn --zlib-strategy default --streams 262144 > "$out/pmc_inflate_dyn.txt" 2>&1
+python tools/bench_inflate_mapping.py default > "$out/inflate_mapping.txt" 2>&1
+python tools/bench_inflate_mapping.py fixed >> "$out/inflate_mapping.txt" 2>&1
 # 3. the configs bench lines
 bash tools/run_configs.sh > "$out/configs_bench_lines.txt" 2>&1
 # 4. single-stream STARTD: sizes and the timelines of one 1 MiB and one 16 MiB call

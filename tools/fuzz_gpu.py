@@ -106,6 +106,27 @@ def main():
                     if hbs[k] != 0 or hbl[k] != lens[b] or hb[k, :lens[b]].tobytes() != flat[off[b]:off[b + 1]].tobytes():
                         print("ZLIB-INFLATE MISMATCH it=%d seed=%d k=%d n=%d status %d len %d" % (it, a.seed, k, lens[b], hbs[k], hbl[k]))
                         return 1
+                # the same streams damaged (one flipped bit, or cut short): status and bytes against the oracle, every mapping in turn
+                zd = []
+                for z in zs[:200]:
+                    zb_ = bytearray(z)
+                    if rng.random() < 0.7 and len(zb_) > 3:
+                        zb_[int(rng.integers(2, len(zb_)))] ^= 1 << int(rng.integers(0, 8))
+                    else:
+                        zb_ = zb_[:max(1, len(zb_) - int(rng.integers(1, 7)))]
+                    zd.append(bytes(zb_))
+                zoff = np.concatenate([[0], np.cumsum([len(z) for z in zd])]).astype(np.int64)
+                zflat = np.frombuffer(b"".join(zd) + bytes(64), dtype=np.uint8).copy()
+                fl_ = int(rng.choice([0, 2, 4, 34])) | (1 if rng.random() < 0.25 else 0)      # (now and then as the DYNAMIC=False build: every block decoded as fixed)
+                zb, zl, zst = eng.inflate_batch(torch.from_numpy(zflat).cuda(), in_off=torch.from_numpy(zoff).cuda(), out_pitch=cap, flags=fl_)
+                torch.cuda.synchronize()
+                hb, hbl, hbs = zb.cpu().numpy(), zl.cpu().numpy(), zst.cpu().numpy()
+                for k, z in enumerate(zd):
+                    rc, ref = O.inflate(z, flags=fl_ & 1, out_cap=cap)
+                    if hbs[k] != rc or hb[k, :hbl[k]].tobytes() != ref:
+                        print("DAMAGED-ZLIB-INFLATE MISMATCH it=%d seed=%d k=%d flags=%d status gpu/ref %d/%d len %d/%d z=%s" %
+                              (it, a.seed, k, fl_, hbs[k], rc, hbl[k], len(ref), z.hex() if len(z) < 400 else "(long)"))
+                        return 1
         # now and then: a fixed-pitch batch of a few LARGE blocks cut from the same data (hdlz_compress_streams: all tiles of
         # all blocks share the stream passes), every block against the oracle
         if it % 8 == 5 and total >= 200000 and (cw <= 64 or total <= 400000):

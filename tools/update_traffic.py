@@ -8,7 +8,8 @@ SPEC = [("pmc_cfg1.txt", "k_compress<1>|blocks=1048576|block=2048|data=families"
         ("pmc_cfg5.txt", "k_compress<1>|blocks=131072|block=65536|data=families", "k_compress<1, true, false>", "profiles/r03_cfg5_pmc_summary.txt"),
         ("pmc_cfg2.txt", "k_compress<2>|blocks=16384|block=65536|data=text", "k_compress<2, true, false>", "profiles/r03_cfg2_pmc_summary.txt"),
         ("pmc_cw256.txt", "k_compress<8>|blocks=16384|block=65536|data=text", "k_compress<8, true, false>", "profiles/r03_cw256_pmc_summary.txt"),
-        ("pmc_inflate.txt", "k_inflate_tok|streams=1048576|block=2048", "k_inflate_tok<false>", "profiles/r03_inflate_tok_pmc_summary.txt")]
+        ("pmc_inflate.txt", "k_inflate_tok|streams=1048576|block=2048", "k_inflate_tok<false", "profiles/r03_inflate_tok_pmc_summary.txt"),
+        ("pmc_inflate_dyn.txt", "k_inflate_tok|streams=262144|block=2048", "k_inflate_tok<true, 144", "profiles/r03_inflate_tokdyn_pmc_summary.txt")]
 tj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
 T = json.load(open(tj))
 for fn, key, kern, dest in SPEC:
@@ -17,8 +18,17 @@ for fn, key, kern, dest in SPEC:
         continue
     txt = open(p).read()
     def val(name):
-        m = re.search(r"%s\s+n=\d+ mean=([0-9.e+]+)" % name, txt)
-        return float(m.group(1)) if m else None
+        # the counter of the named kernel (the summaries list every kernel of the command per PMC pass); first match otherwise
+        cur, first = "", None
+        for ln in txt.splitlines():
+            if ln.lstrip().startswith("kernel "):
+                cur = ln
+            m = re.search(r"%s\s+n=\d+ mean=([0-9.e+]+)" % name, ln)
+            if m:
+                if kern.replace(" ", "") in cur.replace(" ", ""):
+                    return float(m.group(1))
+                first = first if first is not None else float(m.group(1))
+        return first
     f, w = val("FETCH_SIZE"), val("WRITE_SIZE")
     if f is None or w is None:
         print("no counters in", p)
