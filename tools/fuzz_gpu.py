@@ -80,6 +80,34 @@ def main():
                     return 1
             b0 = int(np.nonzero(okb)[0][0])
             assert zlib.decompress(ho[b0, :hl[b0]].tobytes()) == flat[off[b0]:off[b0 + 1]].tobytes()
+        # our own streams damaged (one flipped bit, a cut tail, or untouched), under the reference's build variants -- DYNAMIC=False
+        # (ASSUME_FIXED), ONEBLOCK, an OBSIZE build's history / LEN limits -- and every mapping: status and bytes against the oracle
+        if it % 3 == 1 and okb.any():
+            selb = np.nonzero(okb)[0][:300]
+            zd = []
+            for b in selb:
+                zb_ = bytearray(ho[b, :hl[b]].tobytes())
+                how_ = rng.random()
+                if how_ < 0.6 and len(zb_) > 3:
+                    zb_[int(rng.integers(2, len(zb_)))] ^= 1 << int(rng.integers(0, 8))
+                elif how_ < 0.85:
+                    zb_ = zb_[:max(1, len(zb_) - int(rng.integers(1, 7)))]
+                zd.append(bytes(zb_))
+            zoff = np.concatenate([[0], np.cumsum([len(z) for z in zd])]).astype(np.int64)
+            zflat = np.frombuffer(b"".join(zd) + bytes(64), dtype=np.uint8).copy()
+            fl_ = int(rng.choice([0, 2, 4, 34])) | int(rng.choice([0, 1, 8, 9]))
+            ob_ = int(rng.choice([0, 0, 512, 4096, 32768]))
+            capd = (int(lens[selb].max()) + 300 + 15) // 16 * 16
+            zb, zl, zst = eng.inflate_batch(torch.from_numpy(zflat).cuda(), in_off=torch.from_numpy(zoff).cuda(), out_pitch=capd, flags=fl_,
+                                            obsize=ob_)
+            torch.cuda.synchronize()
+            hb, hbl, hbs = zb.cpu().numpy(), zl.cpu().numpy(), zst.cpu().numpy()
+            for k, z in enumerate(zd):
+                rc, ref = O.inflate(z, flags=fl_ & 9, obsize=ob_, out_cap=capd)
+                if hbs[k] != rc or hb[k, :hbl[k]].tobytes() != ref:
+                    print("DAMAGED-OWN-INFLATE MISMATCH it=%d seed=%d k=%d flags=%d obsize=%d status gpu/ref %d/%d len %d/%d z=%s" %
+                          (it, a.seed, k, fl_, ob_, hbs[k], rc, hbl[k], len(ref), z.hex() if len(z) < 400 else "(long)"))
+                    return 1
         # the whole flat buffer once more as ONE stream through the multi-wave path (needs >= 5 bytes)
         if total >= 5 and (cw <= 64 or total <= 300000):
             so, sl, ss = eng.compress_stream(d_in[mis:], total, cwindow=cw, maxmatch=mm)
