@@ -527,6 +527,47 @@ def test_inflate_dynamic_streams_vs_oracle(engine, oracle):
             assert out[k, :ol[k]].tobytes() == ref, (k, mapping)
 
 
+def test_inflate_dynamic_two_stage_cases(engine, oracle):
+    """the lane mapping's second pass has two stages (k_inflate_tok<true, 144> / <true, 288>): streams that change sides in the
+    middle -- a small-alphabet dynamic block first and a 256-symbol one behind it, a fixed block in front of dynamic ones, a stored
+    block between them -- and a batch that mixes all of them with plain fixed streams; every stream against the oracle and zlib"""
+    import torch
+    r = random.Random(5)
+    wide = bytes(min(255, int(abs(r.gauss(0, 70)))) for _ in range(6000))      # ~200 distinct values, skewed: a dynamic block of > 144 symbols
+    assert len(set(wide)) > 150 and (zlib.compress(wide)[2] >> 1) & 3 == 2
+    narrow = bytes(r.choice(b"abcdef") for _ in range(6000))
+    rnd = bytes(r.getrandbits(8) for _ in range(3000))          # incompressible: zlib stores it
+    def stream(parts, level=6):
+        co = zlib.compressobj(level, zlib.DEFLATED, 15)
+        z = b""
+        for p_ in parts:
+            z += co.compress(p_) + co.flush(zlib.Z_FULL_FLUSH)
+        return z + co.flush()
+    cases = [stream([narrow, wide]), stream([wide, narrow]), stream([b"ab", narrow, wide]), stream([narrow, rnd, wide, narrow]),
+             stream([narrow]), stream([wide]), stream([b"x"]), stream([narrow[:100], wide[:300], narrow[:50]]),
+             zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED).compress(narrow) + b""]
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+    cases[-1] = co.compress(narrow) + co.flush()
+    btypes = set()
+    for z in cases:
+        btypes.add((z[2] >> 1) & 3)
+    assert btypes >= {1, 2}
+    sel = [cases[k % len(cases)] for k in range(640)]
+    flat = b"".join(sel) + bytes(64)
+    off = np.cumsum([0] + [len(z) for z in sel]).astype(np.int64)
+    d_in = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
+    cap = 18016
+    want = [oracle.inflate(z, out_cap=cap) for z in cases]
+    for z, (rc, ref) in zip(cases, want):
+        assert rc == 0 and ref == zlib.decompress(z)
+    for mapping in MAPPINGS:
+        out, ol, st = engine.inflate_batch(d_in, in_off=torch.from_numpy(off).cuda(), out_pitch=cap, flags=mapping)
+        out, ol, st = out.cpu().numpy(), ol.cpu().numpy(), st.cpu().numpy()
+        for k in range(len(sel)):
+            rc, ref = want[k % len(cases)]
+            assert st[k] == rc and out[k, :ol[k]].tobytes() == ref, (k, mapping, int(st[k]))
+
+
 def test_inflate_auto_mapping_second_pass(engine, oracle):
     """the DEFAULT mapping on batches above HDLZ_INFLATE_WAVE_THRESHOLD: pass 1 one lane per stream; the streams with
     dynamic-tree blocks are counted on the device and redone one lane each when they are at least

@@ -45,6 +45,8 @@ def main():
             data[noise] = rng.integers(0, 256, size=int(noise.sum()), dtype=np.uint8)
         elif kind == 2:   # runs
             data = np.repeat(rng.integers(0, 4, size=total // 3 + 1, dtype=np.uint8) + 65, 3)[:total].copy()
+        elif kind == 5:   # a wide, skewed alphabet: compressible with 100..250 distinct symbols (dynamic blocks of many codes)
+            data = np.minimum(255, np.abs(rng.normal(0, float(rng.choice([10, 40, 70, 120])), size=total))).astype(np.uint8)
         else:             # markov-ish text
             words = [bytes(rng.integers(97, 123, size=int(rng.integers(1, 9)), dtype=np.uint8)) for _ in range(50)]
             buf = b" ".join(words[int(i)] for i in rng.integers(0, 50, size=total // 3 + 2))
