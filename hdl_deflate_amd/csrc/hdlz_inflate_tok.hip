@@ -64,7 +64,10 @@ constexpr uint32_t MOVES = HDLZ_TOK_MOVES;    // move iterations (up to 8 bytes 
 // codes is in registers: the X words, the sorted distance symbols (30 x 5 bits), and during the build the code-length code and the
 // per-length counters.  CAP = 144 (41 rows = 10.25 KB, 19.3 KB per wave with ring and input slot: EIGHT waves per CU) holds the codes
 // of small blocks; a stream whose block codes more symbols stays flagged and goes through the CAP = 288 build (81 rows, 5 per CU).
-constexpr uint32_t CAP_SMALL = 144, CAP_FULL = 288;
+#ifndef HDLZ_TOK_CAP_SMALL
+#define HDLZ_TOK_CAP_SMALL 144
+#endif
+constexpr uint32_t CAP_SMALL = HDLZ_TOK_CAP_SMALL, CAP_FULL = 288;
 template <uint32_t CAP> struct Tab {
     static constexpr uint32_t LS8 = 0;                         // CAP bytes: the low 8 bits of the symbols
     static constexpr uint32_t LBIT = CAP / 4;                  // CAP bits: their ninth bit
@@ -165,8 +168,13 @@ __device__ __forceinline__ void x_decode(const uint32_t (&X)[NL], uint32_t bits,
     idx = (m & 511u) - ((m >> 16) >> (15u - len));
 }
 
+#ifdef HDLZ_TOK_WAVES                          // A/B builds: force an occupancy (waves per SIMD) on every instantiation
+#define HDLZ_TOK_ATTR __attribute__((amdgpu_waves_per_eu(HDLZ_TOK_WAVES, HDLZ_TOK_WAVES)))
+#else
+#define HDLZ_TOK_ATTR
+#endif
 template <bool DYN, uint32_t CAP>
-__global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, const uint32_t* __restrict__ list,
+__global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(InflateArgs a, const uint32_t* __restrict__ list,
                                                                 const uint32_t* __restrict__ list_n, uint32_t lane_min) {
     constexpr uint32_t WAVES = Lds<DYN, CAP>::WAVES;
     __shared__ Lds<DYN, CAP> lds;
