@@ -78,6 +78,11 @@ enum {
  * 32 = one output byte per lockstep iteration (k_inflate, the round-1 kernel) */
 #define HDLZ_INFLATE_TOKEN_ROUNDS 16u
 #define HDLZ_INFLATE_BYTE_LOCKSTEP 32u
+/* 64 = the two-phase form of the lane-per-stream mapping for SMALL streams (out_pitch <= 2048; results are identical): phase A
+ * decodes one lane per stream into a token list in stream-ordered scratch (out_pitch + 64 .. + 319 bytes per stream, + 8), phase B
+ * replays it with the stream's whole output in LDS -- no copy reads its history back from HBM (hdlz_inflate_two.hip).  Ignored
+ * when out_pitch is larger or the scratch cannot be had. */
+#define HDLZ_INFLATE_TWO_PHASE 64u
 
 int hdlz_version(void);
 const char* hdlz_status_string(int status);

@@ -605,6 +605,53 @@ def test_inflate_auto_mapping_second_pass(engine, oracle):
             assert out[k, :ol[k]].tobytes() == sel[k][2], (case, k)
 
 
+def test_inflate_two_phase_small_streams(engine, oracle):
+    """HDLZ_INFLATE_TWO_PHASE (hdlz_inflate_two.hip: phase A writes token records, phase B replays them with the stream's output in
+    LDS): stock-zlib streams of every strategy / level over small blocks, stored blocks, multi-block streams, runs (distance 1),
+    damaged and cut streams, capacities below the output size, token lists that overflow (incompressible blocks go back through
+    the one-pass kernel) -- status, length and bytes of EVERY stream equal the oracle, in both builds (DYNAMIC=False / True)"""
+    import torch
+    from hdl_deflate_amd import INFLATE_LANE_PER_STREAM, INFLATE_TWO_PHASE, INFLATE_ASSUME_FIXED
+    from hdl_deflate_amd.data import make_blocks
+    r = random.Random(11)
+    B = 2048
+    for rd, (pitch, n) in enumerate(((2048, 2048), (516, 556), (1024, 512), (64, 64), (2048, 1900))):
+        h = make_blocks(B, n, "cpu", seed=100 + rd, families=(1, 2, 3, 4)).numpy()
+        zs = []
+        for k in range(B):
+            blk = h[k].tobytes()[: r.choice((n, n, n, r.randrange(0, n + 1)))]
+            if r.random() < 0.1:
+                blk = bytes(r.getrandbits(8) for _ in range(len(blk)))
+            if r.random() < 0.05:
+                blk = bytes([r.getrandbits(8)]) * len(blk)
+            strat = r.choice((zlib.Z_FIXED, zlib.Z_FIXED, zlib.Z_FIXED, zlib.Z_DEFAULT_STRATEGY, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY))
+            c = zlib.compressobj(r.choice((0, 1, 6, 9)), zlib.DEFLATED, r.choice((9, 12, 15)), 9, strat)
+            z = (c.compress(blk[: len(blk) // 2]) + (c.flush(zlib.Z_FULL_FLUSH) if r.random() < 0.3 else b"") +
+                 c.compress(blk[len(blk) // 2:]) + c.flush())
+            q = r.random()
+            if q < 0.08 and len(z) > 8:
+                z = bytearray(z)
+                z[r.randrange(2, len(z))] ^= 1 << r.randrange(8)
+                z = bytes(z)
+            elif q < 0.14:
+                z = z[: r.randrange(0, len(z) + 1)]
+            zs.append(z)
+        lens = np.array([len(z) for z in zs], dtype=np.int64)
+        off = np.zeros(B + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        flat = np.frombuffer(b"".join(zs) + bytes(64), dtype=np.uint8).copy()
+        zin, zoff = torch.from_numpy(flat).cuda(), torch.from_numpy(off).cuda()
+        for fl in (0, INFLATE_ASSUME_FIXED):
+            ref, rl, rs = oracle.inflate_batch(flat, off.astype(np.uint64), pitch, flags=fl, nthreads=8)
+            out, ol, st = engine.inflate_batch(zin, in_off=zoff, out_pitch=pitch, flags=fl | INFLATE_LANE_PER_STREAM | INFLATE_TWO_PHASE)
+            torch.cuda.synchronize()
+            assert np.array_equal(st.cpu().numpy().astype(np.uint32), rs), (rd, fl)
+            assert np.array_equal(ol.cpu().numpy().astype(np.uint32), rl), (rd, fl)
+            m = np.arange(pitch)[None, :] < rl[:, None]
+            assert np.array_equal(out.cpu().numpy()[m], ref[m]), (rd, fl)
+            assert len(set(rs.tolist())) >= 3           # (the batch really holds good, cut and damaged streams)
+
+
 def test_inflate_error_statuses(engine, oracle):
     cases = [b"\x78\x9c" + bytes([0x07]) + bytes(8),                                  # BTYPE 3
              zlib.compress(DYN_TEXT, 9),               # dynamic block
