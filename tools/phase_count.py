@@ -25,7 +25,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "hdl_deflate_amd/csrc", srcname)
 asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-", src] + defs,
                      capture_output=True, text=True).stdout
-m = re.search(r"^(_ZN4hdlz\w*%s\w*):[^\n]*\n(.*?)s_endpgm" % re.escape(kern), asm, re.S | re.M)
+m = re.search(r"^(_ZN4hdlz\w*%s\w*):[^\n]*\n(.*?)^\.Lfunc_end" % re.escape(kern), asm, re.S | re.M)
 body = m.group(2)
 phase = "prologue"
 cnt = collections.OrderedDict()
