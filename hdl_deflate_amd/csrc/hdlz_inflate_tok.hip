@@ -48,16 +48,20 @@ constexpr uint32_t RING_DW = RINGB / 4;
 constexpr uint32_t NEAR = RINGB - 16;         // distances up to this are served from the ring: NEAR + 3 (dword alignment of the
                                               // source) + 12 (the unmasked write ahead of the end) < RINGB
 constexpr uint32_t CHUNK = RINGB >= 128u ? 64u : RINGB / 2u;   // bytes per flush
+#ifndef HDLZ_TOK_MOVES
+#define HDLZ_TOK_MOVES 3
+#endif
+#ifdef HDLZ_TOK_FLUSH_ROUND                   // A/B: ONE flush check per round, behind the move loop (see there)
+constexpr uint32_t URGENT = RINGB - 40u - 8u * (HDLZ_TOK_MOVES - 1u);   // the third chunk of a far copy (o - dist + 16 .. + 24) must be flushed
+#else                                         // in the LAST move iteration too: u + 8 (MOVES - 1) + 24 <= NEAR + 1
 constexpr uint32_t URGENT = RINGB - 44;       // a lane with this many unflushed bytes forces a flush (+3 per move, +8 written ahead,
                                               // and the far prefetch reads 24 bytes from o - dist on: they must be flushed)
+#endif
 constexpr uint32_t SLOT_DW = 4;               // input dwords fetched per lane and refill
 #ifndef HDLZ_TOK_BATCH
 #define HDLZ_TOK_BATCH 16
 #endif
 constexpr uint32_t BATCH = HDLZ_TOK_BATCH;    // lanes with a complete line that start a flush
-#ifndef HDLZ_TOK_MOVES
-#define HDLZ_TOK_MOVES 3
-#endif
 constexpr uint32_t MOVES = HDLZ_TOK_MOVES;    // move iterations (up to 8 bytes per lane each) per round; 2 / 3 / 4 / 6: 4.21 / 3.95 / 4.10 / 3.99 ms
 #ifdef HDLZ_TOK_MARKS                         // tools/phase_count.py --src hdlz_inflate_tok.hip -DHDLZ_TOK_MARKS: static counts per part
 #define TOK_MARK(name) asm volatile("; @@PHASE " name ::: "memory")
@@ -546,8 +550,15 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
                 const uint32_t nd = q1 >= 8u ? d2 : q1 >= 4u ? d1 : d0;
                 pend = nd & ((1u << ((q1 & 3u) * 8u)) - 1u);
             }
+#ifndef HDLZ_TOK_FLUSH_ROUND
             TOK_FLUSH();
+#endif
         }
+#ifdef HDLZ_TOK_FLUSH_ROUND
+        // the flush stores are issued where the refill and the decode follow, not another move iteration: hipcc waits vmcnt(0) in
+        // every move iteration (the far chunks are loop-carried loads), and on gfx9 that also waits for the stores of a flush
+        TOK_FLUSH();
+#endif
         TOK_MARK("refill");
         // ------------------------------------------------------------ 0b. input refill (a lane waits only when it opens a new slot)
         {
