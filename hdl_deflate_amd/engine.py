@@ -153,6 +153,97 @@ class Engine(object):
         self._check(rc, "hdlz_compact_batch")
         return archive, offsets
 
+    # -- the job from HOST buffers: the PCIe hops overlapped with the kernels
+    @_on_device
+    def compress_host(self, h_in, cwindow=32, maxmatch=10, chunk_blocks=None, h_archive=None, h_len=None):
+        """h_in: PINNED host uint8 [B, n].  Compresses every block on the GPU and returns (h_archive, h_len, total, status_bad):
+        the blocks' zlib streams back to back in pinned host memory (`h_archive[:total]`; block b at the exclusive scan of
+        `h_len`), their lengths, and the number of blocks whose status is not OK (0 unless n < 5 / the capacity is wrong).
+        The batch goes through the GPU in chunks of `chunk_blocks` blocks on three streams -- H2D of chunk k + 1, compress +
+        scan + hdlz_compact_batch of chunk k, D2H of chunk k - 1's ARCHIVE (not its pitched rows) -- so the job costs about
+        the slower PCIe direction instead of H2D + kernel + D2H.  One host sync per chunk (its archive size)."""
+        assert h_in.dtype == torch.uint8 and h_in.dim() == 2 and h_in.is_contiguous() and h_in.is_pinned()
+        B, n = h_in.shape
+        pitch = pitch_for(n)
+        if chunk_blocks is None:
+            chunk_blocks = max(1, min(B, max((32 << 20) // max(n, 1), (B + 15) // 16)))     # >= 32 MiB per chunk, <= 16 chunks
+        C = chunk_blocks
+        if h_archive is None:
+            h_archive = torch.empty(B * self.lib.hdlz_out_bound(n), dtype=torch.uint8, pin_memory=True)
+        if h_len is None:
+            h_len = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        assert h_archive.is_pinned() and h_len.is_pinned() and h_len.numel() == B
+        dev = self.device
+        cur = torch.cuda.current_stream()
+        # streams and staging buffers are kept between calls (a fresh stream has a fresh allocator pool: device mallocs in the job)
+        ctx = getattr(self, "_host_ctx", None)
+        if ctx is None or ctx["key"] != (C, n):
+            ctx = {"key": (C, n), "streams": [torch.cuda.Stream(dev) for _ in range(3)],
+                   "d_in": [torch.empty((C, n), dtype=torch.uint8, device=dev) for _ in range(2)],
+                   "d_arch": [torch.empty(C * pitch, dtype=torch.uint8, device=dev) for _ in range(2)],
+                   "d_len": [torch.empty(C, dtype=torch.int32, device=dev) for _ in range(2)],
+                   "d_rows": torch.empty((C, pitch), dtype=torch.uint8, device=dev),
+                   "d_tot": [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(2)]}     # archive bytes, failed blocks
+            self._host_ctx = ctx
+        s_in, s_k, s_out = ctx["streams"]
+        d_in, d_arch, d_len, d_rows, d_tot = ctx["d_in"], ctx["d_arch"], ctx["d_len"], ctx["d_rows"], ctx["d_tot"]
+        for st in (s_in, s_k, s_out):
+            st.wait_stream(cur)
+        ev_k = [None, None]        # compute of the chunk that last used buffer pair j
+        ev_out = [None, None]      # D2H of the chunk that last used buffer pair j
+        base, bad = 0, 0
+        pending = None             # (j, first block, blocks) of the chunk whose D2H is still to be issued
+
+        def drain(p):
+            nonlocal base, bad
+            j, b0, nb = p
+            ev_k[j].synchronize()
+            tot = d_tot[j].tolist()                       # (the two words were written before ev_k[j])
+            total, nbad = int(tot[0]), int(tot[1])
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_k[j])
+                h_archive[base:base + total].copy_(d_arch[j][:total], non_blocking=True)
+                h_len[b0:b0 + nb].copy_(d_len[j][:nb], non_blocking=True)
+                ev_out[j] = torch.cuda.Event()
+                ev_out[j].record(s_out)
+            base += total
+            bad += nbad
+
+        k = 0
+        for b0 in range(0, B, C):
+            nb = min(C, B - b0)
+            j = k & 1
+            with torch.cuda.stream(s_in):
+                if ev_k[j] is not None:
+                    s_in.wait_event(ev_k[j])              # the compress that read d_in[j] two chunks ago
+                d_in[j][:nb].copy_(h_in[b0:b0 + nb], non_blocking=True)
+                ev_in = torch.cuda.Event()
+                ev_in.record(s_in)
+            with torch.cuda.stream(s_k):
+                s_k.wait_event(ev_in)
+                if ev_out[j] is not None:
+                    s_k.wait_event(ev_out[j])             # the D2H that read d_arch[j] / d_len[j] two chunks ago
+                _, ol, st = self.compress_batch(d_in[j][:nb], cwindow=cwindow, maxmatch=maxmatch, out=d_rows[:nb], out_pitch=pitch)
+                l64 = ol.to(torch.int64)
+                off = torch.cumsum(l64, 0) - l64
+                self.compact(d_rows[:nb], ol, offsets=off, archive=d_arch[j])
+                d_len[j][:nb].copy_(ol)
+                d_tot[j][0] = l64.sum()
+                d_tot[j][1] = (st != 0).sum()
+                ev_k[j] = torch.cuda.Event()
+                ev_k[j].record(s_k)
+            if pending is not None:
+                drain(pending)                            # chunk k - 1: its size is known now, its D2H runs beside chunk k's kernels
+            pending = (j, b0, nb)
+            k += 1
+        if pending is not None:
+            drain(pending)
+        cur.wait_stream(s_out)
+        cur.wait_stream(s_k)
+        cur.wait_stream(s_in)
+        s_out.synchronize()
+        return h_archive, h_len, base, bad
+
     # -- streaming sessions (hdlz_compress_chunk / hdlz_inflate_chunk): the port adapter's streaming mode
     def compress_session(self, cwindow=32, maxmatch=10):
         return CompressSession(self, cwindow, maxmatch)

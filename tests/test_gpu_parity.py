@@ -436,6 +436,38 @@ def test_compress_full_size_cfg2_properties(engine, oracle):
     assert 0.45 < ratio < 0.75          # expected ~0.59 for the 4-family mix
 
 
+def test_compress_host_pipelined_archive(engine, oracle):
+    """Engine.compress_host (pinned host batch -> chunks on three streams -> one host archive + lengths): every block's slice of the
+    archive equals the oracle's stream, for chunk sizes that divide the batch, do not divide it, and exceed it; n < 5 is counted"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    B, n = 1500, 700
+    d = make_blocks(B, n, "cuda", seed=21)
+    h_in = torch.empty((B, n), dtype=torch.uint8, pin_memory=True)
+    h_in.copy_(d)
+    torch.cuda.synchronize()
+    host = h_in.numpy()
+    ref = [oracle.compress(host[b].tobytes())[1] for b in range(B)]
+    for chunk in (500, 448, 4096, None):
+        h_arch, h_len, total, bad = engine.compress_host(h_in, chunk_blocks=chunk)
+        assert bad == 0 and total == sum(len(z) for z in ref)
+        hl = h_len.numpy().astype(np.int64)
+        off = hl.cumsum() - hl
+        arch = h_arch[:total].numpy().tobytes()
+        for b in range(B):
+            assert arch[off[b]:off[b] + hl[b]] == ref[b], (chunk, b)
+    # the reference's CWINDOW = 256 build through the same path
+    h_arch, h_len, total, bad = engine.compress_host(h_in[:300].contiguous().pin_memory(), cwindow=256, chunk_blocks=128)
+    hl = h_len.numpy().astype(np.int64)
+    off = hl.cumsum() - hl
+    arch = h_arch[:total].numpy().tobytes()
+    for b in range(0, 300, 7):
+        assert arch[off[b]:off[b] + hl[b]] == oracle.compress(host[b].tobytes(), cwindow=256)[1], b
+    h4 = torch.zeros((8, 4), dtype=torch.uint8).pin_memory()
+    _, _, total, bad = engine.compress_host(h4)
+    assert bad == 8 and total == 0
+
+
 def test_inflate_golden_vectors(engine):
     g = load_golden("inflate_vectors.json")
     for v in g["vectors"]:
