@@ -183,6 +183,7 @@ def end_to_end(torch, eng, d_in, r, cwindow, maxmatch, reps=5):
         torch.cuda.synchronize()
         pipe.append((time.perf_counter() - t0) * 1e3)
     pipe = pipe[1:]
+    eng._host_ctx = None                                            # (the staging buffers of compress_host: not needed by the entries that follow)
     assert bad == 0 and total == r["out_bytes"] and int(h_len.to(torch.int64).sum().item()) == total
     hl = h_len.numpy().astype("int64")
     hoff = hl.cumsum() - hl
@@ -537,6 +538,32 @@ def bench_inflate(a, eng=None, cpu=True, streams=None, strategy=None):
            "roofline": roofline(("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok<false>") +
                                 ("" if fixed else " + k_inflate_dyn" if a.inflate_kernel == "byte" else " + k_inflate_tok<true>"), algo, k_ms,
                                 "%s|streams=%d|block=%d" % ("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok", B, n))}
+    if fixed and a.end_to_end:
+        # SURVEY 8(d) "Timing" for STARTD: the job from pinned HOST buffers (streams in, rows out), the three steps one after the other;
+        # PCIe-bound, never `value`
+        h_z = torch.empty(flat.size, dtype=torch.uint8, pin_memory=True)
+        h_z.copy_(torch.from_numpy(flat.copy()))
+        h_rows = torch.empty((B, n), dtype=torch.uint8, pin_memory=True)
+        h_l = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        h_s = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        d_stage = torch.empty_like(d_in)
+        seq = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d_stage.copy_(h_z, non_blocking=True)
+            _, ol2, st2 = eng.inflate_batch(d_stage, in_off=d_off, out_pitch=n, flags=flags, out=d_out)
+            h_rows.copy_(d_out, non_blocking=True)
+            h_l.copy_(ol2, non_blocking=True)
+            h_s.copy_(st2, non_blocking=True)
+            torch.cuda.synchronize()
+            seq.append((time.perf_counter() - t0) * 1e3)
+        assert int((h_s != 0).sum().item()) == 0 and int((h_l != n).sum().item()) == 0 and torch.equal(h_rows, d_plain.cpu()), "host rows differ"
+        seq = seq[1:]
+        res["end_to_end"] = {"ms_median": round(median(seq), 3), "output_MBps": round(u_bytes / median(seq) / 1e3, 1),
+                             "note": "pinned host buffers: H2D of the streams + offsets, hdlz_inflate_batch, D2H of the rows, lengths and statuses, one after the other on the launch stream; "
+                                     "every row compared with its original block"}
+        del h_z, h_rows, d_stage
     if not fixed:
         # the same streams one WAVE each (k_inflate_dyn: what small batches and sessions run), half of them: the mapping's own figure
         Bw = max(1, B // 2)

@@ -244,6 +244,97 @@ class Engine(object):
         s_out.synchronize()
         return h_archive, h_len, base, bad
 
+    @_on_device
+    def inflate_host(self, h_z, h_off, out_pitch, flags=0, obsize=0, chunk_streams=None, h_out=None, h_len=None, h_status=None):
+        """STARTD for a batch held in HOST memory: h_z PINNED flat uint8 (the zlib streams back to back), h_off int64 [B + 1] on the
+        host (ascending; stream b = h_z[h_off[b]:h_off[b + 1]]).  Returns pinned (h_out uint8 [B, out_pitch], h_len int32 [B],
+        h_status int32 [B]).  Chunks of `chunk_streams` streams on three streams: H2D of chunk k + 1, hdlz_inflate_batch of chunk k,
+        D2H of chunk k - 1's rows.  Measured (round 3): when the pipeline runs freely it reaches the D2H floor (0.5 GiB of rows in
+        12.5 ms against 18 ms for the three steps one after the other), but in about every second call one of the torch copy calls
+        blocks the host for ~80 ms (ROCm 7.2 runs these copies as blit kernels; the cause was not found) -- compress_host, the same structure with
+        one sync read per chunk, does not show it.  Results are identical either way (tests/test_gpu_parity.py)."""
+        assert h_z.dtype == torch.uint8 and h_z.dim() == 1 and h_z.is_pinned() and out_pitch % 4 == 0
+        h_off = torch.as_tensor(h_off, dtype=torch.int64)
+        assert not h_off.is_cuda and h_off.dim() == 1 and h_off.numel() >= 1
+        B = h_off.numel() - 1
+        if h_out is None:
+            h_out = torch.empty((B, out_pitch), dtype=torch.uint8, pin_memory=True)
+        if h_len is None:
+            h_len = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        if h_status is None:
+            h_status = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        assert h_out.is_pinned() and h_len.is_pinned() and h_status.is_pinned() and tuple(h_out.shape) == (B, out_pitch)
+        if B == 0:
+            return h_out, h_len, h_status
+        if chunk_streams is None:
+            chunk_streams = max(1, min(B, max((32 << 20) // max(out_pitch, 1), (B + 15) // 16)))
+        C = chunk_streams
+        zmax = max(int(h_off[min(b0 + C, B)] - h_off[b0]) for b0 in range(0, B, C))      # compressed bytes of the largest chunk
+        dev = self.device
+        cur = torch.cuda.current_stream()
+        ctx = getattr(self, "_ihost_ctx", None)
+        if ctx is None or ctx["key"] != (C, out_pitch) or ctx["zcap"] < zmax:
+            ctx = {"key": (C, out_pitch), "zcap": zmax, "streams": [torch.cuda.Stream(dev) for _ in range(3)],
+                   "d_z": [torch.zeros(zmax + 1024, dtype=torch.uint8, device=dev) for _ in range(2)],
+                   "d_len": [torch.empty((2, C), dtype=torch.int32, device=dev) for _ in range(2)],
+                   "d_off": [torch.empty(C + 1, dtype=torch.int64, device=dev) for _ in range(2)],
+                   "h_off": [torch.empty(C + 1, dtype=torch.int64, pin_memory=True) for _ in range(2)],
+                   "d_out": [torch.empty((C, out_pitch), dtype=torch.uint8, device=dev) for _ in range(2)]}
+            self._ihost_ctx = ctx
+        s_in, s_k, s_out = ctx["streams"]
+        for st in (s_in, s_k, s_out):
+            st.wait_stream(cur)
+        ev_in_done = [None, None]          # H2D of the chunk that last used staging pair j (its pinned offsets may be rewritten after it)
+        ev_k = [None, None]
+        ev_out = [None, None]
+        pending = None
+
+        def drain(p):
+            j, b0, nb = p
+            ev_k[j].synchronize()
+            with torch.cuda.stream(s_out):
+                h_out[b0:b0 + nb].copy_(ctx["d_out"][j][:nb], non_blocking=True)
+                h_len[b0:b0 + nb].copy_(ctx["d_len"][j][0, :nb], non_blocking=True)
+                h_status[b0:b0 + nb].copy_(ctx["d_len"][j][1, :nb], non_blocking=True)
+                ev_out[j] = torch.cuda.Event()
+                ev_out[j].record(s_out)
+
+        for k, b0 in enumerate(range(0, B, C)):
+            nb = min(C, B - b0)
+            j = k & 1
+            z0, z1 = int(h_off[b0]), int(h_off[b0 + nb])
+            za = z0 & ~255                                 # (the copy starts at an aligned host address)
+            zb = min((z1 + 255) & ~255, h_z.numel())
+            if ev_in_done[j] is not None:
+                ev_in_done[j].synchronize()                # (two chunks back: long done)
+            torch.sub(h_off[b0:b0 + nb + 1], za, out=ctx["h_off"][j][:nb + 1])
+            with torch.cuda.stream(s_in):
+                if ev_k[j] is not None:
+                    s_in.wait_event(ev_k[j])
+                ctx["d_z"][j][:zb - za].copy_(h_z[za:zb], non_blocking=True)
+                ctx["d_off"][j][:nb + 1].copy_(ctx["h_off"][j][:nb + 1], non_blocking=True)
+                ev_in_done[j] = torch.cuda.Event()
+                ev_in_done[j].record(s_in)
+            with torch.cuda.stream(s_k):
+                s_k.wait_event(ev_in_done[j])
+                if ev_out[j] is not None:
+                    s_k.wait_event(ev_out[j])
+                _, ol, st = self.inflate_batch(ctx["d_z"][j], in_off=ctx["d_off"][j][:nb + 1], out_pitch=out_pitch, flags=flags,
+                                               obsize=obsize, out=ctx["d_out"][j][:nb])
+                ctx["d_len"][j][0, :nb].copy_(ol)
+                ctx["d_len"][j][1, :nb].copy_(st)
+                ev_k[j] = torch.cuda.Event()
+                ev_k[j].record(s_k)
+            if pending is not None:
+                drain(pending)                             # chunk k - 1's D2H is issued once its kernels are done (as in compress_host)
+            pending = (j, b0, nb)
+        if pending is not None:
+            drain(pending)
+        for st_ in (s_out, s_k, s_in):
+            cur.wait_stream(st_)
+        s_out.synchronize()
+        return h_out, h_len, h_status
+
     # -- streaming sessions (hdlz_compress_chunk / hdlz_inflate_chunk): the port adapter's streaming mode
     def compress_session(self, cwindow=32, maxmatch=10):
         return CompressSession(self, cwindow, maxmatch)

@@ -468,6 +468,41 @@ def test_compress_host_pipelined_archive(engine, oracle):
     assert bad == 8 and total == 0
 
 
+def test_inflate_host_pipelined(engine, oracle):
+    """Engine.inflate_host (pinned host streams + offsets -> chunks on three streams -> pinned rows, lengths, statuses): good, cut and
+    damaged stock-zlib streams of both strategies, chunk sizes that divide the batch, do not, and exceed it -- all against the oracle"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    r = random.Random(5)
+    B, n = 3000, 600
+    h = make_blocks(B, n, "cpu", seed=33, families=(1, 2, 4)).numpy()
+    zs = []
+    for k in range(B):
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED if k % 3 else zlib.Z_DEFAULT_STRATEGY)
+        z = c.compress(h[k].tobytes()) + c.flush()
+        q = r.random()
+        if q < 0.05:
+            z = bytearray(z)
+            z[r.randrange(2, len(z))] ^= 1 << r.randrange(8)
+            z = bytes(z)
+        elif q < 0.1:
+            z = z[: r.randrange(0, len(z))]
+        zs.append(z)
+    off = np.zeros(B + 1, np.int64)
+    np.cumsum([len(z) for z in zs], out=off[1:])
+    flat = np.frombuffer(b"".join(zs) + bytes(64), dtype=np.uint8).copy()
+    h_z = torch.from_numpy(flat).pin_memory()
+    pitch = 608
+    ref, rl, rs = oracle.inflate_batch(flat, off.astype(np.uint64), pitch, flags=0, nthreads=8)
+    m = np.arange(pitch)[None, :] < rl[:, None]
+    for chunk in (1000, 896, 5000, None):
+        h_out, h_len, h_st = engine.inflate_host(h_z, torch.from_numpy(off), pitch, chunk_streams=chunk)
+        assert np.array_equal(h_st.numpy().astype(np.uint32), rs), chunk
+        assert np.array_equal(h_len.numpy().astype(np.uint32), rl), chunk
+        assert np.array_equal(h_out.numpy()[m], ref[m]), chunk
+    assert len(set(rs.tolist())) >= 2
+
+
 def test_inflate_golden_vectors(engine):
     g = load_golden("inflate_vectors.json")
     for v in g["vectors"]:
