@@ -250,9 +250,10 @@ class Engine(object):
         host (ascending; stream b = h_z[h_off[b]:h_off[b + 1]]).  Returns pinned (h_out uint8 [B, out_pitch], h_len int32 [B],
         h_status int32 [B]).  Chunks of `chunk_streams` streams on three streams: H2D of chunk k + 1, hdlz_inflate_batch of chunk k,
         D2H of chunk k - 1's rows.  Measured (round 3): when the pipeline runs freely it reaches the D2H floor (0.5 GiB of rows in
-        12.5 ms against 18 ms for the three steps one after the other), but in about every second call one of the torch copy calls
-        blocks the host for ~80 ms (ROCm 7.2 runs these copies as blit kernels; the cause was not found) -- compress_host, the same structure with
-        one sync read per chunk, does not show it.  Results are identical either way (tests/test_gpu_parity.py)."""
+        12.5 ms against 18 ms for the three steps one after the other), but every second call the host is blocked for
+        ~77 ms inside the torch copy calls -- 0.5 GiB at the rate of a CPU memcpy, as if the rows went through a staging buffer; it
+        also happens with all three roles on ONE stream, without the small copies, with fresh pinned offset buffers (ROCm 7.2 /
+        torch 2.10; cause not found).  compress_host, the same structure, does not show it.  Results are identical either way (tests/test_gpu_parity.py)."""
         assert h_z.dtype == torch.uint8 and h_z.dim() == 1 and h_z.is_pinned() and out_pitch % 4 == 0
         h_off = torch.as_tensor(h_off, dtype=torch.int64)
         assert not h_off.is_cuda and h_off.dim() == 1 and h_off.numel() >= 1
