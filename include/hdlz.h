@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HDLZ_VERSION 0x000300   /* round 3: same entry points; CWINDOW > 64 through the window-independent match finder, own scratch pool, HDLZ_E_OUT_CAPACITY from hdlz_inflate_chunk */
+#define HDLZ_VERSION 0x000301   /* round 3: same entry points; CWINDOW > 64 through the window-independent match finder, own scratch pool, HDLZ_E_OUT_CAPACITY from hdlz_inflate_chunk; 0x000301: HDLZ_INFLATE_TWO_PHASE */
 
 /* command codes of the reference port surface (deflate.py:18) -- used by the adapter */
 enum { HDLZ_IDLE = 0, HDLZ_WRITE = 1, HDLZ_READ = 2, HDLZ_STARTC = 3, HDLZ_STARTD = 4 };
