@@ -401,17 +401,6 @@ def main_sharded(a):
     eng = hdl_deflate_amd.Engine(dev)
     total, n = a.cfg5_blocks, CFG5_BLOCK
     pitch = pitch_for(n)
-    # T(1): the WHOLE job on rank 0's GPU first (the other ranks wait at the barrier), so that the line carries its own
-    # single-GPU reference -- same blocks, same kernel, same process; the driver computes efficiency from its own N = 1 run
-    t1 = None
-    if a.t1:
-        if rank == 0:
-            d1 = make_blocks(total, n, dev, seed=0)
-            r1 = run_compress(torch, eng, d1, 32, 10, a.steps, a.warmup, 0)
-            t1 = {"ms": r1["dt"] / a.steps * 1e3, "out_bytes": r1["out_bytes"], "k_ms": r1["k_ms"]}
-            del r1, d1
-            torch.cuda.empty_cache()
-        dist.barrier()
     b0, b1 = shard_range(total, rank, world)               # contiguous shard of the job
     B = b1 - b0
     d_in = make_blocks(B, n, dev, seed=0, first_block=b0)  # exactly the blocks the 1-GPU run holds at [b0, b1) (any world size)
@@ -426,6 +415,18 @@ def main_sharded(a):
     dt, (ol, st, all_len) = time_steps(torch, dist, step, a.steps, a.warmup, world, cdev)
     k_ms = kernel_ms(torch, lambda: eng.compress_batch(d_in, cwindow=32, maxmatch=10, out=d_out, out_pitch=pitch), max(10, a.steps))
     g_ms = kernel_ms(torch, lambda: lg.gather(ol), max(10, a.steps)) if backend == "nccl" else [0.0]
+    # T(1): the WHOLE job on rank 0's GPU (the other ranks wait at the barrier), so that the line carries its own single-GPU
+    # reference -- same blocks, same kernel, same process; the driver computes efficiency from its own N = 1 run.  AFTER the timed
+    # shards: an 18 GiB allocation that came and went before them was seen to cost a later launch up to 10 % (placement of the buffers)
+    t1 = None
+    if a.t1:
+        if rank == 0:
+            d1 = make_blocks(total, n, dev, seed=0)
+            r1 = run_compress(torch, eng, d1, 32, 10, a.steps, a.warmup, 0)
+            t1 = {"ms": r1["dt"] / a.steps * 1e3, "out_bytes": r1["out_bytes"], "k_ms": r1["k_ms"]}
+            del r1, d1
+            torch.cuda.empty_cache()
+        dist.barrier()
 
     tot = torch.tensor([int(ol.to(torch.int64).sum().item()), B * n, int((st != 0).sum().item())], dtype=torch.int64, device=cdev)
     dist.all_reduce(tot)
