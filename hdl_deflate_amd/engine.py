@@ -249,11 +249,10 @@ class Engine(object):
         """STARTD for a batch held in HOST memory: h_z PINNED flat uint8 (the zlib streams back to back), h_off int64 [B + 1] on the
         host (ascending; stream b = h_z[h_off[b]:h_off[b + 1]]).  Returns pinned (h_out uint8 [B, out_pitch], h_len int32 [B],
         h_status int32 [B]).  Chunks of `chunk_streams` streams on three streams: H2D of chunk k + 1, hdlz_inflate_batch of chunk k,
-        D2H of chunk k - 1's rows.  Measured (round 3): when the pipeline runs freely it reaches the D2H floor (0.5 GiB of rows in
-        12.5 ms against 18 ms for the three steps one after the other), but every second call the host is blocked for
-        ~77 ms inside the torch copy calls -- 0.5 GiB at the rate of a CPU memcpy, as if the rows went through a staging buffer; it
-        also happens with all three roles on ONE stream, without the small copies, with fresh pinned offset buffers (ROCm 7.2 /
-        torch 2.10; cause not found).  compress_host, the same structure, does not show it.  Results are identical either way (tests/test_gpu_parity.py)."""
+        D2H of chunk k - 1's rows.  The job is bound by the D2H of the rows (ROCm 7.2 runs it as a blit kernel beside the inflate
+        kernel): 0.5 GiB of rows in 13.0 ms, what the three steps take one after the other -- the overlap buys nothing here, unlike
+        compress_host.  Chunks stay below 64 MiB of rows: with larger D2H copies hipMemcpyAsync (torch's copy_ or the raw call)
+        was seen to block the host for ~77 ms in every second call."""
         assert h_z.dtype == torch.uint8 and h_z.dim() == 1 and h_z.is_pinned() and out_pitch % 4 == 0
         h_off = torch.as_tensor(h_off, dtype=torch.int64)
         assert not h_off.is_cuda and h_off.dim() == 1 and h_off.numel() >= 1
@@ -268,7 +267,7 @@ class Engine(object):
         if B == 0:
             return h_out, h_len, h_status
         if chunk_streams is None:
-            chunk_streams = max(1, min(B, max((32 << 20) // max(out_pitch, 1), (B + 15) // 16)))
+            chunk_streams = max(1, min(B, (48 << 20) // max(out_pitch, 1)))
         C = chunk_streams
         zmax = max(int(h_off[min(b0 + C, B)] - h_off[b0]) for b0 in range(0, B, C))      # compressed bytes of the largest chunk
         dev = self.device
