@@ -456,6 +456,13 @@ def test_compress_host_pipelined_archive(engine, oracle):
         arch = h_arch[:total].numpy().tobytes()
         for b in range(B):
             assert arch[off[b]:off[b] + hl[b]] == ref[b], (chunk, b)
+    # ... and back: the host archive + the scan of its lengths is what inflate_host takes
+    offs = np.zeros(B + 1, np.int64)
+    np.cumsum(hl, out=offs[1:])
+    h_z = torch.empty(total + 64, dtype=torch.uint8).pin_memory()
+    h_z[:total].copy_(h_arch[:total])
+    rows, rl, rs = engine.inflate_host(h_z, torch.from_numpy(offs), 704, flags=1, chunk_streams=640)
+    assert int((rs != 0).sum()) == 0 and int((rl != n).sum()) == 0 and torch.equal(rows[:, :n], h_in)
     # the reference's CWINDOW = 256 build through the same path
     h_arch, h_len, total, bad = engine.compress_host(h_in[:300].contiguous().pin_memory(), cwindow=256, chunk_blocks=128)
     hl = h_len.numpy().astype(np.int64)
