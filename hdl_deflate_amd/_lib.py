@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("HDLZ_LIB") or os.path.join(_HERE, "lib", "libhdlz.so"
 EXPORTS = ("hdlz_version", "hdlz_status_string", "hdlz_last_error", "hdlz_device_count", "hdlz_out_bound",
            "hdlz_compress_batch", "hdlz_inflate_batch", "hdlz_compact_batch",
            "hdlz_stream_work_bytes", "hdlz_compress_stream", "hdlz_streams_work_bytes", "hdlz_compress_streams",
-           "hdlz_compress_chunk", "hdlz_inflate_chunk")
+           "hdlz_compress_chunk", "hdlz_inflate_chunk", "hdlz_release_scratch")
 _lib = None
 
 
@@ -50,5 +50,6 @@ def load():
     L.hdlz_compress_chunk.argtypes = [vp, u32, u32, ci, ci, ci, vp, u64, vp, vp]
     L.hdlz_inflate_chunk.restype = ci
     L.hdlz_inflate_chunk.argtypes = [vp, u32, ci, u32, u32, vp, u64, u32, vp, vp]
+    L.hdlz_release_scratch.restype = ci
     _lib = L
     return L

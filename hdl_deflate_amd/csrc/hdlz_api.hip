@@ -43,15 +43,21 @@ hipError_t zero_words(uint32_t* p, uint32_t n, hipStream_t stream) {
     hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, p, n);
     return hipGetLastError();
 }
+// The library's own per-device pool for stream-ordered scratch.  Release threshold: SCRATCH_KEEP bytes stay cached between calls (the
+// per-call lists of a 2^20-stream batch are 4 MB, the markers of a 16 MiB port stream 128 MB: neither pays a device allocation per
+// call); anything above it goes back to the device at the next synchronisation point of the stream, so one 256 MiB single-stream
+// inflate (2 GiB of markers) does not keep 2 GiB of HBM away from the caller's own allocator for the life of the process.
+// hdlz_release_scratch() trims the rest.
+constexpr uint64_t SCRATCH_KEEP = 256ull << 20;
+static hipMemPool_t g_pools[64] = {nullptr};
+static bool g_pool_tried[64] = {false};
+static std::mutex g_pool_mu;                             // (callers may drive several streams / devices from several threads)
 hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t stream) {
-    static hipMemPool_t pools[64] = {nullptr};
-    static bool tried[64] = {false};
-    static std::mutex mu;                                // (callers may drive several streams / devices from several threads)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
-    std::lock_guard<std::mutex> lock(mu);
-    if (dev >= 0 && dev < 64 && !tried[dev]) {
-        tried[dev] = true;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (dev >= 0 && dev < 64 && !g_pool_tried[dev]) {
+        g_pool_tried[dev] = true;
         hipMemPoolProps props;
         memset(&props, 0, sizeof(props));
         props.allocType = hipMemAllocationTypePinned;
@@ -60,18 +66,25 @@ hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t stream) {
         props.location.id = dev;
         hipMemPool_t pool = nullptr;
         if (hipMemPoolCreate(&pool, &props) == hipSuccess) {
-            uint64_t keep = ~0ull;
-            if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) pools[dev] = pool;
+            uint64_t keep = SCRATCH_KEEP;
+            if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) g_pools[dev] = pool;
             else (void)hipMemPoolDestroy(pool);
         }
         (void)hipGetLastError();
     }
-    if (dev >= 0 && dev < 64 && pools[dev]) {
-        const hipError_t e = hipMallocFromPoolAsync(p, bytes, pools[dev], stream);
+    if (dev >= 0 && dev < 64 && g_pools[dev]) {
+        const hipError_t e = hipMallocFromPoolAsync(p, bytes, g_pools[dev], stream);
         if (e == hipSuccess) return e;
         (void)hipGetLastError();
     }
     return hipMallocAsync(p, bytes, stream);
+}
+hipError_t scratch_release() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (dev >= 0 && dev < 64 && g_pools[dev]) return hipMemPoolTrimTo(g_pools[dev], 0);
+    return hipSuccess;
 }
 }  // namespace hdlz
 
@@ -110,6 +123,14 @@ int hdlz_device_count(void) {
 }
 
 size_t hdlz_out_bound(size_t n) { return 6 + (9 * n + 10 + 7) / 8; }
+
+int hdlz_release_scratch(void) {
+    int rc = check_device();
+    if (rc != HDLZ_OK) return rc;
+    const hipError_t e = hdlz::scratch_release();
+    if (e != hipSuccess) return fail_hip(e, "hipMemPoolTrimTo");
+    return HDLZ_OK;
+}
 
 int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
                         uint64_t nblocks, int cwindow, int maxmatch, uint8_t* d_out, uint64_t out_pitch,

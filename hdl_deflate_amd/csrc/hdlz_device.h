@@ -71,9 +71,11 @@ hipError_t launch_compress_chunk(const uint8_t* in, uint32_t n, uint32_t q_end, 
                                  uint64_t out_cap, void* state, hipStream_t stream);
 hipError_t launch_inflate_chunk(const uint8_t* in, uint32_t in_len, int final_, uint32_t flags, uint32_t obsize, uint8_t* out,
                                 uint64_t out_cap, uint32_t out_limit, void* state, hipStream_t stream);
-// stream-ordered scratch memory from the library's OWN per-device memory pool (release threshold: keep -- with the default
-// pool's threshold of 0 every call paid a fresh device allocation: 10..40 ms for the 8 MB of a 1 MiB single-stream inflate)
+// stream-ordered scratch memory from the library's OWN per-device memory pool (release threshold 256 MiB -- with the default
+// pool's threshold of 0 every call paid a fresh device allocation: 10..40 ms for the 8 MB of a 1 MiB single-stream inflate; with
+// "keep everything" one large single-stream inflate held gigabytes of HBM for the life of the process)
 hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t stream);
+hipError_t scratch_release();          // give the cached scratch of the current device back (hdlz_release_scratch)
 // p[0 .. n) = 0 by a kernel.  (Not hipMemsetAsync: captured into a HIP graph, a memset node on memory that a mem-alloc node of the
 // same graph hands out was seen to leave the words unchanged on ROCm 7.2 -- the device-side counters then started from garbage.)
 hipError_t zero_words(uint32_t* p, uint32_t n, hipStream_t stream);

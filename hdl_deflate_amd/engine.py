@@ -155,13 +155,15 @@ class Engine(object):
 
     # -- the job from HOST buffers: the PCIe hops overlapped with the kernels
     @_on_device
-    def compress_host(self, h_in, cwindow=32, maxmatch=10, chunk_blocks=None, h_archive=None, h_len=None):
+    def compress_host(self, h_in, cwindow=32, maxmatch=10, chunk_blocks=None, h_archive=None, h_len=None, keep_buffers=True):
         """h_in: PINNED host uint8 [B, n].  Compresses every block on the GPU and returns (h_archive, h_len, total, status_bad):
         the blocks' zlib streams back to back in pinned host memory (`h_archive[:total]`; block b at the exclusive scan of
         `h_len`), their lengths, and the number of blocks whose status is not OK (0 unless n < 5 / the capacity is wrong).
         The batch goes through the GPU in chunks of `chunk_blocks` blocks on three streams -- H2D of chunk k + 1, compress +
         scan + hdlz_compact_batch of chunk k, D2H of chunk k - 1's ARCHIVE (not its pitched rows) -- so the job costs about
-        the slower PCIe direction instead of H2D + kernel + D2H.  One host sync per chunk (its archive size)."""
+        the slower PCIe direction instead of H2D + kernel + D2H.  One host sync per chunk (its archive size).
+        The three side streams and the staging buffers are kept on the Engine between calls (`keep_buffers=False` or
+        release_host_buffers() drops them); compress_host / inflate_host of ONE Engine must not run from two threads at once."""
         assert h_in.dtype == torch.uint8 and h_in.dim() == 2 and h_in.is_contiguous() and h_in.is_pinned()
         B, n = h_in.shape
         pitch = pitch_for(n)
@@ -174,7 +176,9 @@ class Engine(object):
             h_archive = torch.empty(B * self.lib.hdlz_out_bound(n), dtype=torch.uint8, pin_memory=True)
         if h_len is None:
             h_len = torch.empty(B, dtype=torch.int32, pin_memory=True)
-        assert h_archive.is_pinned() and h_len.is_pinned() and h_len.numel() == B
+        assert h_archive.is_pinned() and h_len.is_pinned() and h_len.numel() == B and h_len.dtype == torch.int32
+        assert h_archive.dtype == torch.uint8 and h_archive.dim() == 1 and h_archive.numel() >= B * self.lib.hdlz_out_bound(n), \
+            "h_archive must hold B * hdlz_out_bound(n) bytes (the size of the archive is only known at the end)"
         dev = self.device
         cur = torch.cuda.current_stream()
         # streams and staging buffers are kept between calls (a fresh stream has a fresh allocator pool: device mallocs in the job)
@@ -212,39 +216,53 @@ class Engine(object):
             bad += nbad
 
         k = 0
-        for b0 in range(0, B, C):
-            nb = min(C, B - b0)
-            j = k & 1
-            with torch.cuda.stream(s_in):
-                if ev_k[j] is not None:
-                    s_in.wait_event(ev_k[j])              # the compress that read d_in[j] two chunks ago
-                d_in[j][:nb].copy_(h_in[b0:b0 + nb], non_blocking=True)
-                ev_in = torch.cuda.Event()
-                ev_in.record(s_in)
-            with torch.cuda.stream(s_k):
-                s_k.wait_event(ev_in)
-                if ev_out[j] is not None:
-                    s_k.wait_event(ev_out[j])             # the D2H that read d_arch[j] / d_len[j] two chunks ago
-                _, ol, st = self.compress_batch(d_in[j][:nb], cwindow=cwindow, maxmatch=maxmatch, out=d_rows[:nb], out_pitch=pitch)
-                l64 = ol.to(torch.int64)
-                off = torch.cumsum(l64, 0) - l64
-                self.compact(d_rows[:nb], ol, offsets=off, archive=d_arch[j])
-                d_len[j][:nb].copy_(ol)
-                d_tot[j][0] = l64.sum()
-                d_tot[j][1] = (st != 0).sum()
-                ev_k[j] = torch.cuda.Event()
-                ev_k[j].record(s_k)
+        try:
+            for b0 in range(0, B, C):
+                nb = min(C, B - b0)
+                j = k & 1
+                with torch.cuda.stream(s_in):
+                    if ev_k[j] is not None:
+                        s_in.wait_event(ev_k[j])              # the compress that read d_in[j] two chunks ago
+                    d_in[j][:nb].copy_(h_in[b0:b0 + nb], non_blocking=True)
+                    ev_in = torch.cuda.Event()
+                    ev_in.record(s_in)
+                with torch.cuda.stream(s_k):
+                    s_k.wait_event(ev_in)
+                    if ev_out[j] is not None:
+                        s_k.wait_event(ev_out[j])             # the D2H that read d_arch[j] / d_len[j] two chunks ago
+                    _, ol, st = self.compress_batch(d_in[j][:nb], cwindow=cwindow, maxmatch=maxmatch, out=d_rows[:nb], out_pitch=pitch)
+                    l64 = ol.to(torch.int64)
+                    off = torch.cumsum(l64, 0) - l64
+                    self.compact(d_rows[:nb], ol, offsets=off, archive=d_arch[j])
+                    d_len[j][:nb].copy_(ol)
+                    d_tot[j][0] = l64.sum()
+                    d_tot[j][1] = (st != 0).sum()
+                    ev_k[j] = torch.cuda.Event()
+                    ev_k[j].record(s_k)
+                if pending is not None:
+                    drain(pending)                            # chunk k - 1: its size is known now, its D2H runs beside chunk k's kernels
+                pending = (j, b0, nb)
+                k += 1
             if pending is not None:
-                drain(pending)                            # chunk k - 1: its size is known now, its D2H runs beside chunk k's kernels
-            pending = (j, b0, nb)
-            k += 1
-        if pending is not None:
-            drain(pending)
-        cur.wait_stream(s_out)
-        cur.wait_stream(s_k)
-        cur.wait_stream(s_in)
-        s_out.synchronize()
+                drain(pending)
+        finally:
+            # also on an exception (a failed C-ABI call in the loop): nothing stays queued on the side streams behind the caller's back
+            cur.wait_stream(s_out)
+            cur.wait_stream(s_k)
+            cur.wait_stream(s_in)
+            s_out.synchronize()
+            if not keep_buffers:
+                self.release_host_buffers()
         return h_archive, h_len, base, bad
+
+    def release_host_buffers(self):
+        """drop the streams and the device / pinned staging buffers compress_host and inflate_host keep between calls (about
+        2 C n + 3 C pitch bytes of HBM for chunks of C blocks: ~250 MB at the default 48 MiB chunk) and give the library's cached
+        scratch back to the device"""
+        self._host_ctx = None
+        self._ihost_ctx = None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.hdlz_release_scratch(), "hdlz_release_scratch")
 
     @_on_device
     def inflate_host(self, h_z, h_off, out_pitch, flags=0, obsize=0, chunk_streams=None, h_out=None, h_len=None, h_status=None):

@@ -95,6 +95,12 @@ int hdlz_device_count(void);
  * per literal + 7 EOB bits, padded, + 4 Adler bytes = 6 + ceil((9n+10)/8)  (SURVEY 8(a)). */
 size_t hdlz_out_bound(size_t n);
 
+/* The calls that need stream-ordered scratch (the dynamic-tree pass of the lane mapping, the parallel single-stream inflate) draw it
+ * from the library's own per-device memory pool, which keeps up to 256 MiB cached between calls (a fresh device allocation per call
+ * costs 10-40 ms) and returns anything above that to the device when the stream synchronises.  hdlz_release_scratch() gives the
+ * cached rest of the CURRENT device back as well (e.g. before the caller's own large allocations).  HDLZ_OK / HDLZ_E_HIP. */
+int hdlz_release_scratch(void);
+
 /*
  * STARTC for a batch: zlib stream 78 9C, ONE final fixed-Huffman block, LZ77 with a `cwindow`
  * byte look-back, nearest 3-byte match extended to at most `maxmatch` bytes, greedy parse,
@@ -177,6 +183,13 @@ int hdlz_compress_stream(const uint8_t* d_in, uint32_t in_len, int cwindow, int 
  *             q_end - state.pos a positive multiple of 32.  Final: q_end == in_len = the stream length (>= 5, else
  *             HDLZ_E_SHORT_INPUT); writes EOB, padding, Adler-32 and sets done.
  *   d_out     the whole output stream, linear, 4-byte aligned; out_cap >= hdlz_out_bound(final length) + 2400
+ * CONTRACT: the stream is the one the reference writes for an EAGER writer (test_deflate.py:250-258 -- its own harness -- keeps the
+ * writer >= 21 bytes ahead), whatever the arrival pattern of the pieces.  The reference's bitstream depends on the writer's timing:
+ * fill_buf latches iram[di+4 .. di+9] while the FSM stalls at di >= isize - 10 (deflate.py:466-500, :768-770), SEARCHF then compares
+ * against those stale registers (deflate.py:913-952), and a writer that supplies a byte every 3rd .. 8th iteration gets one match cut
+ * short (1262 instead of 1260 bytes on the recorded fixture, tests/golden/streaming_r3_vectors.json; both streams inflate to the
+ * input).  That clock-by-clock dependence is NOT reproduced -- it would take a cycle-accurate model of the FSM on the host -- and is
+ * recorded as fixtures instead.  Likewise the output memory: this engine never overwrites unread output.
  * After a call state.out_len complete output bytes are readable at d_out (the final call: the stream length, R9).
  * Violations are reported in state.status (HDLZ_E_BAD_PARAM / _OUT_CAPACITY / _SHORT_INPUT); a failed or finished session
  * ignores further calls.  One wave per call: the port adapter's path, not a throughput path. */
