@@ -39,14 +39,33 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROA
 CFG5_BLOCKS, CFG5_BLOCK = 131072, 65536          # BASELINE configs[4]: 8 GiB of 64 KiB blocks
 
 
-def measured_traffic(key):
-    """HBM bytes per launch measured with rocprofv3 PMC passes for exactly this kernel/config (profiles/traffic.json)"""
+def measured_counters(key, kname=None, grid=None):
+    """counters measured with rocprofv3 PMC passes for exactly this kernel / workload (profiles/traffic.json, written by
+    tools/update_traffic.py from the summaries under profiles/).  The entry is REFUSED -- (None, reason) -- when it was recorded for
+    another kernel symbol, launch grid or library version than the one this run just launched: a stale number must not pass
+    as this run's traffic (VERDICT r3 #5c)."""
     try:
         with open(os.path.join(REPO, "profiles", "traffic.json")) as f:
             e = json.load(f).get(key)
-        return (e["traffic_bytes"], e["source"]) if e else (None, None)
     except Exception:
+        return None, "profiles/traffic.json unreadable"
+    if not e:
         return None, None
+    from hdl_deflate_amd import _lib
+    ver = _lib.load().hdlz_version()
+    norm = lambda x: x.replace(" ", "")
+    if e.get("hdlz_version") != ver:
+        return None, "STALE: %s was recorded with libhdlz version 0x%06x, this is 0x%06x" % (e.get("source"), e.get("hdlz_version") or 0, ver)
+    if kname is not None and not norm(e.get("kernel", "")).startswith(norm(kname).split("+")[0].rstrip(">")):
+        return None, "STALE: %s was recorded for kernel %s, this run launched %s" % (e.get("source"), e.get("kernel"), kname)
+    if grid is not None and e.get("grid") not in (None, grid):
+        return None, "STALE: %s was recorded for a grid of %s threads, this run launched %d" % (e.get("source"), e.get("grid"), grid)
+    return e, e.get("source")
+
+
+def compress_grid(nblocks, ncu=256):
+    """threads hdlz_compress_batch launches for the one-block-per-wave kernels (hdlz_compress.hip: launch_compress)"""
+    return min(ncu * 64, nblocks) * 64
 
 
 def kname_for(cwindow, n=1 << 16):
@@ -57,19 +76,38 @@ def kname_for(cwindow, n=1 << 16):
     return "k_compress<%d, %s, %s>" % (nch, "true" if cwindow == 32 * nch else "false", "true" if (nch == 1 and n <= 2048) else "false")
 
 
+def lengths_digest(torch, lens):
+    """position-weighted checksum of a length vector: equal digests <=> (for all practical purposes) the same length at every index"""
+    l64 = lens.to(torch.int64).reshape(-1)
+    w = torch.arange(1, l64.numel() + 1, dtype=torch.int64, device=l64.device)
+    return int(((l64 * (w % 1000003)).sum() % 2305843009213693951).item())
+
+
 def median(v):
     v = sorted(v)
     return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
 
 
-def roofline(kname, algo_bytes, k_ms, traffic_key=None, extra=None):
+def roofline(kname, algo_bytes, k_ms, traffic_key=None, extra=None, grid=None, in_bytes=None):
+    """`hbm`: algorithmic bytes / average launch duration against the 8 TB/s peak (SURVEY 8(d) fixes this class for every kernel of
+    the path).  `issue`: the resource that actually binds these integer kernels -- VALU issue: wave-instructions per launch
+    (SQ_INSTS_VALU) x cycles per instruction / 1024 SIMDs against the kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs), both from the PMC
+    file named in `source`, so that the fraction can be recomputed from the line alone."""
     k_avg = sum(k_ms) / len(k_ms)
     achieved = algo_bytes / (k_avg * 1e-3) / 1e9
-    traffic, tsrc = measured_traffic(traffic_key) if traffic_key else (None, None)
+    e, tsrc = measured_counters(traffic_key, kname, grid) if traffic_key else (None, None)
     r = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": e["traffic_bytes"] if e else None, "traffic_source": tsrc,
          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg, 4), "kernel_ms_median": round(median(k_ms), 4),
          "kernel_ms_min": round(min(k_ms), 4), "launches_timed": len(k_ms)}
+    if e and e.get("valu_insts") and e.get("gui_active"):
+        cpi = e.get("cycles_per_valu_inst", 4.0)
+        est = e["valu_insts"] * cpi / 1024.0
+        cyc = e["gui_active"] / 8.0
+        r["issue"] = {"valu_insts_per_launch": int(e["valu_insts"]), "salu_insts_per_launch": int(e.get("salu_insts") or 0),
+                      "valu_insts_per_byte": round(e["valu_insts"] / in_bytes, 3) if in_bytes else None,
+                      "cycles_per_valu_inst": cpi, "est_issue_cycles": int(est), "kernel_cycles": int(cyc), "frac": round(est / cyc, 3),
+                      "source": e.get("source"), "note": e.get("issue_note")}
     if extra:
         r.update(extra)
     return r
@@ -183,7 +221,7 @@ def end_to_end(torch, eng, d_in, r, cwindow, maxmatch, reps=5):
         torch.cuda.synchronize()
         pipe.append((time.perf_counter() - t0) * 1e3)
     pipe = pipe[1:]
-    eng._host_ctx = None                                            # (the staging buffers of compress_host: not needed by the entries that follow)
+    eng.release_host_buffers()                                      # (the staging buffers of compress_host: not needed by the entries that follow)
     assert bad == 0 and total == r["out_bytes"] and int(h_len.to(torch.int64).sum().item()) == total
     hl = h_len.numpy().astype("int64")
     hoff = hl.cumsum() - hl
@@ -208,7 +246,7 @@ def compress_entry(name, workload, r, cwindow, maxmatch, steps, warmup, traffic_
             "ms_per_step": round(r["dt"] / steps * 1e3, 4), "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "cwindow": cwindow, "maxmatch": maxmatch, "blocks": r["B"], "block_bytes": r["n"]},
             "compression_ratio_out_over_in": round(r["out_bytes"] / r["in_bytes"], 4),
-            "roofline": roofline(kname_for(cwindow, r["n"]), algo, r["k_ms"], traffic_key)}
+            "roofline": roofline(kname_for(cwindow, r["n"]), algo, r["k_ms"], traffic_key, None, compress_grid(r["B"]), r["in_bytes"])}
 
 
 # ------------------------------------------------------------------------------------------------ N = 1
@@ -240,7 +278,9 @@ def main_single(a):
     kname = kname_for(a.cwindow, n)
     rl = roofline(kname, algo, r["k_ms"], "k_compress<%d>|blocks=%d|block=%d|data=%s" % (1 if a.cwindow <= 32 else 2 if a.cwindow <= 64 else 8, B, n, a.data),
                   {"device_copy_GBps": round(copy_gbs, 1),
-                   "note": "bytes = N_in + N_out + 4 per block; this path is VALU-issue bound, not HBM bound (DESIGN.md)"})
+                   "note": "bytes = N_in + N_out + 4 per block; this path is VALU-issue bound, not HBM bound: see `issue`; kernel_ms_* are "
+                           "HIP events around %d separate launches AFTER the timed loop of ms_per_step (two loops: they differ by noise)"
+                           % len(r["k_ms"])}, compress_grid(B) if n > 1024 else None, r["in_bytes"])
     rl["frac_of_device_copy"] = round(rl["achieved"] / copy_gbs, 4)
     res = {
         "metric": "compress_input_throughput (CWINDOW=%d, MATCH10=%s, static tree)" % (a.cwindow, a.maxmatch == 10),
@@ -296,6 +336,7 @@ def main_single(a):
                                   "CWINDOW=32 -- north_star's target block shape; ms_per_step = T(1) of `bench.py --gpus N`"
                                   % (a.cfg5_blocks, a.cfg5_blocks * CFG5_BLOCK / 2 ** 30), r5, 32, 10, a.steps, a.warmup,
                                   "k_compress<1>|blocks=%d|block=65536|data=families" % a.cfg5_blocks))
+        sec.append(bench_roundtrip(torch, eng, a, d5, r5))
         d_out5 = r5["d_out"]
         del r5, d5
         # -- configs[2]: CWINDOW=64 + MATCH10 on 64 KiB text blocks, next to CWINDOW=32 on the same data
@@ -332,6 +373,39 @@ def main_single(a):
         sec.append(bench_single_stream(torch, eng, dev, a))
         res["secondary"] = sec
     print(json.dumps(res), flush=True)
+
+
+def bench_roundtrip(torch, eng, a, d_plain, r):
+    """the round trip of the configs[4] job (the reference's harness always inflates what it compressed,
+    test_deflate.py:197-286): the streams STARTC just wrote -- compacted into ONE archive, so the inflate reads ragged streams
+    through in_off, the form a stored archive has -- through hdlz_inflate_batch, every stream compared with its block"""
+    B, n = d_plain.shape
+    dev = d_plain.device
+    l64 = r["ol"].to(torch.int64)
+    offs = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(l64, 0, out=offs[1:])
+    total = int(offs[-1].item())
+    arch = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
+    eng.compact(r["d_out"], r["ol"], offsets=offs[:B], archive=arch)
+    back = torch.empty((B, n), dtype=torch.uint8, device=dev)
+
+    def step():
+        return eng.inflate_batch(arch, in_off=offs, out_pitch=n, out=back)
+
+    dt, (_, bl, bs) = time_steps(torch, None, step, a.steps, a.warmup, 1, None)
+    k_ms = kernel_ms(torch, step, max(3, a.steps))
+    assert int((bs != 0).sum().item()) == 0 and int((bl != n).sum().item()) == 0, "round trip: streams failed"
+    assert torch.equal(back, d_plain), "round trip: inflated bytes differ from the blocks that were compressed"
+    algo = total + B * n + 4 * B
+    return {"name": "configs[4] round trip", "metric": "inflate_output_throughput (the streams STARTC wrote for the configs[4] job, one archive)",
+            "value": round(B * n / (dt / a.steps) / 1e6, 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "STARTD of the %d streams the 'configs[4]-shape' entry wrote (CWINDOW=32 streams of 64 KiB blocks, compacted "
+                                   "into one %.2f GB archive, ragged in_off), every stream compared with its block" % (B, total / 1e9),
+                       "streams": B, "block_bytes": n, "archive_bytes": total},
+            "input_MBps": round(total / (dt / a.steps) / 1e6, 1),
+            "roofline": roofline("k_inflate_tok<false>", algo, k_ms, "k_inflate_tok|roundtrip|streams=%d|block=%d" % (B, n), None,
+                                 (B + 255) // 256 * 256, B * n)}
 
 
 def bench_single_stream(torch, eng, dev, a, n=1 << 24):
@@ -392,10 +466,12 @@ def main_sharded(a):
     dev = torch.device("cuda", local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import datetime
+    tmo = datetime.timedelta(minutes=30)                     # (ranks > 0 wait at a barrier while rank 0 runs T(1) of the whole job)
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     cdev = dev if backend == "nccl" else torch.device("cpu")
 
     eng = hdl_deflate_amd.Engine(dev)
@@ -423,7 +499,7 @@ def main_sharded(a):
         if rank == 0:
             d1 = make_blocks(total, n, dev, seed=0)
             r1 = run_compress(torch, eng, d1, 32, 10, a.steps, a.warmup, 0)
-            t1 = {"ms": r1["dt"] / a.steps * 1e3, "out_bytes": r1["out_bytes"], "k_ms": r1["k_ms"]}
+            t1 = {"ms": r1["dt"] / a.steps * 1e3, "out_bytes": r1["out_bytes"], "k_ms": r1["k_ms"], "digest": lengths_digest(torch, r1["ol"])}
             del r1, d1
             torch.cuda.empty_cache()
         dist.barrier()
@@ -434,8 +510,10 @@ def main_sharded(a):
     assert bad == 0, "%d blocks failed" % bad
     assert all_len.numel() == total and int(all_len.to(torch.int64).sum().item()) == out_bytes, "gathered lengths disagree"
     assert torch.equal(all_len[b0:b1].to(ol.device), ol.to(torch.int32)), "own shard not at its place in the gathered lengths"
-    if t1 is not None:                                     # the shards together ARE the single-GPU job: same bytes in, same bytes out
+    digest = lengths_digest(torch, all_len)
+    if t1 is not None:                                     # the shards together ARE the single-GPU job: same bytes in, same bytes out,
         assert out_bytes == t1["out_bytes"], "sharded job wrote %d bytes, the 1-GPU job %d" % (out_bytes, t1["out_bytes"])
+        assert digest == t1["digest"], "the gathered lengths are not the 1-GPU job's lengths"     # ... the same length at every index
     if rank == 0 and a.verify:
         zlib_spot_check(torch, d_in, d_out, ol, min(a.verify, 32))
     if rank == 0:
@@ -451,14 +529,16 @@ def main_sharded(a):
                                          "crosses xGMI)" % (world, B, "RCCL" if backend == "nccl" else backend)},
                "per_gpu_MBps": round(value / world, 1),
                "compression_ratio_out_over_in": round(out_bytes / in_bytes, 4),
-               "length_allgather_ms_avg": round(sum(g_ms) / len(g_ms), 4),
+               "length_allgather_ms_avg": round(sum(g_ms) / len(g_ms), 4), "lengths_digest": digest,
                "roofline": roofline(kname_for(32, n), algo, k_ms, None, {"note": "rank 0's shard; per-GPU figure"})}
         if t1 is not None:
             res["T1_ms"] = round(t1["ms"], 4)
             res["T1_kernel_ms_median"] = round(median(t1["k_ms"]), 4)
             res["speedup_vs_T1"] = round(t1["ms"] / (dt / a.steps * 1e3), 3)
-            res["note"] = ("T1_ms = the whole job (%d blocks) on rank 0's GPU alone, measured in this run before the shards (same blocks: "
-                           "output byte counts asserted equal); speedup_vs_T1 / n_gpus is the strong-scaling efficiency" % total)
+            res["T1_lengths_digest"] = t1["digest"]
+            res["note"] = ("T1_ms = the whole job (%d blocks) on rank 0's GPU alone, measured in this run AFTER the timed shards (same blocks: "
+                           "output byte counts and the position-weighted digest of the gathered lengths asserted equal to the 1-GPU "
+                           "job's); speedup_vs_T1 / n_gpus is the strong-scaling efficiency" % total)
         else:
             res["note"] = "T(1) of this job is the ms_per_step of the 'configs[4]-shape, 1 GPU' entry of `bench.py --gpus 1`"
         print(json.dumps(res), flush=True)
@@ -538,7 +618,8 @@ def bench_inflate(a, eng=None, cpu=True, streams=None, strategy=None):
            "compression_ratio_out_over_in": round(z_bytes / u_bytes, 4),
            "roofline": roofline(("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok<false>") +
                                 ("" if fixed else " + k_inflate_dyn" if a.inflate_kernel == "byte" else " + k_inflate_tok<true>"), algo, k_ms,
-                                "%s|streams=%d|block=%d" % ("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok", B, n))}
+                                "%s|streams=%d|block=%d|%s" % ("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_tok", B, n, a.zlib_strategy),
+                                None, None, u_bytes)}
     if fixed and a.end_to_end:
         # SURVEY 8(d) "Timing" for STARTD: the job from pinned HOST buffers (streams in, rows out), the three steps one after the other;
         # PCIe-bound, never `value`
@@ -562,9 +643,27 @@ def bench_inflate(a, eng=None, cpu=True, streams=None, strategy=None):
         assert os.environ.get("HDLZ_BENCH_NOCHECK") or (int((h_s != 0).sum().item()) == 0 and int((h_l != n).sum().item()) == 0 and
                                                         torch.equal(h_rows, d_plain.cpu())), "host rows differ"
         seq = seq[1:]
+        # the same job through Engine.inflate_host: chunks on three streams, the rows written into the pinned host rows by a kernel
+        h_rows.zero_()
+        pipe = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.inflate_host(h_z, torch.from_numpy(off), n, flags=flags, h_out=h_rows, h_len=h_l, h_status=h_s)
+            torch.cuda.synchronize()
+            pipe.append((time.perf_counter() - t0) * 1e3)
+        pipe = pipe[1:]
+        assert os.environ.get("HDLZ_BENCH_NOCHECK") or (int((h_s != 0).sum().item()) == 0 and int((h_l != n).sum().item()) == 0 and
+                                                        torch.equal(h_rows, d_plain.cpu())), "host rows differ (inflate_host)"
+        eng.release_host_buffers()
         res["end_to_end"] = {"ms_median": round(median(seq), 3), "output_MBps": round(u_bytes / median(seq) / 1e3, 1),
+                             "d2h_floor_ms": round(u_bytes / 57.0e6, 2),
+                             "pipelined": {"ms_median": round(median(pipe), 3), "ms_min": round(min(pipe), 3), "ms_all": [round(x, 2) for x in pipe],
+                                           "output_MBps": round(u_bytes / median(pipe) / 1e3, 1),
+                                           "note": "Engine.inflate_host: chunks on three streams (H2D | hdlz_inflate_batch | rows -> pinned host rows by "
+                                                   "hdlz_compact_batch), no host synchronisation inside the job; every row compared with its block"},
                              "note": "pinned host buffers: H2D of the streams + offsets, hdlz_inflate_batch, D2H of the rows, lengths and statuses, one after the other on the launch stream; "
-                                     "every row compared with its original block"}
+                                     "every row compared with its original block; d2h_floor_ms = the rows alone at the 57 GB/s this link delivers"}
         del h_z, h_rows, d_stage
     if not fixed:
         # the same streams one WAVE each (k_inflate_dyn: what small batches and sessions run), half of them: the mapping's own figure
@@ -685,7 +784,7 @@ def main():
                          "(exercises the second pass k_inflate_tok<true> / k_inflate_dyn, SURVEY 8(f) rank 1)")
     ap.add_argument("--inflate-kernel", default="default", choices=["default", "token", "byte", "two"],
                     help="inflate: lane-per-stream kernel variant (token = k_inflate_tok, byte = k_inflate)")
-    ap.add_argument("--mode", default="compress", choices=["compress", "inflate"],
+    ap.add_argument("--mode", default="compress", choices=["compress", "inflate", "roundtrip"],
                     help="compress = BASELINE metric (default); inflate = only the configs[3] side metric (1 GPU)")
     ap.add_argument("--no-archive", dest="archive", action="store_false",
                     help="N=1: skip the archive figure (compress + scan + hdlz_compact_batch) of the headline job")
@@ -696,6 +795,15 @@ def main():
     a = ap.parse_args()
     if a.mode == "inflate":
         print(json.dumps(bench_inflate(a)), flush=True)
+    elif a.mode == "roundtrip":                               # only the configs[4] round-trip entry (profiling)
+        import torch
+        import hdl_deflate_amd
+        from hdl_deflate_amd.data import make_blocks
+        torch.cuda.set_device(0)
+        eng = hdl_deflate_amd.Engine(torch.device("cuda", 0))
+        d5 = make_blocks(a.cfg5_blocks, CFG5_BLOCK, torch.device("cuda", 0), seed=0)
+        r5 = run_compress(torch, eng, d5, 32, 10, 1, 1, 0)
+        print(json.dumps(bench_roundtrip(torch, eng, a, d5, r5)), flush=True)
     elif a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
     elif a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:

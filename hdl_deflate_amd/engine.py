@@ -265,14 +265,20 @@ class Engine(object):
             self._check(self.lib.hdlz_release_scratch(), "hdlz_release_scratch")
 
     @_on_device
-    def inflate_host(self, h_z, h_off, out_pitch, flags=0, obsize=0, chunk_streams=None, h_out=None, h_len=None, h_status=None):
+    def inflate_host(self, h_z, h_off, out_pitch, flags=0, obsize=0, chunk_streams=None, h_out=None, h_len=None, h_status=None,
+                     keep_buffers=True, d2h="copy"):
         """STARTD for a batch held in HOST memory: h_z PINNED flat uint8 (the zlib streams back to back), h_off int64 [B + 1] on the
         host (ascending; stream b = h_z[h_off[b]:h_off[b + 1]]).  Returns pinned (h_out uint8 [B, out_pitch], h_len int32 [B],
-        h_status int32 [B]).  Chunks of `chunk_streams` streams on three streams: H2D of chunk k + 1, hdlz_inflate_batch of chunk k,
-        D2H of chunk k - 1's rows.  The job is bound by the D2H of the rows (ROCm 7.2 runs it as a blit kernel beside the inflate
-        kernel): 0.5 GiB of rows in 13.0 ms, what the three steps take one after the other -- the overlap buys nothing here, unlike
-        compress_host.  Chunks stay below 64 MiB of rows: with larger D2H copies hipMemcpyAsync (torch's copy_ or the raw call)
-        was seen to block the host for ~77 ms in every second call."""
+        h_status int32 [B]).  Chunks of `chunk_streams` streams (the first one a quarter of that: the pipeline fills sooner) on three
+        streams, nothing but enqueues on the host -- no synchronisation before the end: H2D of chunk k + 1 | hdlz_inflate_batch of
+        chunk k | D2H of chunk k - 1's rows in copies of at most 32 MiB (larger hipMemcpyAsync D2H copies were seen to block the host
+        on ROCm 7.2).  Measured on BASELINE configs[3] (profiles/r04_inflate_host.txt): 42.5 ms against 37.7 ms for the rows alone at
+        the link's 57 GB/s (round 3: 51.9 ms -- it waited on the host for a chunk's kernel before issuing its D2H, and its 48 MiB
+        chunks ran the inflate kernel 43 times at the ~0.6 ms a lane-per-stream launch costs whatever its size).  What is left above the
+        floor: a kernel that runs BESIDE a D2H -- the runtime's blit or a kernel of ours storing into the mapped rows, d2h="kernel" --
+        completes only when the D2H's writes have drained (0.63 -> 3.1 ms in the kernel trace; its end-of-kernel write-back queues
+        behind the PCIe-bound stores), so inflate and D2H alternate per chunk pair instead of overlapping freely.
+        Buffers and streams are kept on the Engine between calls (see compress_host); one call at a time per Engine."""
         assert h_z.dtype == torch.uint8 and h_z.dim() == 1 and h_z.is_pinned() and out_pitch % 4 == 0
         h_off = torch.as_tensor(h_off, dtype=torch.int64)
         assert not h_off.is_cuda and h_off.dim() == 1 and h_off.numel() >= 1
@@ -284,75 +290,85 @@ class Engine(object):
         if h_status is None:
             h_status = torch.empty(B, dtype=torch.int32, pin_memory=True)
         assert h_out.is_pinned() and h_len.is_pinned() and h_status.is_pinned() and tuple(h_out.shape) == (B, out_pitch)
+        assert h_out.dtype == torch.uint8 and h_out.is_contiguous() and h_len.numel() == B and h_status.numel() == B
+        assert h_len.dtype == torch.int32 and h_status.dtype == torch.int32
         if B == 0:
             return h_out, h_len, h_status
         if chunk_streams is None:
-            chunk_streams = max(1, min(B, (48 << 20) // max(out_pitch, 1)))
+            # 256 MiB of rows per chunk: a lane-per-stream batch needs ~10^5 streams to fill the GPU (131 072 streams of 2 KiB take
+            # 0.73 ms, 16 384 take 0.6 ms as well), so small chunks only multiply the kernel time (profiles/r04_inflate_host.txt)
+            chunk_streams = max(1, min(B, (256 << 20) // max(out_pitch, 1)))
         C = chunk_streams
-        zmax = max(int(h_off[min(b0 + C, B)] - h_off[b0]) for b0 in range(0, B, C))      # compressed bytes of the largest chunk
+        piece = max(1, (32 << 20) // max(out_pitch, 1))
+        starts = [0] + list(range(max(1, C // 4), B, C))               # chunk k = streams [starts[k], starts[k + 1])
+        ends = starts[1:] + [B]
+        zlo = [int(h_off[b0]) & ~255 for b0 in starts]                  # (the H2D copies start at aligned host addresses)
+        zhi = [min((int(h_off[b1]) + 255) & ~255, h_z.numel()) for b1 in ends]
+        zmax = max(b - a for a, b in zip(zlo, zhi))                      # compressed bytes of the largest chunk
         dev = self.device
         cur = torch.cuda.current_stream()
         ctx = getattr(self, "_ihost_ctx", None)
-        if ctx is None or ctx["key"] != (C, out_pitch) or ctx["zcap"] < zmax:
-            ctx = {"key": (C, out_pitch), "zcap": zmax, "streams": [torch.cuda.Stream(dev) for _ in range(3)],
+        if ctx is None or ctx["key"] != (C, out_pitch) or ctx["zcap"] < zmax or ctx["h_off"].numel() < B + 1:
+            # (the inflate stream has the higher priority: its workgroups are placed before the pending ones of the row copy beside it)
+            ctx = {"key": (C, out_pitch), "zcap": zmax,
+                   "streams": [torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev)],
                    "d_z": [torch.zeros(zmax + 1024, dtype=torch.uint8, device=dev) for _ in range(2)],
                    "d_len": [torch.empty((2, C), dtype=torch.int32, device=dev) for _ in range(2)],
                    "d_off": [torch.empty(C + 1, dtype=torch.int64, device=dev) for _ in range(2)],
-                   "h_off": [torch.empty(C + 1, dtype=torch.int64, pin_memory=True) for _ in range(2)],
+                   "h_off": torch.empty(B + 1, dtype=torch.int64, pin_memory=True),
+                   "row_off": torch.arange(C, dtype=torch.int64, device=dev) * out_pitch,
                    "d_out": [torch.empty((C, out_pitch), dtype=torch.uint8, device=dev) for _ in range(2)]}
             self._ihost_ctx = ctx
+        ctx["h_off"][:B + 1].copy_(h_off)                               # pinned copy of the offsets: the per-chunk H2D reads it asynchronously
         s_in, s_k, s_out = ctx["streams"]
         for st in (s_in, s_k, s_out):
             st.wait_stream(cur)
-        ev_in_done = [None, None]          # H2D of the chunk that last used staging pair j (its pinned offsets may be rewritten after it)
-        ev_k = [None, None]
-        ev_out = [None, None]
-        pending = None
-
-        def drain(p):
-            j, b0, nb = p
-            ev_k[j].synchronize()
-            with torch.cuda.stream(s_out):
-                h_out[b0:b0 + nb].copy_(ctx["d_out"][j][:nb], non_blocking=True)
-                h_len[b0:b0 + nb].copy_(ctx["d_len"][j][0, :nb], non_blocking=True)
-                h_status[b0:b0 + nb].copy_(ctx["d_len"][j][1, :nb], non_blocking=True)
-                ev_out[j] = torch.cuda.Event()
-                ev_out[j].record(s_out)
-
-        for k, b0 in enumerate(range(0, B, C)):
-            nb = min(C, B - b0)
-            j = k & 1
-            z0, z1 = int(h_off[b0]), int(h_off[b0 + nb])
-            za = z0 & ~255                                 # (the copy starts at an aligned host address)
-            zb = min((z1 + 255) & ~255, h_z.numel())
-            if ev_in_done[j] is not None:
-                ev_in_done[j].synchronize()                # (two chunks back: long done)
-            torch.sub(h_off[b0:b0 + nb + 1], za, out=ctx["h_off"][j][:nb + 1])
-            with torch.cuda.stream(s_in):
-                if ev_k[j] is not None:
-                    s_in.wait_event(ev_k[j])
-                ctx["d_z"][j][:zb - za].copy_(h_z[za:zb], non_blocking=True)
-                ctx["d_off"][j][:nb + 1].copy_(ctx["h_off"][j][:nb + 1], non_blocking=True)
-                ev_in_done[j] = torch.cuda.Event()
-                ev_in_done[j].record(s_in)
-            with torch.cuda.stream(s_k):
-                s_k.wait_event(ev_in_done[j])
-                if ev_out[j] is not None:
-                    s_k.wait_event(ev_out[j])
-                _, ol, st = self.inflate_batch(ctx["d_z"][j], in_off=ctx["d_off"][j][:nb + 1], out_pitch=out_pitch, flags=flags,
-                                               obsize=obsize, out=ctx["d_out"][j][:nb])
-                ctx["d_len"][j][0, :nb].copy_(ol)
-                ctx["d_len"][j][1, :nb].copy_(st)
-                ev_k[j] = torch.cuda.Event()
-                ev_k[j].record(s_k)
-            if pending is not None:
-                drain(pending)                             # chunk k - 1's D2H is issued once its kernels are done (as in compress_host)
-            pending = (j, b0, nb)
-        if pending is not None:
-            drain(pending)
-        for st_ in (s_out, s_k, s_in):
-            cur.wait_stream(st_)
-        s_out.synchronize()
+        ev_k = [None, None]                # inflate of the chunk that last used staging pair j (read d_z / d_off, wrote d_out / d_len)
+        ev_out = [None, None]              # its rows are in host memory
+        try:
+            for k, b0 in enumerate(starts):
+                nb = ends[k] - b0
+                j = k & 1
+                za, zb = zlo[k], zhi[k]
+                with torch.cuda.stream(s_in):
+                    if ev_k[j] is not None:
+                        s_in.wait_event(ev_k[j])
+                    ctx["d_z"][j][:zb - za].copy_(h_z[za:zb], non_blocking=True)
+                    ctx["d_off"][j][:nb + 1].copy_(ctx["h_off"][b0:b0 + nb + 1], non_blocking=True)
+                    ctx["d_off"][j][:nb + 1].sub_(za)                   # offsets relative to the staged piece
+                    ev_in = torch.cuda.Event()
+                    ev_in.record(s_in)
+                with torch.cuda.stream(s_k):
+                    s_k.wait_event(ev_in)
+                    if ev_out[j] is not None:
+                        s_k.wait_event(ev_out[j])
+                    _, ol, st = self.inflate_batch(ctx["d_z"][j], in_off=ctx["d_off"][j][:nb + 1], out_pitch=out_pitch, flags=flags,
+                                                   obsize=obsize, out=ctx["d_out"][j][:nb])
+                    ctx["d_len"][j][0, :nb].copy_(ol)
+                    ctx["d_len"][j][1, :nb].copy_(st)
+                    ev_k[j] = torch.cuda.Event()
+                    ev_k[j].record(s_k)
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(ev_k[j])
+                    if d2h == "kernel":
+                        # rows -> pinned host rows by a kernel (row b of the chunk to h_out[b0 + b]; out_len bytes each)
+                        rc = self.lib.hdlz_compact_batch(ctx["d_out"][j].data_ptr(), out_pitch, ctx["d_len"][j][0].data_ptr(),
+                                                         ctx["row_off"].data_ptr(), nb, h_out[b0:].data_ptr(), s_out.cuda_stream)
+                        self._check(rc, "hdlz_compact_batch (rows -> pinned host memory)")
+                    else:
+                        for r0 in range(0, nb, piece):                  # copy-engine transfers of at most 32 MiB (see the docstring)
+                            r1 = min(nb, r0 + piece)
+                            h_out[b0 + r0:b0 + r1].copy_(ctx["d_out"][j][r0:r1], non_blocking=True)
+                    h_len[b0:b0 + nb].copy_(ctx["d_len"][j][0, :nb], non_blocking=True)
+                    h_status[b0:b0 + nb].copy_(ctx["d_len"][j][1, :nb], non_blocking=True)
+                    ev_out[j] = torch.cuda.Event()
+                    ev_out[j].record(s_out)
+        finally:
+            for st_ in (s_out, s_k, s_in):
+                cur.wait_stream(st_)
+            s_out.synchronize()
+            if not keep_buffers:
+                self.release_host_buffers()
         return h_out, h_len, h_status
 
     # -- streaming sessions (hdlz_compress_chunk / hdlz_inflate_chunk): the port adapter's streaming mode

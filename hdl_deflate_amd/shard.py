@@ -20,10 +20,10 @@ def shard_range(nblocks, rank, world):
 def gather_lengths(local_len, nblocks, group=None):
     """all-gather per-block output lengths of contiguous shards -> int32 [nblocks] on every rank (one-off form; a
     loop should hold a LengthGather, which keeps its buffers)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         assert local_len.numel() == nblocks
         return local_len.to(torch.int32)
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group)          # (a world of ONE rank still goes through the collective, like LengthGather)
     rank = dist.get_rank(group)
     sizes = [shard_range(nblocks, r, world) for r in range(world)]
     maxn = max(b1 - b0 for b0, b1 in sizes)
@@ -89,9 +89,9 @@ def archive_offsets(all_len):
 def gather_archive(local_archive, nbytes_local, group=None):
     """concatenate the per-rank archives on every rank (payload gather; NOT on the timed path):
     all-gather of sizes, pad to the largest, all-gather, trim.  Returns uint8 [sum of sizes]."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_archive[:nbytes_local]
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group)          # (world == 1 included: the first real multi-GPU run must not be the first RCCL payload gather)
     dev = local_archive.device
     cdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
     sizes = torch.zeros(world, dtype=torch.int64, device=cdev)

@@ -747,6 +747,38 @@ def test_inflate_error_statuses(engine, oracle):
     assert st == 2
 
 
+def test_round_trip_of_own_streams_through_an_archive(engine, oracle):
+    """what bench.py's "configs[4] round trip" entry does, at reduced count and against the oracle: 64 KiB blocks ->
+    STARTC -> one archive (ragged in_off) -> STARTD in every mapping; streams, lengths, statuses and bytes equal the oracle's, the
+    bytes equal the blocks (the reference's harness inflates what it compressed, test_deflate.py:197-286)"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    B, n = 192, 65536
+    d = make_blocks(B, n, "cuda", seed=77)
+    d[5, 1000:] = 0                                            # a block that compresses to almost nothing
+    d[6] = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")      # and one that does not compress at all
+    for cw in (32, 256):
+        rows, ol, st = engine.compress_batch(d, cwindow=cw)
+        assert int((st != 0).sum()) == 0
+        arch, offs = engine.compact(rows, ol)
+        in_off = torch.cat([offs, (offs[-1:] + ol[-1:].to(torch.int64))])
+        z = torch.cat([arch, torch.zeros(64, dtype=torch.uint8, device="cuda")])
+        hz, hoff = z.cpu().numpy(), in_off.cpu().numpy().astype(np.uint64)
+        host = d.cpu().numpy()
+        for b in (0, 5, 6, B - 1):
+            assert hz[int(hoff[b]):int(hoff[b + 1])].tobytes() == oracle.compress(host[b].tobytes(), cw, 10)[1]
+        ref, rl, rs = oracle.inflate_batch(hz, hoff, n, flags=0, nthreads=8)
+        assert (rs == 0).all() and (rl == n).all() and np.array_equal(ref, host)
+        for mapping in (0,) + MAPPINGS:
+            for fl in (0, 1):
+                out, bl, bs = engine.inflate_batch(z, in_off=in_off, out_pitch=n, flags=mapping | fl)
+                assert int((bs != 0).sum()) == 0 and int((bl != n).sum()) == 0 and torch.equal(out, d), (cw, mapping, fl)
+    # a capacity one byte short: every stream reports OUT_CAPACITY, as the oracle does
+    out, bl, bs = engine.inflate_batch(z, in_off=in_off, out_pitch=n - 4, flags=2)
+    _, rl, rs = oracle.inflate_batch(hz, hoff, n - 4, flags=0, nthreads=8)
+    assert np.array_equal(bs.cpu().numpy().astype(np.uint32), rs) and np.array_equal(bl.cpu().numpy().astype(np.uint32), rl)
+
+
 def test_compact_archive(engine, oracle):
     """variable-length rows -> one contiguous archive; every stream must still inflate"""
     import torch

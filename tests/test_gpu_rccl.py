@@ -47,6 +47,17 @@ def _rank_main(rank, world, port, nblocks, n, q):
         torch.cuda.synchronize()
         assert int((st != 0).sum()) == 0 and torch.equal(all_len, again)
         assert torch.equal(all_len[b0:b1], ol)
+        # the same exchange on a process group that is not the default one, and the payload gather (8(f) rank 2) on
+        # RCCL -- a world of ONE rank goes through ncclAllGather too, so the first real multi-GPU run is not their first execution
+        from hdl_deflate_amd.shard import gather_archive, gather_lengths
+        grp = dist.new_group(ranks=list(range(world)))
+        assert torch.equal(LengthGather(nblocks, dev, group=grp).gather(ol), all_len)
+        assert torch.equal(gather_lengths(ol, nblocks, group=grp), all_len)
+        arch, aoff = eng.compact(out, ol)
+        nloc = int(ol.to(torch.int64).sum().item())
+        whole = gather_archive(arch, nloc, group=grp)
+        torch.cuda.synchronize()
+        assert whole.numel() == total and torch.equal(whole[int(offs[b0]):int(offs[b0]) + nloc], arch[:nloc])
         q.put((rank, b0, d_in.cpu().numpy(), out.cpu().numpy(), all_len.cpu().numpy(), offs.cpu().numpy(), total))
     finally:
         dist.destroy_process_group()
@@ -142,3 +153,17 @@ def test_shards_of_any_world_size_hold_the_single_gpu_jobs_bytes():
         parts = [make_blocks(b1 - b0, 4096, "cuda", seed=0, first_block=b0, chunk=5 + world)
                  for b0, b1 in (shard_range(203, r, world) for r in range(world))]
         assert torch.equal(torch.cat(parts), whole), world
+
+
+def test_bench_gpus_8_even_and_uneven_jobs():
+    """`bench.py --gpus 8` end to end on the job shapes of BASELINE configs[4] (blocks / 8 per rank) and on an UNEVEN job
+    (three ranks hold one block more): eight ranks -- over RCCL when eight devices are visible, else sharing the visible device(s) over
+    gloo --, the gathered lengths asserted equal to the 1-rank job's INSIDE the run (byte count + position-weighted digest, T1 leg)"""
+    import torch
+    ndev = torch.cuda.device_count()
+    env = {} if ndev >= 8 else {"HDLZ_BENCH_BACKEND": "gloo"}
+    for blocks in (1024, 1027):
+        r = _run_bench(8, env, ["--cfg5-blocks", str(blocks), "--steps", "2", "--warmup", "1"])
+        assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["value"] > 0 and r["config"]["blocks_total"] == blocks
+        assert r["config"]["blocks_per_gpu"] == blocks // 8 + (1 if blocks % 8 else 0)          # rank 0's shard
+        assert r["lengths_digest"] == r["T1_lengths_digest"] and r["T1_ms"] > 0

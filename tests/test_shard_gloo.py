@@ -79,3 +79,66 @@ def test_single_process_passthrough():
     assert gather_lengths(l, 3).tolist() == [3, 4, 5]
     offs, tot = archive_offsets(l)
     assert offs.tolist() == [0, 3, 7] and tot == 12
+
+
+# ---- the shapes of the real job (BASELINE configs[4]: 131 072 blocks over 8 ranks), an UNEVEN job, and a
+# LengthGather on a process group that is not the default one -- eight gloo ranks, lengths only (no compress: this is the exchange step)
+def _lens_of(nblocks):
+    g = torch.Generator().manual_seed(nblocks)
+    return torch.randint(30, 74000, (nblocks,), dtype=torch.int32, generator=g)
+
+
+def _worker8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = {}
+        for nblocks in (131072, 131075):
+            want = _lens_of(nblocks)
+            b0, b1 = shard_range(nblocks, rank, world)
+            lg = LengthGather(nblocks, "cpu")
+            assert lg.equal == (nblocks % world == 0)
+            for _ in range(2):                                    # buffers are reused between steps
+                got = lg.gather(want[b0:b1].clone())
+                assert torch.equal(got, want), (rank, nblocks)
+            assert torch.equal(gather_lengths(want[b0:b1].clone(), nblocks), want)
+            offs, total = archive_offsets(got)
+            res[nblocks] = (int(offs[-1]), total)
+        # a sub-group of the odd ranks: group-relative rank and world size decide the shard
+        odd = dist.new_group(ranks=[1, 3, 5, 7])
+        if rank % 2 == 1:
+            nblocks = 1003
+            want = _lens_of(nblocks)
+            gr, gw = dist.get_rank(odd), dist.get_world_size(odd)
+            assert gw == 4 and gr == rank // 2
+            b0, b1 = shard_range(nblocks, gr, gw)
+            lg = LengthGather(nblocks, "cpu", group=odd)
+            assert torch.equal(lg.gather(want[b0:b1].clone()), want)
+            blob = torch.arange(b0, b1, dtype=torch.int64).to(torch.uint8)
+            whole = gather_archive(blob, blob.numel(), group=odd)
+            assert torch.equal(whole, torch.arange(nblocks, dtype=torch.int64).to(torch.uint8))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_length_allgather_world8_job_shapes_and_subgroup():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for nblocks in (131072, 131075):
+        want = _lens_of(nblocks).to(torch.int64)
+        for rank, r in res:
+            assert r[nblocks] == (int(want[:-1].sum()), int(want.sum())), (rank, nblocks)
