@@ -155,7 +155,7 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     if (nstreams > 0x7FFFFFFFull * 32) return fail_param("nstreams too large for one launch");
     if (nstreams && (!d_in || !d_out || !d_out_len || !d_status)) return fail_param("null device pointer");
     if (flags & ~(HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_ONEBLOCK |
-                  HDLZ_INFLATE_TOKEN_ROUNDS | HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_TWO_PHASE))
+                  HDLZ_INFLATE_TOKEN_ROUNDS | HDLZ_INFLATE_BYTE_LOCKSTEP))
         return fail_param("unknown flag");
     // the kernels keep stream lengths and bit positions in 32 bits (8 * length must not wrap)
     if (!d_in_off && in_len >= 0x10000000u) return fail_param("in_len too large (streams are limited to 256 MiB - 1)");
@@ -206,13 +206,7 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     }
     // lane per stream: one TOKEN per round (k_inflate_tok, round 2: 362 GB/s on BASELINE configs[3]) unless the caller asks for
     // round 1's one-byte-per-iteration kernel (k_inflate, 278 GB/s)
-    bool two = false;
-    hipError_t e = hipSuccess;
-    if ((flags & HDLZ_INFLATE_TWO_PHASE) && !(flags & (HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_TOKEN_ROUNDS))) {
-        e = hdlz::launch_inflate_two(a, st, &two);
-        if (e != hipSuccess) return fail_hip(e, "launch the two-phase inflate");
-    }
-    if (!two) e = (flags & HDLZ_INFLATE_BYTE_LOCKSTEP) ? hdlz::launch_inflate(a, st) : hdlz::launch_inflate_tok(a, st);
+    hipError_t e = (flags & HDLZ_INFLATE_BYTE_LOCKSTEP) ? hdlz::launch_inflate(a, st) : hdlz::launch_inflate_tok(a, st);
     if (e != hipSuccess) return fail_hip(e, "launch k_inflate");
     // second pass, same stream: streams in which pass 1 met a dynamic-tree block (status 6) are redone, again one lane each
     // (k_inflate_tok<true>; HDLZ_INFLATE_BYTE_LOCKSTEP keeps round 1's pair: one wave per such stream); everything else is

@@ -36,9 +36,6 @@ struct InflateArgs {
     uint32_t* status;
 };
 
-// internal hand-over mark of the two-phase inflate (phase A -> the one-pass kernel); never returned
-constexpr uint32_t HDLZ_E_TOK_OVERFLOW = 0x100u;
-
 __host__ __device__ inline uint32_t out_bound(uint32_t n) {
     return 6u + (uint32_t)((9ull * n + 10ull + 7ull) >> 3);
 }
@@ -56,9 +53,6 @@ hipError_t launch_compress(const CompressArgs& a, hipStream_t stream);
 hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int ncu);
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t stream);
 hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream);
-hipError_t launch_inflate_tok_list(const InflateArgs& a, const uint32_t* list, const uint32_t* list_n, uint64_t max_n, hipStream_t stream);
-// two-phase lane-per-stream inflate for small streams (hdlz_inflate_two.hip); *used = false: not eligible / no scratch, nothing was done
-hipError_t launch_inflate_two(const InflateArgs& a, hipStream_t stream, bool* used);
 hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool all);
 hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used);
 hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream, bool all, const uint32_t* few_n = nullptr, uint32_t lane_min = 0);

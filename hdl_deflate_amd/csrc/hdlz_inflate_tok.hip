@@ -31,14 +31,8 @@
 #include "hdlz_device.h"
 #include "hdlz_inflate_tables.h"
 
-#ifndef HDLZ_TOK_NS
-#define HDLZ_TOK_NS tok
-#endif
 namespace hdlz {
-namespace HDLZ_TOK_NS {
-#ifdef HDLZ_TOK_PHASE_A
-using namespace ::hdlz::tok;          // (hdlz_inflate_tables.h)
-#endif
+namespace tok {
 
 #ifndef HDLZ_TOK_RING
 #define HDLZ_TOK_RING 128
@@ -48,21 +42,11 @@ constexpr uint32_t RING_DW = RINGB / 4;
 constexpr uint32_t NEAR = RINGB - 16;         // distances up to this are served from the ring: NEAR + 3 (dword alignment of the
                                               // source) + 12 (the unmasked write ahead of the end) < RINGB
 constexpr uint32_t CHUNK = RINGB >= 128u ? 64u : RINGB / 2u;   // bytes per flush
-#ifndef HDLZ_TOK_MOVES
-#define HDLZ_TOK_MOVES 3
-#endif
-#ifdef HDLZ_TOK_FLUSH_ROUND                   // A/B: ONE flush check per round, behind the move loop (see there)
-constexpr uint32_t URGENT = RINGB - 40u - 8u * (HDLZ_TOK_MOVES - 1u);   // the third chunk of a far copy (o - dist + 16 .. + 24) must be flushed
-#else                                         // in the LAST move iteration too: u + 8 (MOVES - 1) + 24 <= NEAR + 1
 constexpr uint32_t URGENT = RINGB - 44;       // a lane with this many unflushed bytes forces a flush (+3 per move, +8 written ahead,
                                               // and the far prefetch reads 24 bytes from o - dist on: they must be flushed)
-#endif
 constexpr uint32_t SLOT_DW = 4;               // input dwords fetched per lane and refill
-#ifndef HDLZ_TOK_BATCH
-#define HDLZ_TOK_BATCH 16
-#endif
-constexpr uint32_t BATCH = HDLZ_TOK_BATCH;    // lanes with a complete line that start a flush
-constexpr uint32_t MOVES = HDLZ_TOK_MOVES;    // move iterations (up to 8 bytes per lane each) per round; 2 / 3 / 4 / 6: 4.21 / 3.95 / 4.10 / 3.99 ms
+constexpr uint32_t BATCH = 16;             // lanes with a complete line that start a flush
+constexpr uint32_t MOVES = 3;              // move iterations (up to 8 bytes per lane each) per round; 2 / 3 / 4 / 6: 4.21 / 3.95 / 4.10 / 3.99 ms
 #ifdef HDLZ_TOK_MARKS                         // tools/phase_count.py --src hdlz_inflate_tok.hip -DHDLZ_TOK_MARKS: static counts per part
 #define TOK_MARK(name) asm volatile("; @@PHASE " name ::: "memory")
 #else
@@ -178,17 +162,9 @@ __device__ __forceinline__ void x_decode(const uint32_t (&X)[NL], uint32_t bits,
     idx = (m & 511u) - ((m >> 16) >> (15u - len));
 }
 
-#ifdef HDLZ_TOK_WAVES                          // A/B builds: force an occupancy (waves per SIMD) on every instantiation
-#define HDLZ_TOK_ATTR __attribute__((amdgpu_waves_per_eu(HDLZ_TOK_WAVES, HDLZ_TOK_WAVES)))
-#else
-#define HDLZ_TOK_ATTR
-#endif
 template <bool DYN, uint32_t CAP>
-__global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(InflateArgs a, const uint32_t* __restrict__ list,
+__global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, const uint32_t* __restrict__ list,
                                                                 const uint32_t* __restrict__ list_n, uint32_t lane_min
-#ifdef HDLZ_TOK_PHASE_A
-                                                                , uint8_t* __restrict__ tokbuf, uint32_t tpitch, uint32_t* __restrict__ tok_len
-#endif
                                                                 ) {
     constexpr uint32_t WAVES = Lds<DYN, CAP>::WAVES;
     __shared__ Lds<DYN, CAP> lds;
@@ -221,12 +197,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
         }
     }
     const uint8_t* __restrict__ z = a.in + off;
-#ifdef HDLZ_TOK_PHASE_A
-    uint8_t* out = tokbuf + sid * tpitch;              // (the ring is flushed into the token buffer)
-    const uint32_t tcap = tpitch;
-#else
     uint8_t* out = a.out + sid * a.out_pitch;
-#endif
     uint8_t* ring8 = reinterpret_cast<uint8_t*>(lds.ring[wave]);
     const uint32_t lane4 = lane << 2;
     const uint32_t cap = a.out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00u : (uint32_t)a.out_pitch;   // o + 258 never wraps
@@ -246,20 +217,6 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
     uint32_t ip = 2;            // D0: next byte to load; the 2 zlib header bytes are skipped unvalidated
     uint32_t sbase = 2;         // first stream byte held by this lane's input slot
     uint32_t o = 0;             // bytes produced by THIS lane
-#ifdef HDLZ_TOK_PHASE_A
-    // phase A of the two-phase inflate (hdlz_inflate_two.hip includes this file with HDLZ_TOK_PHASE_A): the lane writes its TOKENS,
-    // one record per round, through the same ring + flush into `tokbuf` and reads no history at all; `vo` is the output position
-    // the reference's checks see, `o` the position in the token stream
-    uint32_t vo = 0;
-#define TOK_OPOS vo
-#else
-#define TOK_OPOS o
-#endif
-#ifdef HDLZ_TOK_PHASE_A
-#define TOK_FAR(d) false
-#else
-#define TOK_FAR(d) ((d) > NEAR)
-#endif
     uint32_t flushed = 0;       // ... of which in HBM (a multiple of 64)
     uint32_t pend = 0;          // the valid low bytes of the ring dword that holds position o
     uint32_t rem = 0, dist = 0; // pending LZ copy
@@ -506,14 +463,6 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
         for (uint32_t mvi = 0; mvi < MOVES && __ballot(exists && (litn != 0u || rem != 0u)) != 0ull; mvi++) {
             const bool mv = exists && (litn != 0u || rem != 0u);
             if (mv) {
-#ifdef HDLZ_TOK_PHASE_A
-                // ONE RECORD per round: a 4-byte header -- literals 0..3 | match length << 2 (0 = none) | (distance - 1) << 11 --
-                // and the literal bytes behind it (hdlz_inflate_two.hip: k_emit replays the records with the output in LDS)
-                uint32_t v = litn | (rem << 2) | ((dist - 1u) << 11), vhi = litv, k = 4u + litn;
-                vo += litn + rem;
-                rem = 0u;
-                if (o + 8u > tcap) { status = HDLZ_E_TOK_OVERFLOW; out_len = 0; active = false; k = 0u; }   // -> the one-pass kernel
-#else
                 uint32_t v = litv, vhi = 0, k = litn;              // 1..3 literals, or
                 if (litn == 0u) {
                     const uint32_t src = o - dist;
@@ -534,7 +483,6 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
                     }
                     rem -= k;
                 }
-#endif
                 litn = 0;
                 // eight bytes at position o, unmasked; `pend` holds the valid low bytes of the dword at o
                 const uint32_t s8 = (o & 3u) * 8u;
@@ -550,15 +498,8 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
                 const uint32_t nd = q1 >= 8u ? d2 : q1 >= 4u ? d1 : d0;
                 pend = nd & ((1u << ((q1 & 3u) * 8u)) - 1u);
             }
-#ifndef HDLZ_TOK_FLUSH_ROUND
             TOK_FLUSH();
-#endif
         }
-#ifdef HDLZ_TOK_FLUSH_ROUND
-        // the flush stores are issued where the refill and the decode follow, not another move iteration: hipcc waits vmcnt(0) in
-        // every move iteration (the far chunks are loop-carried loads), and on gfx9 that also waits for the stores of a flush
-        TOK_FLUSH();
-#endif
         TOK_MARK("refill");
         // ------------------------------------------------------------ 0b. input refill (a lane waits only when it opens a new slot)
         {
@@ -619,7 +560,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
                 }
                 bool lt[3];                                        // a literal is taken while a buffered bit is left behind it
 #pragma unroll
-                for (int k = 0; k < 3; k++) lt[k] = vd[k] && sy[k] < 256u && of[k] + ln[k] < bc && TOK_OPOS + (uint32_t)k < cap;
+                for (int k = 0; k < 3; k++) lt[k] = vd[k] && sy[k] < 256u && of[k] + ln[k] < bc && o + (uint32_t)k < cap;
                 const uint32_t nl = !lt[0] ? 0u : !lt[1] ? 1u : !lt[2] ? 2u : 3u;
                 litv = (sy[0] & 255u) | ((sy[1] & 255u) << 8) | ((sy[2] & 255u) << 16);     // (bytes behind the nl-th are never used)
                 litn = nl;
@@ -643,14 +584,14 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
                 deb &= 15u;
                 const uint32_t distance = dbase + ((uint32_t)(x >> dnb) & ((1u << deb) - 1u));
                 const uint32_t mbits = tof + tln + leb + dnb + deb;
-                const uint32_t om = TOK_OPOS + nl;                 // where the copy will start
+                const uint32_t om = o + nl;                 // where the copy will start
                 const bool len_ok = tvd & (token < 29u) & dvd & (ds < 30u) & (mbits < bc) & (distance <= om) & (distance <= obsize) &
                                     (om + tlength <= cap);
                 const uint32_t take = len_ok ? mbits : tof;
                 bb >>= take; bc -= take;
                 if (len_ok) {
                     rem = tlength; dist = distance;
-                    if (TOK_FAR(distance)) {
+                    if (distance > NEAR) {
                         // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 < om - 96 <= flushed)
                         const u128_unaligned f16 = *reinterpret_cast<const u128_unaligned*>(out + (om - distance));
                         fpre = f16.lo; fpre2 = f16.hi;
@@ -663,7 +604,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
 #pragma unroll
                 for (uint32_t extra = 0; extra < 3u; extra++) {    // (the third look-up still has 33 - 9 - 9 = 15 valid bits;
                     const uint32_t e2 = lit_at((uint32_t)bb);      //  DYN: codes of up to 15 bits, taken while a bit is left behind)
-                    if (nl == extra && ((e2 >> 13) & 3u) == (uint32_t)T_LIT && TOK_OPOS + extra < cap && (!DYN || (e2 & 15u) < bc)) {
+                    if (nl == extra && ((e2 >> 13) & 3u) == (uint32_t)T_LIT && o + extra < cap && (!DYN || (e2 & 15u) < bc)) {
                         litv = extra == 0u ? ((e2 >> 4) & 0xFFu) : (litv | (((e2 >> 4) & 0xFFu) << (8u * extra)));
                         nl = extra + 1u;
                         bb >>= (e2 & 15u); bc -= (e2 & 15u);
@@ -681,13 +622,13 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
                 const uint32_t deb = (de >> 16) & 15u;
                 const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> dnb) & ((1u << deb) - 1u));
                 const uint32_t mbits = nb + leb + dnb + deb;
-                const uint32_t om = TOK_OPOS + nl;                 // where the copy will start
+                const uint32_t om = o + nl;                 // where the copy will start
                 const bool len_ok = (type == (uint32_t)T_LEN) & (mbits < bc) & (de < NO_DCODE) & (distance <= om) &
                                     (distance <= obsize) & (om + tlength <= cap);
                 if (len_ok) {
                     bb >>= mbits; bc -= mbits;
                     rem = tlength; dist = distance;
-                    if (TOK_FAR(distance)) {
+                    if (distance > NEAR) {
                         // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 < om - 96 <= flushed)
                         const u128_unaligned f16 = *reinterpret_cast<const u128_unaligned*>(out + (om - distance));
                         fpre = f16.lo; fpre2 = f16.hi;
@@ -725,7 +666,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
                         if (length == 0u) {
                             // COPY with nothing to copy (deflate.py:1617-1626)
                             if ((int32_t)(TOK_BITPOS() >> 3) >= isize) { TOK_FAIL(HDLZ_E_NO_EOF); break; }
-                            if (final_) { out_len = TOK_OPOS; active = false; break; }
+                            if (final_) { out_len = o; active = false; break; }
                             need_header = true;
                         }
                     } else {
@@ -745,12 +686,12 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
                 // INFLATE (deflate.py:1519-1591)
                 if ((int32_t)(TOK_BITPOS() >> 3) > isize - 3) { TOK_FAIL(HDLZ_E_NO_EOF); break; }   // :1535-1539
                 if (code == 256u) {
-                    if (final_) { out_len = TOK_OPOS; active = false; break; }   // D6
+                    if (final_) { out_len = o; active = false; break; }   // D6
                     need_header = true;
                     continue;
                 }
                 if (code < 256u) {
-                    if (TOK_OPOS >= cap) { TOK_FAIL(HDLZ_E_OUT_CAPACITY); break; }
+                    if (o >= cap) { TOK_FAIL(HDLZ_E_OUT_CAPACITY); break; }
                     litv = code; litn = 1;
                     break;
                 }
@@ -769,12 +710,12 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
                 const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)bb & ((1u << deb) - 1u));
                 bb >>= deb;
                 bc -= dnb + deb;
-                if (distance > TOK_OPOS || distance > obsize) { TOK_FAIL(HDLZ_E_BAD_DISTANCE); break; }        // D8
+                if (distance > o || distance > obsize) { TOK_FAIL(HDLZ_E_BAD_DISTANCE); break; }        // D8
                 if ((int32_t)(TOK_BITPOS() >> 3) >= isize - 2) { TOK_FAIL(HDLZ_E_NO_EOF); break; }      // COPY hold, :1600
-                if ((uint64_t)TOK_OPOS + tlength > cap) { TOK_FAIL(HDLZ_E_OUT_CAPACITY); break; }
+                if ((uint64_t)o + tlength > cap) { TOK_FAIL(HDLZ_E_OUT_CAPACITY); break; }
                 rem = tlength;
                 dist = distance;
-                if (TOK_FAR(distance)) {
+                if (distance > NEAR) {
                     const u128_unaligned f16 = *reinterpret_cast<const u128_unaligned*>(out + (o - distance));
                     fpre = f16.lo; fpre2 = f16.hi;
                 }
@@ -783,14 +724,14 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
             if (active && srem != 0u && litn == 0u && rem == 0u) {
                 TOK_REFILL();
                 if ((int32_t)(TOK_BITPOS() >> 3) >= isize) { TOK_FAIL(HDLZ_E_NO_EOF); }
-                else if (TOK_OPOS >= cap) { TOK_FAIL(HDLZ_E_OUT_CAPACITY); }
+                else if (o >= cap) { TOK_FAIL(HDLZ_E_OUT_CAPACITY); }
                 else {
                     litv = (uint32_t)bb & 0xFFu; litn = 1;
                     bb >>= 8; bc -= 8u;
                     srem--;
                     if (srem == 0u) {                              // the block ends with this byte (deflate.py:1617-1626)
                         if ((int32_t)(TOK_BITPOS() >> 3) >= isize) { TOK_FAIL(HDLZ_E_NO_EOF); litn = 0; }
-                        else if (final_) { out_len = TOK_OPOS + 1u; active = false; }      // (the byte is still emitted below)
+                        else if (final_) { out_len = o + 1u; active = false; }      // (the byte is still emitted below)
                         else need_header = true;
                     }
                 }
@@ -817,25 +758,16 @@ __global__ __launch_bounds__(DYN ? 64 : 256) HDLZ_TOK_ATTR void k_inflate_tok(In
 #undef TOK_REFILL
 #undef TOK_REQUEST
 #undef TOK_FLUSH
-#undef TOK_OPOS
-#undef TOK_FAR
 
     // no LDS-DMA load may still be in flight when this wave's LDS is handed to another workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- tail: the bytes behind the last flushed line are still only in the ring
     if (exists && status == HDLZ_OK) {
-#ifdef HDLZ_TOK_PHASE_A
-        for (uint32_t p = flushed; p < o; p++) out[p] = ring8[ring_addr(p, lane4)];
-#else
         for (uint32_t p = flushed; p < out_len; p++) out[p] = ring8[ring_addr(p, lane4)];
-#endif
     }
     if (exists) {
         a.out_len[sid] = out_len;
         a.status[sid] = status;
-#ifdef HDLZ_TOK_PHASE_A
-        tok_len[sid] = o;
-#endif
     }
 }
 
@@ -853,9 +785,8 @@ __global__ __launch_bounds__(256) void k_collect_dyn(const uint32_t* __restrict_
     if (mine) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)gid;
 }
 
-}  // namespace HDLZ_TOK_NS
+}  // namespace tok
 
-#ifndef HDLZ_TOK_PHASE_A
 hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
     if (a.nstreams == 0) return hipSuccess;
     typedef tok::Lds<false, tok::CAP_FULL> L;
@@ -863,16 +794,6 @@ hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
     const dim3 grid((unsigned)((a.nstreams + per_wg - 1u) / per_wg)), block(64 * L::WAVES);
     hipLaunchKernelGGL((tok::k_inflate_tok<false, tok::CAP_FULL>), grid, block, 0, stream, a, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, 0u);
-    return hipGetLastError();
-}
-
-// the streams list[0 .. *list_n) through the same kernel (hdlz_inflate_two.hip: what phase A handed back); `max_n` bounds *list_n
-hipError_t launch_inflate_tok_list(const InflateArgs& a, const uint32_t* list, const uint32_t* list_n, uint64_t max_n, hipStream_t stream) {
-    if (max_n == 0) return hipSuccess;
-    typedef tok::Lds<false, tok::CAP_FULL> L;
-    const uint64_t per_wg = 64u * L::WAVES;
-    const dim3 grid((unsigned)((max_n + per_wg - 1u) / per_wg)), block(64 * L::WAVES);
-    hipLaunchKernelGGL((tok::k_inflate_tok<false, tok::CAP_FULL>), grid, block, 0, stream, a, list, list_n, 0u);
     return hipGetLastError();
 }
 
@@ -919,6 +840,5 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
     return e != hipSuccess ? e : e2;
 }
 
-#endif  // HDLZ_TOK_PHASE_A
 
 }  // namespace hdlz

@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define HDLZ_VERSION 0x000301   /* round 3: same entry points; CWINDOW > 64 through the window-independent match finder, own scratch pool, HDLZ_E_OUT_CAPACITY from hdlz_inflate_chunk; 0x000301: HDLZ_INFLATE_TWO_PHASE */
+#define HDLZ_VERSION 0x000400   /* round 4: + hdlz_release_scratch (bounded scratch pool); hdlz_compact_batch accepts a pinned-host destination; the opt-in
+                                   two-phase inflate of 0x000301 (HDLZ_INFLATE_TWO_PHASE = 64) was measured slower than the one-pass kernel and is gone */
 
 /* command codes of the reference port surface (deflate.py:18) -- used by the adapter */
 enum { HDLZ_IDLE = 0, HDLZ_WRITE = 1, HDLZ_READ = 2, HDLZ_STARTC = 3, HDLZ_STARTD = 4 };
@@ -78,11 +79,6 @@ enum {
  * 32 = one output byte per lockstep iteration (k_inflate, the round-1 kernel) */
 #define HDLZ_INFLATE_TOKEN_ROUNDS 16u
 #define HDLZ_INFLATE_BYTE_LOCKSTEP 32u
-/* 64 = the two-phase form of the lane-per-stream mapping for SMALL streams (out_pitch <= 2048; results are identical): phase A
- * decodes one lane per stream into a token list in stream-ordered scratch (out_pitch + 64 .. + 319 bytes per stream, + 8), phase B
- * replays it with the stream's whole output in LDS -- no copy reads its history back from HBM (hdlz_inflate_two.hip).  Ignored
- * when out_pitch is larger or the scratch cannot be had. */
-#define HDLZ_INFLATE_TWO_PHASE 64u
 
 int hdlz_version(void);
 const char* hdlz_status_string(int status);

@@ -679,13 +679,12 @@ def test_inflate_auto_mapping_second_pass(engine, oracle):
             assert out[k, :ol[k]].tobytes() == sel[k][2], (case, k)
 
 
-def test_inflate_two_phase_small_streams(engine, oracle):
-    """HDLZ_INFLATE_TWO_PHASE (hdlz_inflate_two.hip: phase A writes token records, phase B replays them with the stream's output in
-    LDS): stock-zlib streams of every strategy / level over small blocks, stored blocks, multi-block streams, runs (distance 1),
-    damaged and cut streams, capacities below the output size, token lists that overflow (incompressible blocks go back through
-    the one-pass kernel) -- status, length and bytes of EVERY stream equal the oracle, in both builds (DYNAMIC=False / True)"""
+def test_inflate_small_streams_every_kind(engine, oracle):
+    """small streams of every kind (strategy / level / wbits, stored and multi-block streams, distance-1 runs, damaged and cut streams,
+    capacities below the output size, both builds) through every mapping: status + length + bytes of every stream against the oracle
+    (written for round 3's two-phase inflate, which is gone; the batch is kept for the kernels that stayed)"""
     import torch
-    from hdl_deflate_amd import INFLATE_LANE_PER_STREAM, INFLATE_TWO_PHASE, INFLATE_ASSUME_FIXED
+    from hdl_deflate_amd import INFLATE_ASSUME_FIXED
     from hdl_deflate_amd.data import make_blocks
     r = random.Random(11)
     B = 2048
@@ -717,12 +716,13 @@ def test_inflate_two_phase_small_streams(engine, oracle):
         zin, zoff = torch.from_numpy(flat).cuda(), torch.from_numpy(off).cuda()
         for fl in (0, INFLATE_ASSUME_FIXED):
             ref, rl, rs = oracle.inflate_batch(flat, off.astype(np.uint64), pitch, flags=fl, nthreads=8)
-            out, ol, st = engine.inflate_batch(zin, in_off=zoff, out_pitch=pitch, flags=fl | INFLATE_LANE_PER_STREAM | INFLATE_TWO_PHASE)
-            torch.cuda.synchronize()
-            assert np.array_equal(st.cpu().numpy().astype(np.uint32), rs), (rd, fl)
-            assert np.array_equal(ol.cpu().numpy().astype(np.uint32), rl), (rd, fl)
             m = np.arange(pitch)[None, :] < rl[:, None]
-            assert np.array_equal(out.cpu().numpy()[m], ref[m]), (rd, fl)
+            for mapping in MAPPINGS:
+                out, ol, st = engine.inflate_batch(zin, in_off=zoff, out_pitch=pitch, flags=fl | mapping)
+                torch.cuda.synchronize()
+                assert np.array_equal(st.cpu().numpy().astype(np.uint32), rs), (rd, fl, mapping)
+                assert np.array_equal(ol.cpu().numpy().astype(np.uint32), rl), (rd, fl, mapping)
+                assert np.array_equal(out.cpu().numpy()[m], ref[m]), (rd, fl, mapping)
             assert len(set(rs.tolist())) >= 3           # (the batch really holds good, cut and damaged streams)
 
 
