@@ -52,6 +52,20 @@ constexpr uint32_t MOVES = 3;              // move iterations (up to 8 bytes per
 #else
 #define TOK_MARK(name) do {} while (0)
 #endif
+#ifdef HDLZ_TOK_TIMING                        // diagnostic build (tools/exp_tok_timing.py): s_memtime per part of the round; lanes 0..7 of every
+                                              // wave report the wave's totals in out_len / status instead of their results
+#define TOK_TIME_DECL() uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter()
+#define TOK_TIME(k) do { const uint64_t t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#define TOK_TIME_ROUND() tacc[7] += 1u
+#define TOK_TIME_REPORT() do { TOK_TIME(4); if (exists && lane < 8u) { uint64_t v_ = 0;                      \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; k_++) v_ = lane == (uint32_t)k_ ? tacc[k_] : v_;             \
+        a.out_len[gid] = (uint32_t)v_; a.status[gid] = (uint32_t)(v_ >> 32); } } while (0)   /* (by grid lane, not by stream) */
+#else
+#define TOK_TIME_DECL() do {} while (0)
+#define TOK_TIME(k) do {} while (0)
+#define TOK_TIME_ROUND() do {} while (0)
+#define TOK_TIME_REPORT() do {} while (0)
+#endif
 
 // DYN: per-lane tables in LDS, rows of 64 dwords (row j of lane l = dword j * 64 + l: every lane stays in its own bank): only the
 // literal/length symbols, sorted by (code length, value) -- CAP low bytes and CAP ninth bits.  Everything else a lane needs of its
@@ -452,8 +466,10 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
 
     if (active) { TOK_REQUEST(issued + 1u); }
     if (__ballot(active && sbase + 16u <= zn) != 0ull) issued += 1u;
+    TOK_TIME_DECL();
 
     for (;;) {
+        TOK_TIME(5);
         TOK_MARK("move");
         // ------------------------------------------------------------ 0. move the bytes of the tokens decoded in the PREVIOUS round: up to
         // eight per lane and iteration.  (Moving first, decoding after: the far history a token needs was requested when it was
@@ -499,7 +515,9 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 pend = nd & ((1u << ((q1 & 3u) * 8u)) - 1u);
             }
             TOK_FLUSH();
+            TOK_TIME(6);                    /* (counted into [0] too: tacc[6] = the flush's share is not separable without a second read) */
         }
+        TOK_TIME(0);
         TOK_MARK("refill");
         // ------------------------------------------------------------ 0b. input refill (a lane waits only when it opens a new slot)
         {
@@ -527,6 +545,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 }
             }
         }
+        TOK_TIME(1);
         TOK_MARK("decode");
         // ------------------------------------------------------------ 1a. fast path: up to three literals and then a match, inside a
         // fixed block.  (One token per round made the literal-heavy streams the lanes the whole wave waits for: 362 -> 390 GB/s with
@@ -641,6 +660,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 slow = true;                                        // header, end of the input
             }
         }
+        TOK_TIME(2);
         TOK_MARK("slow");
         // ------------------------------------------------------------ 1b. slow path (wave-uniform branch, rare)
         if (__ballot(slow || (active && srem != 0u)) != 0ull) {
@@ -737,6 +757,8 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 }
             }
         }
+        TOK_TIME(3);
+        TOK_TIME_ROUND();
         TOK_MARK("loopend");
         if (__ballot(active || rem != 0u || litn != 0u) == 0ull) break;
     }
@@ -769,6 +791,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         a.out_len[sid] = out_len;
         a.status[sid] = status;
     }
+    TOK_TIME_REPORT();
 }
 
 // the streams pass 1 flagged HDLZ_E_DYNAMIC_UNSUPPORTED, as a dense list: the lanes of k_inflate_tok<true> are then all busy whatever
@@ -785,6 +808,57 @@ __global__ __launch_bounds__(256) void k_collect_dyn(const uint32_t* __restrict_
     if (mine) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)gid;
 }
 
+// ---- length-binned lane assignment (round 4).  The 64 streams of a wave run in lockstep until the LAST of them is done, and a
+// round costs the same whatever its lanes have to do: a wave of mixed streams pays the rounds of its longest stream with the
+// instruction mix of its most demanding one (BASELINE configs[4] read back, blocks of four families side by side: 85.7 M cycles per
+// wave against 57 M / 40 M for waves of one family, profiles/r04_tok_round_timing.txt).  With a ragged archive the compressed
+// lengths are known before the launch, so the streams are handed to the lanes in the order of their length class -- quarter octaves,
+// longest first (the long streams start first, the short ones fill the tail): a counting sort in three small launches, the
+// permutation in stream-ordered scratch.  The order inside a class is whatever the atomics give: streams are independent,
+// results do not depend on it.
+constexpr uint32_t NBIN = 128;
+__device__ __forceinline__ uint32_t len_bin(uint64_t len64) {
+    const uint32_t l = (uint32_t)(len64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : len64) | 4u;
+    const uint32_t msb = 31u - (uint32_t)__builtin_clz(l);
+    return (NBIN - 1u) - (4u * msb + ((l >> (msb - 2u)) & 3u));        // bin 0 = the longest streams
+}
+__global__ __launch_bounds__(256) void k_bin_hist(const uint64_t* __restrict__ in_off, uint32_t n, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[NBIN];
+    if (threadIdx.x < NBIN) lh[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) atomicAdd(&lh[len_bin(in_off[i + 1] - in_off[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < NBIN && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+// hist[0 .. NBIN) -> first slot per class (in place); ws[NBIN] = n (the list length the decode kernel reads)
+__global__ __launch_bounds__(64) void k_bin_scan(uint32_t* __restrict__ ws, uint32_t n) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c0 = ws[2u * lane], c1 = ws[2u * lane + 1u];
+    uint32_t v = c0 + c1;
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const uint32_t o = __shfl_up(v, ofs, 64);
+        if (lane >= (uint32_t)ofs) v += o;
+    }
+    const uint32_t excl = v - (c0 + c1);
+    ws[2u * lane] = excl; ws[2u * lane + 1u] = excl + c0;
+    if (lane == 0u) ws[NBIN] = n;
+}
+__global__ __launch_bounds__(256) void k_bin_scatter(const uint64_t* __restrict__ in_off, uint32_t n, uint32_t* __restrict__ cursor,
+                                                      uint32_t* __restrict__ list) {
+    __shared__ uint32_t lh[NBIN], lbase[NBIN];
+    if (threadIdx.x < NBIN) lh[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t bin = 0, rank = 0;
+    if (i < n) { bin = len_bin(in_off[i + 1] - in_off[i]); rank = atomicAdd(&lh[bin], 1u); }
+    __syncthreads();
+    if (threadIdx.x < NBIN && lh[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], lh[threadIdx.x]);
+    __syncthreads();
+    if (i < n) list[lbase[bin] + rank] = i;
+}
+
 }  // namespace tok
 
 hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
@@ -792,6 +866,27 @@ hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
     typedef tok::Lds<false, tok::CAP_FULL> L;
     const uint64_t per_wg = 64u * L::WAVES;
     const dim3 grid((unsigned)((a.nstreams + per_wg - 1u) / per_wg)), block(64 * L::WAVES);
+    // ragged input of more than one wave: the lanes take the streams in the order of their length class (see k_bin_*)
+    if (a.in_off && a.nstreams > HDLZ_INFLATE_BIN_MIN && a.nstreams <= 0xFFFFFFFFull) {
+        uint32_t* ws = nullptr;                  // ws[0 .. NBIN): counts, then cursors; ws[NBIN]: n; the list from ws + NBIN + 1 on
+        const uint32_t n = (uint32_t)a.nstreams;
+        hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * ((size_t)n + tok::NBIN + 1u), stream);
+        if (e == hipSuccess) {
+            e = zero_words(ws, tok::NBIN, stream);
+            if (e == hipSuccess) {
+                const dim3 bgrid((n + 255u) / 256u), bblock(256);
+                hipLaunchKernelGGL(tok::k_bin_hist, bgrid, bblock, 0, stream, a.in_off, n, ws);
+                hipLaunchKernelGGL(tok::k_bin_scan, dim3(1), dim3(64), 0, stream, ws, n);
+                hipLaunchKernelGGL(tok::k_bin_scatter, bgrid, bblock, 0, stream, a.in_off, n, ws, ws + tok::NBIN + 1u);
+                hipLaunchKernelGGL((tok::k_inflate_tok<false, tok::CAP_FULL>), grid, block, 0, stream, a,
+                                   (const uint32_t*)(ws + tok::NBIN + 1u), (const uint32_t*)(ws + tok::NBIN), 0u);
+                e = hipGetLastError();
+            }
+            const hipError_t e2 = hipFreeAsync(ws, stream);
+            return e != hipSuccess ? e : e2;
+        }
+        (void)hipGetLastError();                 // no scratch: stream order
+    }
     hipLaunchKernelGGL((tok::k_inflate_tok<false, tok::CAP_FULL>), grid, block, 0, stream, a, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, 0u);
     return hipGetLastError();

@@ -70,6 +70,11 @@ enum {
 #define HDLZ_INFLATE_WAVE_PER_STREAM 4u
 #define HDLZ_INFLATE_WAVE_THRESHOLD 22528u
 #define HDLZ_INFLATE_DYN_LANE_MIN 28672u
+/* lane mapping, ragged input (d_in_off given) of more than this many streams: the lanes take the streams in the order of their
+ * compressed-length class (a counting sort on the device, 4 bytes per stream of stream-ordered scratch; stream order if that
+ * allocation fails) -- a wave runs as long as its longest stream, so streams of similar length share a wave.  Results are
+ * identical; the output rows stay where their stream index puts them. */
+#define HDLZ_INFLATE_BIN_MIN 64u
 /* a batch of ONE stream of at least this many bytes (fixed-pitch form, no mapping hint) is cut into 1 KiB pieces and decoded by
  * the whole GPU when it is a single fixed-Huffman block -- the streams STARTC writes --, else by one wave as before (decided on
  * the device, same results); scratch: stream-ordered, 8 bytes per possible output byte (min(out_pitch, 172 * in_len)).
