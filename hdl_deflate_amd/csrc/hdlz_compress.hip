@@ -42,7 +42,7 @@ namespace hdlz {
 // carried from a previous tile, no carried bit / Adler state
 template <int NCH, bool FULLWIN, bool ONE_TILE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH>(), waves_eu<NCH>()))) void k_compress(CompressArgs a) {
-    constexpr bool HASH = wide_hash<NCH>();         // windows > 32 (64: see HDLZ_CW64_BRUTE): the window-independent finder
+    constexpr bool HASH = wide_hash<NCH>();         // windows > 32: the window-independent finder
     __shared__ typename std::conditional<HASH, WaveLdsNoOut, WaveLds>::type lds;
     __shared__ typename std::conditional<HASH, HashLds<NCH>, uint32_t>::type hl;
     // the bit buffer of a tile: HASH kernels keep it in the finder's transposition buffer, which is dead once best[] is in registers

@@ -9,9 +9,6 @@
 namespace hdlz {
 
 // waves per SIMD the CWINDOW <= 32 kernels are register-capped for (96 VGPRs at 5)
-#ifndef HDLZ_W2
-#define HDLZ_W2 4                             // waves per SIMD of the CWINDOW = 64 kernels
-#endif
 #ifndef HDLZ_W1
 #define HDLZ_W1 5
 #endif
@@ -134,57 +131,6 @@ __device__ __forceinline__ void load_own(const uint32_t* in, uint32_t run_dw, ui
 // bytes are the register peak of the whole kernel; later phases reload the 48 bytes from LDS, three ds_read_b128.)
 template <int NCH>
 __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw, uint32_t (&best)[RUN]) {
-#ifndef HDLZ_CW64_TWO_PASSES
-    if constexpr (NCH == 2) {
-        // CWINDOW = 64 in ONE pass: with the tag at scale 2 (2 * window index <= 190) the 95 candidate positions of a run fit the
-        // key's tag byte, so there is no second chunk, no best[] beside the running minima and no set-up twice.  Own index i pairs
-        // with candidates j in [i, i + 63]; candidate j >= 64 IS own position j - 64 (same tag 2j); the minimum is 2 * distance.
-        uint32_t ko[RUN], cd[17];
-        {
-            uint32_t ow[12];
-            load_own(in, run_dw, ow);
-            static_for<0, RUN>([&](auto I) { constexpr int i = decltype(I)::value; ko[i] = key3<i>(ow, (uint32_t)(2 * (i + 64))); });
-            const uint32_t cdw = run_dw - 16u;
-            const uint4 c0 = *reinterpret_cast<const uint4*>(&in[cdw]), c1 = *reinterpret_cast<const uint4*>(&in[cdw + 4]);
-            const uint4 c2 = *reinterpret_cast<const uint4*>(&in[cdw + 8]), c3 = *reinterpret_cast<const uint4*>(&in[cdw + 12]);
-            cd[0] = c0.x; cd[1] = c0.y; cd[2] = c0.z; cd[3] = c0.w; cd[4] = c1.x; cd[5] = c1.y; cd[6] = c1.z; cd[7] = c1.w;
-            cd[8] = c2.x; cd[9] = c2.y; cd[10] = c2.z; cd[11] = c2.w; cd[12] = c3.x; cd[13] = c3.y; cd[14] = c3.z; cd[15] = c3.w;
-            cd[16] = ow[0];                                   // candidate 63 needs the first own bytes
-        }
-        pin(ko);
-        PHASE_FENCE();
-        uint32_t (&m)[RUN] = best;
-#pragma unroll
-        for (int i = 0; i < RUN; i++) m[i] = 0xFFFFFFFFu;
-        static_for<0, 95>([&](auto J) {
-            constexpr int j = decltype(J)::value;             // handles candidates j and j+1 (j even)
-            if constexpr ((j & 1) == 0) {
-                uint32_t kc0, kc1;
-                if constexpr (j >= 64) {
-                    asm volatile("" : "+v"(ko[j - 64]), "+v"(ko[j - 63 > 31 ? 31 : j - 63]));
-                    kc0 = ko[j - 64];
-                    kc1 = ko[j - 63 > 31 ? 31 : j - 63];
-                } else {
-                    kc0 = key3<j>(cd, (uint32_t)(2 * j));
-                    kc1 = key3<j + 1>(cd, (uint32_t)(2 * (j + 1)));
-                }
-                static_for<0, RUN>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    constexpr bool use0 = (j >= i) && (j <= i + 63);
-                    constexpr bool use1 = (j + 1 >= i) && (j + 1 <= i + 63);
-                    if constexpr (use0 && use1) m[i] = umin3(m[i], ko[i] - kc0, ko[i] - kc1);
-                    else if constexpr (use0) m[i] = min(m[i], ko[i] - kc0);
-                    else if constexpr (use1) m[i] = min(m[i], ko[i] - kc1);
-                });
-                if constexpr ((j & 7) == 6) { pin(m); PHASE_FENCE(); }
-            }
-        });
-        // 2 * distance -> the 4 * distance make_tokens reads; "none" (>= 256) -> a value its position test rejects
-#pragma unroll
-        for (int i = 0; i < RUN; i++) best[i] = m[i] < 256u ? m[i] << 1 : 0xFFFFFFFFu;
-        return;
-    }
-#endif
     uint32_t ko[RUN];
     uint32_t ow0;
     {
@@ -262,12 +208,16 @@ __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw
 // is a predecessor query; its cost need not grow with the window.  match_search pays 1.5 VALU instructions per (position,
 // distance) pair -- 48 per position at CWINDOW = 32, 384 at 256.  Here the tile is walked in ROUNDS of 64 consecutive positions,
 // one lane per position, through three LDS structures:
-//   T[h]    last position with hash h among the rounds before the current one (updated by ds_max_u32: order-independent);
-//   B[l]    the lanes of the CURRENT round that share a hash, as a 64-bit map kept at the slot of their LEADER: after the round's
-//           ds_max every lane of the class reads T[h] back -- the class's last lane, the leader they all agree on; ds_or_b64 into
-//           B[leader], read back, cleared.  The highest set bit below the own lane is the nearest previous position of the same
-//           round -- deterministic, no reliance on the order in which the LDS serialises same-address atomics.  (A map per BUCKET -- the first version -- cost 8 bytes per bucket
-//           and capped the table at 512 buckets; 64 maps cost 512 bytes, and leader slots are distinct addresses: no conflicts.)
+//   T[h]    last position with hash h so far.  ONE returning atomic per position -- old = ds_max_rtn_u32(T[h], own position) -- both
+//           inserts the position and answers "previous position of my hash class", INCLUDING the up to 63 nearer members of the
+//           same round, if the LDS applies the lanes of a wave instruction to one address in lane order: the positions of a round
+//           rise with the lane.  That order is not architected, so it is CHECKED instead of assumed: if a later lane b is applied
+//           before an earlier lane a of the same class, a reads back a value >= position(b) > its own position -- every inversion
+//           shows up as a negative distance in some lane.  A group of rounds that saw one is redone by a 64-step readlane loop (the
+//           minimum of the values a class got back is the table entry before the round; the nearest lower lane of the class the
+//           candidate inside the round): exact whatever the hardware does, and T's final content (a maximum) never depends on the
+//           order.  (Round 3 read T, ds_max-ed, read the class's LEADER back and kept a 64-bit lane map per leader slot -- six LDS
+//           operations and ~15 VALU instructions per round instead of one and two: the LDS was 65 % busy, VERDICT r3 #2.)
 //   E[p]    (distance from p to the previous position with the same HASH) - 1 as one byte, 255 = none or >= 256: every hash class
 //           is a chain in descending position order.
 // h = the top HB bits of (K * odd) mod 2^24 (K = the three bytes): a bijection of the key, well mixed in its high bits.  A lane
@@ -293,7 +243,6 @@ template <int NCH> struct __attribute__((aligned(16))) HashLds {
         uint32_t T[HashCfg<NCH>::NT];
         uint16_t D[TILE];                   // the results on their way from the round layout to the run layout
     };
-    uint64_t B[64];                         // zero between rounds
     uint16_t E[HALO + TILE];                // per position: eight tag bits of the key << 8 | link
     static_assert(sizeof(uint32_t) * HashCfg<NCH>::NT >= sizeof(uint16_t) * TILE, "D overlays T");
 };
@@ -310,9 +259,7 @@ __device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NC
     constexpr uint32_t base = HALO - PRE;
     // empty table (it was the transposition buffer and the bit buffer of the previous tile)
     for (uint32_t k = lane * 4u; k < (uint32_t)NT; k += 256u) *reinterpret_cast<uint4*>(&hl.T[k]) = make_uint4(0, 0, 0, 0);
-    hl.B[lane] = 0ull;
     __syncthreads();
-    const uint64_t bit = 1ull << lane, lower = bit - 1ull;
 
     // Rounds are batched in groups of G: the LDS executes a wave's instructions in order, so the table operations of G rounds
     // are ISSUED back to back (round r+1's T read behind round r's ds_max) and their results are consumed afterwards -- one
@@ -326,12 +273,16 @@ __device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NC
     uint32_t res2[RUN / 2];                  // round layout, two rounds per register: 4 * distance of position 64 r + lane, 16 bits each
     // A group's work comes in three pieces: issue (key, hash, the table operations), consume (first candidate, chain entry) and
     // walk (the chain steps of its queries).  (Issuing group g+1 before walking group g changed nothing measurable.)
-    struct Grp { uint32_t kw[G], ow[G], c0[G], dd[G]; uint64_t bm[G]; };
+    struct Grp { uint32_t kw[G], ow[G], c0[G], dd[G]; };
+    auto hash_of = [&](uint32_t kw, uint32_t& tag) -> uint32_t {
+        uint32_t mix;
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(mix) : "v"(kw), "v"(0x9E3779u));     // (ignores the top byte; hipcc picks the quarter-rate v_mul_lo_u32)
+        tag = (mix << (HB - 8)) & 0xFF00u;                    // the eight bits BELOW the hash bits of (K * odd) mod 2^24, as the entry's tag
+        return __builtin_amdgcn_ubfe(mix, 24 - HB, HB);
+    };
     auto issue = [&](auto G0, auto CNT, Grp& q) {             // rounds [g0, g0 + cnt), counted from position `base`
         constexpr int g0 = decltype(G0)::value, cnt = decltype(CNT)::value;
-        // three stages, each over all rounds of the group, so that a stage's LDS operations are in flight together: the leader's
-        // slot address depends on a table read-back, and a round-by-round order would wait for two round trips per round
-        uint32_t w0_[cnt], w1_[cnt], lead_[cnt];
+        uint32_t w0_[cnt], w1_[cnt];
         static_for<0, cnt>([&](auto J) {
             constexpr int j = decltype(J)::value;
             const uint32_t idx = base + 64u * (uint32_t)(g0 + j) + lane;      // byte index of the position in `in`
@@ -340,33 +291,48 @@ __device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NC
         static_for<0, cnt>([&](auto J) {
             constexpr int j = decltype(J)::value;
             constexpr uint32_t rbase = base + 64u * (uint32_t)(g0 + j);
-            const uint32_t idx = rbase + lane;
             q.kw[j] = alignbyte(w1_[j], w0_[j], lane);                        // (rbase is a multiple of 4) the key is its low three bytes
-            uint32_t mix;
-            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(mix) : "v"(q.kw[j]), "v"(0x9E3779u));     // (ignores the top byte; hipcc picks the quarter-rate v_mul_lo_u32)
-            q.ow[j] = (mix << (HB - 8)) & 0xFF00u;            // the eight bits BELOW the hash bits of (K * odd) mod 2^24, as the entry's tag
-            const uint32_t h = __builtin_amdgcn_ubfe(mix, 24 - HB, HB);
-            q.c0[j] = __hip_atomic_load(&hl.T[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            // the last position of the hash class: what the next rounds must find -- and the leader its lanes agree on
-            __hip_atomic_fetch_max(&hl.T[h], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            lead_[j] = __hip_atomic_load(&hl.T[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - rbase;
+            const uint32_t h = hash_of(q.kw[j], q.ow[j]);
+            // insert the position and get the previous one of the hash class back (the rounds of a group back to back: the LDS
+            // executes a wave's instructions in order)
+            q.c0[j] = __hip_atomic_fetch_max(&hl.T[h], rbase + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         });
-        static_for<0, cnt>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            __hip_atomic_fetch_or(&hl.B[lead_[j]], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            q.bm[j] = __hip_atomic_load(&hl.B[lead_[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&hl.B[lead_[j]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        });
+    };
+    // (never taken on this hardware so far: see the head of this section) the previous position of the hash class of every lane of
+    // one round, from the values the atomics returned, whatever order they were applied in
+    auto reorder = [&](uint32_t rbase, uint32_t kw, uint32_t got) -> uint32_t {
+        uint32_t tag;
+        const uint32_t h = hash_of(kw, tag);
+        uint32_t before = got, nearer = 0u;
+        bool has = false;
+#pragma unroll 1
+        for (uint32_t s_ = 0; s_ < 64u; s_++) {
+            const uint32_t hs = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)s_), gs = (uint32_t)__builtin_amdgcn_readlane((int)got, (int)s_);
+            if (hs == h) {
+                before = min(before, gs);
+                if (s_ < lane) { nearer = rbase + s_; has = true; }
+            }
+        }
+        return has ? nearer : before;
     };
     auto consume = [&](auto G0, auto CNT, Grp& q) {
         constexpr int g0 = decltype(G0)::value, cnt = decltype(CNT)::value;
+        uint32_t inv = 0;                                     // sign bit: some lane got a position behind its own back
+        static_for<0, cnt>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            inv |= (base + 64u * (uint32_t)(g0 + j) + lane) - q.c0[j];
+        });
+        if (__ballot((int32_t)inv < 0) != 0ull) {
+            static_for<0, cnt>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                q.c0[j] = reorder(base + 64u * (uint32_t)(g0 + j), q.kw[j], q.c0[j]);
+            });
+        }
         static_for<0, cnt>([&](auto J) {
             constexpr int j = decltype(J)::value;
             constexpr uint32_t rbase = base + 64u * (uint32_t)(g0 + j);
             const uint32_t idx = rbase + lane;
-            const uint64_t below = q.bm[j] & lower;
-            const uint32_t c = below != 0ull ? rbase + 63u - (uint32_t)__builtin_clzll(below) : q.c0[j];
-            const uint32_t d = idx - c;                       // (an empty T entry reads as position 0: a distance that is either outside
+            const uint32_t d = idx - q.c0[j];                 // (an empty T entry reads as position 0: a distance that is either outside
                                                               //  the window or leads to a real position whose key is then compared)
             hl.E[idx] = (uint16_t)(q.ow[j] | min(d - 1u, 255u));
             q.dd[j] = (d - 1u) < cw ? d : 0u;                 // 0 = this lane has nothing (more) to look at
@@ -483,14 +449,8 @@ __device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NC
 #ifndef HDLZ_WH
 #define HDLZ_WH 3                               // waves per SIMD of the kernels with the hash finder (13.6 KB of LDS per wave: 12 per CU)
 #endif
-template <int NCH> constexpr bool wide_hash() {
-#ifdef HDLZ_CW64_HASH
-    return NCH > 1;      // CWINDOW = 64 through the hash finder: 237 / 211 GB/s (text / families) against 247 for the one-pass brute force
-#else
-    return NCH > 2;
-#endif
-}
-template <int NCH> constexpr int waves_eu() { return NCH == 1 ? HDLZ_W1 : wide_hash<NCH>() ? HDLZ_WH : NCH == 2 ? HDLZ_W2 : 4; }
+template <int NCH> constexpr bool wide_hash() { return NCH > 1; }      // every window > 32 (round 4: CWINDOW = 64 too, 279 against 246 GB/s for the one-pass brute force, which is gone)
+template <int NCH> constexpr int waves_eu() { return NCH == 1 ? HDLZ_W1 : HDLZ_WH; }
 
 
 // ---- phase 3, eligibility + extension (R3/R5; SEARCHF / SEARCH10, deflate.py:899-964, :1018-1062):

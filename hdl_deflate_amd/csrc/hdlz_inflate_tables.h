@@ -10,6 +10,7 @@ namespace tok {
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
 struct __attribute__((packed, aligned(1))) u128_unaligned { uint64_t lo, hi; };
 
 __device__ __forceinline__ uint32_t rev(uint32_t v, uint32_t nbits) { return __builtin_bitreverse32(v) >> (32u - nbits); }

@@ -5,15 +5,15 @@
 // streams in lockstep ONE OUTPUT BYTE per iteration, which keeps the output offset wave-uniform -- but every iteration pays the
 // whole token decode (~50 VALU + ~40 SALU instructions) although only the lanes standing at a token boundary need it: with
 // ~6 bytes per token the decode is paid six times.  Here a ROUND decodes, in every lane, up to three literals and the match behind
-// them, and a short loop moves the bytes: up to eight per lane and iteration (the literals, or the next bytes of the copy: four
-// from the ring, eight of far history), so the decode is paid once per token.  What changes with it:
+// them, and a short loop moves the bytes: up to four per lane and iteration (the literals, or the next bytes of a copy out of the
+// ring) and, behind the loop, up to sixteen bytes of far history in one step, so the decode is paid once per token.  What changes with it:
 //   * every lane has its own output position.  The ring stays lane-interleaved (dword w of lane l at dword index w*64 + l: each
-//     lane owns a bank, whatever the positions are) and is 128 bytes per lane; three dwords are written at once, unmasked -- the
-//     bytes behind the new end are not-yet-produced positions whose old content (history > 112 back) is never read again;
+//     lane owns a bank, whatever the positions are) and is 128 bytes per lane; two dwords (far step: three to five) are written at
+//     once, unmasked -- the bytes behind the new end are not-yet-produced positions whose old content (history > 112 back) is never read again;
 //   * a lane's 64-byte line is flushed when complete, by the lane itself (16 conflict-free ds_read_b32 + 4 x global_store_dwordx4: a
 //     full 64-byte sector per lane); flushes are batched: they run when a quarter of the wave is ready or one lane is about to overrun;
 //   * near history (distance <= 112) is read from the ring, far history from the stream's own flushed output (one 16-byte load
-//     when the token is decoded);
+//     when the token is decoded, taken a round later; a longer far copy asks for its next 16 bytes when it takes the last ones);
 //   * input arrives through 16-byte LDS-DMA slots per lane (hdlz_inflate.hip explains the ordering rule).
 // Status codes and the ORDER of the reference's checks are those of k_inflate: the slow path is the same code.
 //
@@ -42,29 +42,31 @@ constexpr uint32_t RING_DW = RINGB / 4;
 constexpr uint32_t NEAR = RINGB - 16;         // distances up to this are served from the ring: NEAR + 3 (dword alignment of the
                                               // source) + 12 (the unmasked write ahead of the end) < RINGB
 constexpr uint32_t CHUNK = RINGB >= 128u ? 64u : RINGB / 2u;   // bytes per flush
-constexpr uint32_t URGENT = RINGB - 44;       // a lane with this many unflushed bytes forces a flush (+3 per move, +8 written ahead,
-                                              // and the far prefetch reads 24 bytes from o - dist on: they must be flushed)
+constexpr uint32_t URGENT = RINGB - 48;       // a lane with this many unflushed bytes forces a flush: a step advances o by at most 16 (the far
+                                              // step), so o - flushed < URGENT + 16 when a far load is issued, and the 16 bytes it reads end at
+                                              // o - dist + 16 <= o - NEAR + 15 = o - 97: below `flushed`.  (The ring itself only needs
+                                              // URGENT + 16 + 3 written bytes + 11 written ahead < RINGB + CHUNK.)
 constexpr uint32_t SLOT_DW = 4;               // input dwords fetched per lane and refill
 constexpr uint32_t BATCH = 16;             // lanes with a complete line that start a flush
-constexpr uint32_t MOVES = 3;              // move iterations (up to 8 bytes per lane each) per round; 2 / 3 / 4 / 6: 4.21 / 3.95 / 4.10 / 3.99 ms
+constexpr uint32_t MOVES = 3;              // move iterations (up to 4 bytes per lane each) per round; round 3, with the far copies in the loop: 2 / 3 / 4 / 6: 4.21 / 3.95 / 4.10 / 3.99 ms
 #ifdef HDLZ_TOK_MARKS                         // tools/phase_count.py --src hdlz_inflate_tok.hip -DHDLZ_TOK_MARKS: static counts per part
 #define TOK_MARK(name) asm volatile("; @@PHASE " name ::: "memory")
 #else
 #define TOK_MARK(name) do {} while (0)
 #endif
 #ifdef HDLZ_TOK_TIMING                        // diagnostic build (tools/exp_tok_timing.py): s_memtime per part of the round; lanes 0..7 of every
-                                              // wave report the wave's totals in out_len / status instead of their results
+                                              // wave report the wave's totals in out_len / status INSTEAD of the results
 #define TOK_TIME_DECL() uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter()
 #define TOK_TIME(k) do { const uint64_t t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
 #define TOK_TIME_ROUND() tacc[7] += 1u
-#define TOK_TIME_REPORT() do { TOK_TIME(4); if (exists && lane < 8u) { uint64_t v_ = 0;                      \
+#define TOK_STORE_RESULT() do { TOK_TIME(4); if (exists) { uint64_t v_ = 0;          /* by GRID lane; lanes >= 8 report 0 */       \
         _Pragma("unroll") for (int k_ = 0; k_ < 8; k_++) v_ = lane == (uint32_t)k_ ? tacc[k_] : v_;             \
-        a.out_len[gid] = (uint32_t)v_; a.status[gid] = (uint32_t)(v_ >> 32); } } while (0)   /* (by grid lane, not by stream) */
+        a.out_len[gid] = (uint32_t)v_; a.status[gid] = (uint32_t)(v_ >> 32); } } while (0)
 #else
 #define TOK_TIME_DECL() do {} while (0)
 #define TOK_TIME(k) do {} while (0)
 #define TOK_TIME_ROUND() do {} while (0)
-#define TOK_TIME_REPORT() do {} while (0)
+#define TOK_STORE_RESULT() do { if (exists) { a.out_len[sid] = out_len; a.status[sid] = status; } } while (0)
 #endif
 
 // DYN: per-lane tables in LDS, rows of 64 dwords (row j of lane l = dword j * 64 + l: every lane stays in its own bank): only the
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     uint32_t flushed = 0;       // ... of which in HBM (a multiple of 64)
     uint32_t pend = 0;          // the valid low bytes of the ring dword that holds position o
     uint32_t rem = 0, dist = 0; // pending LZ copy
-    [[maybe_unused]] uint64_t fpre = 0, fpre2 = 0;  // far copy: the next 16 source bytes, requested a round / two moves ahead
+    u32x4 far4 = {0u, 0u, 0u, 0u};                  // far copy: the next 16 source bytes, requested a round ahead
     uint32_t litv = 0, litn = 0;// pending literal / stored byte (litn = 0 or 1)
     uint32_t srem = 0;          // pending stored bytes
     uint32_t final_ = 0;
@@ -472,50 +474,72 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         TOK_TIME(5);
         TOK_MARK("move");
         // ------------------------------------------------------------ 0. move the bytes of the tokens decoded in the PREVIOUS round: up to
-        // eight per lane and iteration.  (Moving first, decoding after: the far history a token needs was requested when it was
+        // four per lane and iteration.  (Moving first, decoding after: the far history a token needs was requested when it was
         // decoded, a whole round ago -- waiting for it right after the decode left 67 % of the wave cycles in s_waitcnt.)
         // At most MOVES iterations per round: a long copy goes on in the next rounds while the other lanes decode on -- waiting
         // for the longest copy of the wave in every round left the short tokens idle (measured: 91 VALU per byte instead of ~25)
-        for (uint32_t mvi = 0; mvi < MOVES && __ballot(exists && (litn != 0u || rem != 0u)) != 0ull; mvi++) {
-            const bool mv = exists && (litn != 0u || rem != 0u);
+        // Far copies (distance > NEAR) take no part in this loop: they move in ONE step of up to 16 bytes behind it (below), so the loop
+        // holds no load at all -- round 3's form (8 far bytes per iteration, the next chunk requested inside the loop) made hipcc wait
+        // vmcnt(0) in EVERY iteration, near branch included: for the flush stores and the input DMA too (profiles/r04_tok_round_timing.txt)
+        for (uint32_t mvi = 0; mvi < MOVES && __ballot(exists && (litn != 0u || (rem != 0u && dist <= NEAR))) != 0ull; mvi++) {
+            const bool mv = exists && (litn != 0u || (rem != 0u && dist <= NEAR));
             if (mv) {
-                uint32_t v = litv, vhi = 0, k = litn;              // 1..3 literals, or
-                if (litn == 0u) {
+                uint32_t v = litv, k = litn;                       // 1..3 literals, or
+                if (litn == 0u) {                                  // near history: the ring (unflushed bytes live only here), 4 bytes
                     const uint32_t src = o - dist;
-                    if (dist <= NEAR) {                             // near history: the ring (unflushed bytes live only here), 4 bytes
-                        k = min(rem, 4u);
-                        const uint32_t a0 = ((src & (RINGB - 4u)) << 6) | lane4, a1 = (((src + 4u) & (RINGB - 4u)) << 6) | lane4;
-                        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(ring8 + a0), w1 = *reinterpret_cast<const uint32_t*>(ring8 + a1);
-                        v = __builtin_amdgcn_alignbyte(w1, w0, src);
-                        // an overlapping copy repeats a pattern of `dist` bytes: only its first period is there yet
-                        if (dist < 4u) v = __builtin_amdgcn_perm(v, v, dist == 1u ? 0x00000000u : dist == 2u ? 0x01000100u : 0x00020100u);
-                    } else {
-                        // far history: the stream's own output, flushed long ago (src + 23 < flushed: URGENT), 8 bytes per move; two
-                        // more chunks are in flight, the third is requested as soon as this one is taken
-                        k = min(rem, 8u);
-                        v = (uint32_t)fpre; vhi = (uint32_t)(fpre >> 32);
-                        fpre = fpre2;
-                        if (rem > 16u) fpre2 = *reinterpret_cast<const u64_unaligned*>(out + src + 16u);
-                    }
+                    k = min(rem, 4u);
+                    const uint32_t a0 = ((src & (RINGB - 4u)) << 6) | lane4, a1 = (((src + 4u) & (RINGB - 4u)) << 6) | lane4;
+                    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(ring8 + a0), w1 = *reinterpret_cast<const uint32_t*>(ring8 + a1);
+                    v = __builtin_amdgcn_alignbyte(w1, w0, src);
+                    // an overlapping copy repeats a pattern of `dist` bytes: only its first period is there yet
+                    if (dist < 4u) v = __builtin_amdgcn_perm(v, v, dist == 1u ? 0x00000000u : dist == 2u ? 0x01000100u : 0x00020100u);
                     rem -= k;
                 }
                 litn = 0;
-                // eight bytes at position o, unmasked; `pend` holds the valid low bytes of the dword at o
+                // four bytes at position o, unmasked; `pend` holds the valid low bytes of the dword at o
                 const uint32_t s8 = (o & 3u) * 8u;
-                const uint64_t ta = (uint64_t)v << s8, tb = (uint64_t)vhi << s8;
-                const uint32_t d0 = (uint32_t)ta | pend, d1 = (uint32_t)(ta >> 32) | (uint32_t)tb, d2 = (uint32_t)(tb >> 32);
-                const uint32_t b0 = ((o & (RINGB - 4u)) << 6) | lane4, b1 = (((o + 4u) & (RINGB - 4u)) << 6) | lane4,
-                               b2 = (((o + 8u) & (RINGB - 4u)) << 6) | lane4;
+                const uint64_t ta = (uint64_t)v << s8;
+                const uint32_t d0 = (uint32_t)ta | pend, d1 = (uint32_t)(ta >> 32);
+                const uint32_t b0 = ((o & (RINGB - 4u)) << 6) | lane4, b1 = (((o + 4u) & (RINGB - 4u)) << 6) | lane4;
                 *reinterpret_cast<uint32_t*>(ring8 + b0) = d0;
                 *reinterpret_cast<uint32_t*>(ring8 + b1) = d1;
-                *reinterpret_cast<uint32_t*>(ring8 + b2) = d2;
-                const uint32_t q1 = (o & 3u) + k;                  // 1..11
+                const uint32_t q1 = (o & 3u) + k;                  // 1..7
                 o += k;
-                const uint32_t nd = q1 >= 8u ? d2 : q1 >= 4u ? d1 : d0;
+                const uint32_t nd = q1 >= 4u ? d1 : d0;
                 pend = nd & ((1u << ((q1 & 3u) * 8u)) - 1u);
             }
             TOK_FLUSH();
-            TOK_TIME(6);                    /* (counted into [0] too: tacc[6] = the flush's share is not separable without a second read) */
+            TOK_TIME(6);
+        }
+        // ------------------------------------------------------------ 0a. the far step: up to 16 bytes of far history -- the stream's own output,
+        // flushed long ago (URGENT) -- requested when the token was decoded (or by this step a round ago) and taken once the token's
+        // literals are out.  The only place that waits for a history load, and only in rounds in which a lane takes one.
+        {
+            const bool fc = exists && litn == 0u && rem != 0u && dist > NEAR;
+            if (__ballot(fc) != 0ull) {
+                if (fc) {
+                    const uint32_t k = min(rem, 16u);
+                    const uint32_t s8 = (o & 3u) * 8u;
+                    const uint64_t t0 = (uint64_t)far4.x << s8, t1 = (uint64_t)far4.y << s8, t2 = (uint64_t)far4.z << s8, t3 = (uint64_t)far4.w << s8;
+                    const uint32_t d0 = (uint32_t)t0 | pend, d1 = (uint32_t)(t0 >> 32) | (uint32_t)t1, d2 = (uint32_t)(t1 >> 32) | (uint32_t)t2,
+                                   d3 = (uint32_t)(t2 >> 32) | (uint32_t)t3, d4 = (uint32_t)(t3 >> 32);
+                    const uint32_t q1 = (o & 3u) + k;              // 1..19
+                    // three dwords unmasked as in the loop; the fourth and fifth only when valid bytes reach them (what is written
+                    // ahead of the new end stays below 12 bytes: NEAR + 3 + 12 < RINGB holds as before)
+                    *reinterpret_cast<uint32_t*>(ring8 + (((o & (RINGB - 4u)) << 6) | lane4)) = d0;
+                    *reinterpret_cast<uint32_t*>(ring8 + ((((o + 4u) & (RINGB - 4u)) << 6) | lane4)) = d1;
+                    *reinterpret_cast<uint32_t*>(ring8 + ((((o + 8u) & (RINGB - 4u)) << 6) | lane4)) = d2;
+                    if (q1 > 12u) *reinterpret_cast<uint32_t*>(ring8 + ((((o + 12u) & (RINGB - 4u)) << 6) | lane4)) = d3;
+                    if (q1 > 16u) *reinterpret_cast<uint32_t*>(ring8 + ((((o + 16u) & (RINGB - 4u)) << 6) | lane4)) = d4;
+                    o += k;
+                    rem -= k;
+                    const uint32_t qd = q1 >> 2;
+                    const uint32_t nd = qd == 0u ? d0 : qd == 1u ? d1 : qd == 2u ? d2 : qd == 3u ? d3 : d4;
+                    pend = nd & ((1u << ((q1 & 3u) * 8u)) - 1u);
+                    if (rem != 0u) far4 = *reinterpret_cast<const u32x4_unaligned*>(out + (o - dist));
+                }
+                TOK_FLUSH();
+            }
         }
         TOK_TIME(0);
         TOK_MARK("refill");
@@ -611,9 +635,8 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 if (len_ok) {
                     rem = tlength; dist = distance;
                     if (distance > NEAR) {
-                        // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 < om - 96 <= flushed)
-                        const u128_unaligned f16 = *reinterpret_cast<const u128_unaligned*>(out + (om - distance));
-                        fpre = f16.lo; fpre2 = f16.hi;
+                        // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 <= om - 97 < flushed)
+                        far4 = *reinterpret_cast<const u32x4_unaligned*>(out + (om - distance));
                     }
                 } else if (nl == 0u) {
                     slow = true;                                    // EOB, invalid data, any failing check
@@ -648,9 +671,8 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                     bb >>= mbits; bc -= mbits;
                     rem = tlength; dist = distance;
                     if (distance > NEAR) {
-                        // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 < om - 96 <= flushed)
-                        const u128_unaligned f16 = *reinterpret_cast<const u128_unaligned*>(out + (om - distance));
-                        fpre = f16.lo; fpre2 = f16.hi;
+                        // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 <= om - 97 < flushed)
+                        far4 = *reinterpret_cast<const u32x4_unaligned*>(out + (om - distance));
                     }
                 } else if (nl == 0u) {
                     slow = true;                                    // EOB, invalid data, any failing check
@@ -736,8 +758,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 rem = tlength;
                 dist = distance;
                 if (distance > NEAR) {
-                    const u128_unaligned f16 = *reinterpret_cast<const u128_unaligned*>(out + (o - distance));
-                    fpre = f16.lo; fpre2 = f16.hi;
+                    far4 = *reinterpret_cast<const u32x4_unaligned*>(out + (o - distance));
                 }
             }
             // stored COPY (deflate.py:1603-1616): one byte per round (rare: level-0 streams, incompressible blocks)
@@ -787,11 +808,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     if (exists && status == HDLZ_OK) {
         for (uint32_t p = flushed; p < out_len; p++) out[p] = ring8[ring_addr(p, lane4)];
     }
-    if (exists) {
-        a.out_len[sid] = out_len;
-        a.status[sid] = status;
-    }
-    TOK_TIME_REPORT();
+    TOK_STORE_RESULT();
 }
 
 // the streams pass 1 flagged HDLZ_E_DYNAMIC_UNSUPPORTED, as a dense list: the lanes of k_inflate_tok<true> are then all busy whatever

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out="gpurun_out/prof_$tag"
 mkdir -p "$out"
-BENCH="python bench.py --mode inflate --steps 3 --warmup 1 --cpu-seconds 0 $*"
+BENCH="python bench.py --mode inflate --steps 3 --warmup 1 --cpu-seconds 0 --no-end-to-end $*"
 i=0
 for grp in "TA_TA_BUSY TA_FLAT_READ_WAVEFRONTS GRBM_GUI_ACTIVE" \
            "TA_FLAT_WRITE_WAVEFRONTS TA_ADDR_STALLED_BY_TC_CYCLES" \
