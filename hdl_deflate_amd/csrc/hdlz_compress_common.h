@@ -322,6 +322,9 @@ __device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NC
             constexpr int j = decltype(J)::value;
             inv |= (base + 64u * (uint32_t)(g0 + j) + lane) - q.c0[j];
         });
+#ifdef HDLZ_HASH_FORCE_REORDER                     // test build (tools/r4_exp13.sh): every group takes the path the hardware never asks for
+        inv = 0x80000000u;
+#endif
         if (__ballot((int32_t)inv < 0) != 0ull) {
             static_for<0, cnt>([&](auto J) {
                 constexpr int j = decltype(J)::value;

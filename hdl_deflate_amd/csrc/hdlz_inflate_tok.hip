@@ -59,7 +59,9 @@ constexpr uint32_t MOVES = 3;              // move iterations (up to 4 bytes per
 #define TOK_TIME_DECL() uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter()
 #define TOK_TIME(k) do { const uint64_t t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
 #define TOK_TIME_ROUND() tacc[7] += 1u
-#define TOK_STORE_RESULT() do { TOK_TIME(4); if (exists) { uint64_t v_ = 0;          /* by GRID lane; lanes >= 8 report 0 */       \
+#define TOK_STORE_RESULT() do { TOK_TIME(4);       /* -DHDLZ_TOK_TIMING=1: the DYN = false kernel reports, =2: the DYN = true kernels */ \
+        if (DYN != (HDLZ_TOK_TIMING == 2)) { if (exists) { a.out_len[sid] = out_len; a.status[sid] = status; } }  \
+        else if (exists) { uint64_t v_ = 0;          /* by GRID lane; lanes >= 8 report 0 */                          \
         _Pragma("unroll") for (int k_ = 0; k_ < 8; k_++) v_ = lane == (uint32_t)k_ ? tacc[k_] : v_;             \
         a.out_len[gid] = (uint32_t)v_; a.status[gid] = (uint32_t)(v_ >> 32); } } while (0)
 #else
