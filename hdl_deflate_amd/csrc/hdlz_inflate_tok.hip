@@ -42,10 +42,11 @@ constexpr uint32_t RING_DW = RINGB / 4;
 constexpr uint32_t NEAR = RINGB - 16;         // distances up to this are served from the ring: NEAR + 3 (dword alignment of the
                                               // source) + 12 (the unmasked write ahead of the end) < RINGB
 constexpr uint32_t CHUNK = RINGB >= 128u ? 64u : RINGB / 2u;   // bytes per flush
-constexpr uint32_t URGENT = RINGB - 48;       // a lane with this many unflushed bytes forces a flush: a step advances o by at most 16 (the far
-                                              // step), so o - flushed < URGENT + 16 when a far load is issued, and the 16 bytes it reads end at
+constexpr uint32_t URGENT = RINGB - 52;       // a lane with this many unflushed bytes forces a flush.  ONE flush check per round, behind the far
+                                              // step: a round advances o by at most 19 (three literals + 16 far bytes; 12 out of the ring), so
+                                              // o - flushed < URGENT + 19 when a far load is issued, and the 16 bytes it reads end at
                                               // o - dist + 16 <= o - NEAR + 15 = o - 97: below `flushed`.  (The ring itself only needs
-                                              // URGENT + 16 + 3 written bytes + 11 written ahead < RINGB + CHUNK.)
+                                              // URGENT + 19 written bytes + 11 written ahead < RINGB.)
 constexpr uint32_t SLOT_DW = 4;               // input dwords fetched per lane and refill
 constexpr uint32_t BATCH = 16;             // lanes with a complete line that start a flush
 constexpr uint32_t MOVES = 3;              // move iterations (up to 4 bytes per lane each) per round; round 3, with the far copies in the loop: 2 / 3 / 4 / 6: 4.21 / 3.95 / 4.10 / 3.99 ms
@@ -510,7 +511,6 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 const uint32_t nd = q1 >= 4u ? d1 : d0;
                 pend = nd & ((1u << ((q1 & 3u) * 8u)) - 1u);
             }
-            TOK_FLUSH();
             TOK_TIME(6);
         }
         // ------------------------------------------------------------ 0a. the far step: up to 16 bytes of far history -- the stream's own output,
@@ -540,9 +540,9 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                     pend = nd & ((1u << ((q1 & 3u) * 8u)) - 1u);
                     if (rem != 0u) far4 = *reinterpret_cast<const u32x4_unaligned*>(out + (o - dist));
                 }
-                TOK_FLUSH();
             }
         }
+        TOK_FLUSH();
         TOK_TIME(0);
         TOK_MARK("refill");
         // ------------------------------------------------------------ 0b. input refill (a lane waits only when it opens a new slot)
@@ -841,17 +841,21 @@ __device__ __forceinline__ uint32_t len_bin(uint64_t len64) {
     const uint32_t msb = 31u - (uint32_t)__builtin_clz(l);
     return (NBIN - 1u) - (4u * msb + ((l >> (msb - 2u)) & 3u));        // bin 0 = the longest streams
 }
-__global__ __launch_bounds__(256) void k_bin_hist(const uint64_t* __restrict__ in_off, uint32_t n, uint32_t* __restrict__ hist) {
+// (src / src_n: the streams to order are src[0 .. *src_n) -- the list of the dynamic-tree pass -- instead of 0 .. n - 1)
+__global__ __launch_bounds__(256) void k_bin_hist(const uint64_t* __restrict__ in_off, uint32_t n, uint32_t* __restrict__ hist,
+                                                   const uint32_t* __restrict__ src, const uint32_t* __restrict__ src_n) {
     __shared__ uint32_t lh[NBIN];
+    if (src_n) n = min(n, *src_n);
+    if (blockIdx.x * 256u >= n) return;
     if (threadIdx.x < NBIN) lh[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) atomicAdd(&lh[len_bin(in_off[i + 1] - in_off[i])], 1u);
+    if (i < n) { const uint32_t sid = src ? src[i] : i; atomicAdd(&lh[len_bin(in_off[sid + 1] - in_off[sid])], 1u); }
     __syncthreads();
     if (threadIdx.x < NBIN && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
-// hist[0 .. NBIN) -> first slot per class (in place); ws[NBIN] = n (the list length the decode kernel reads)
-__global__ __launch_bounds__(64) void k_bin_scan(uint32_t* __restrict__ ws, uint32_t n) {
+// hist[0 .. NBIN) -> first slot per class (in place); ws[NBIN] = the list length the decode kernel reads
+__global__ __launch_bounds__(64) void k_bin_scan(uint32_t* __restrict__ ws, uint32_t n, const uint32_t* __restrict__ src_n) {
     const uint32_t lane = threadIdx.x;
     const uint32_t c0 = ws[2u * lane], c1 = ws[2u * lane + 1u];
     uint32_t v = c0 + c1;
@@ -862,20 +866,36 @@ __global__ __launch_bounds__(64) void k_bin_scan(uint32_t* __restrict__ ws, uint
     }
     const uint32_t excl = v - (c0 + c1);
     ws[2u * lane] = excl; ws[2u * lane + 1u] = excl + c0;
-    if (lane == 0u) ws[NBIN] = n;
+    if (lane == 0u) ws[NBIN] = src_n ? min(n, *src_n) : n;
 }
 __global__ __launch_bounds__(256) void k_bin_scatter(const uint64_t* __restrict__ in_off, uint32_t n, uint32_t* __restrict__ cursor,
-                                                      uint32_t* __restrict__ list) {
+                                                      uint32_t* __restrict__ list, const uint32_t* __restrict__ src,
+                                                      const uint32_t* __restrict__ src_n) {
     __shared__ uint32_t lh[NBIN], lbase[NBIN];
+    if (src_n) n = min(n, *src_n);
+    if (blockIdx.x * 256u >= n) return;
     if (threadIdx.x < NBIN) lh[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    uint32_t bin = 0, rank = 0;
-    if (i < n) { bin = len_bin(in_off[i + 1] - in_off[i]); rank = atomicAdd(&lh[bin], 1u); }
+    uint32_t bin = 0, rank = 0, sid = 0;
+    if (i < n) { sid = src ? src[i] : i; bin = len_bin(in_off[sid + 1] - in_off[sid]); rank = atomicAdd(&lh[bin], 1u); }
     __syncthreads();
     if (threadIdx.x < NBIN && lh[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], lh[threadIdx.x]);
     __syncthreads();
-    if (i < n) list[lbase[bin] + rank] = i;
+    if (i < n) list[lbase[bin] + rank] = sid;
+}
+
+// the three launches: bins[0 .. NBIN] (zeroed here) and `list` (n words) in caller-provided scratch; the decode kernel takes
+// `list` and the count at bins + NBIN
+static hipError_t bin_streams(const uint64_t* in_off, uint32_t n, uint32_t* bins, uint32_t* list, const uint32_t* src,
+                              const uint32_t* src_n, hipStream_t stream) {
+    hipError_t e = zero_words(bins, NBIN, stream);
+    if (e != hipSuccess) return e;
+    const dim3 bgrid((n + 255u) / 256u), bblock(256);
+    hipLaunchKernelGGL(k_bin_hist, bgrid, bblock, 0, stream, in_off, n, bins, src, src_n);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(64), 0, stream, bins, n, src_n);
+    hipLaunchKernelGGL(k_bin_scatter, bgrid, bblock, 0, stream, in_off, n, bins, list, src, src_n);
+    return hipGetLastError();
 }
 
 }  // namespace tok
@@ -891,12 +911,8 @@ hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
         const uint32_t n = (uint32_t)a.nstreams;
         hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * ((size_t)n + tok::NBIN + 1u), stream);
         if (e == hipSuccess) {
-            e = zero_words(ws, tok::NBIN, stream);
+            e = tok::bin_streams(a.in_off, n, ws, ws + tok::NBIN + 1u, nullptr, nullptr, stream);
             if (e == hipSuccess) {
-                const dim3 bgrid((n + 255u) / 256u), bblock(256);
-                hipLaunchKernelGGL(tok::k_bin_hist, bgrid, bblock, 0, stream, a.in_off, n, ws);
-                hipLaunchKernelGGL(tok::k_bin_scan, dim3(1), dim3(64), 0, stream, ws, n);
-                hipLaunchKernelGGL(tok::k_bin_scatter, bgrid, bblock, 0, stream, a.in_off, n, ws, ws + tok::NBIN + 1u);
                 hipLaunchKernelGGL((tok::k_inflate_tok<false, tok::CAP_FULL>), grid, block, 0, stream, a,
                                    (const uint32_t*)(ws + tok::NBIN + 1u), (const uint32_t*)(ws + tok::NBIN), 0u);
                 e = hipGetLastError();
@@ -923,7 +939,10 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
     uint32_t* ws = nullptr;                      // ws[0], ws[1]: the two counts; the list from ws + 2 on (both stages: the launches are ordered)
     // (the explicit lane hint keeps every such stream in the lane kernels)
     const uint32_t lane_min = (a.flags & HDLZ_INFLATE_LANE_PER_STREAM) ? 0u : HDLZ_INFLATE_DYN_LANE_MIN;
-    hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * (a.nstreams + 2u), stream);
+    // ragged input: stage 1 takes its streams in the order of their length class, like pass 1 (bins + the ordered list behind the list)
+    const bool binned = a.in_off != nullptr && a.nstreams > HDLZ_INFLATE_BIN_MIN && !all;
+    const size_t nws = (size_t)a.nstreams + 2u + (binned ? (size_t)a.nstreams + tok::NBIN + 1u : 0u);
+    hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * nws, stream);
     if (e != hipSuccess) {                      // no scratch: the wave-per-stream pass needs none and finishes the job
         (void)hipGetLastError();
         return launch_inflate_dyn(a, stream, all);
@@ -936,9 +955,16 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
             e = hipGetLastError();
         } else {
             hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, ws + 2, ws);
-            hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, (const uint32_t*)(ws + 2),
-                               (const uint32_t*)ws, lane_min);
-            e = hipGetLastError();
+            const uint32_t* list1 = ws + 2;
+            if (binned) {
+                uint32_t* bins = ws + 2 + a.nstreams;
+                e = tok::bin_streams(a.in_off, (uint32_t)a.nstreams, bins, bins + tok::NBIN + 1u, ws + 2, ws, stream);
+                list1 = bins + tok::NBIN + 1u;
+            }
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, list1, (const uint32_t*)ws, lane_min);
+                e = hipGetLastError();
+            }
             if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws, lane_min);   // (one of the two returns at once)
         }
     }
