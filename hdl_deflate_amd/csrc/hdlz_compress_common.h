@@ -325,7 +325,7 @@ __device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NC
 #ifdef HDLZ_HASH_FORCE_REORDER                     // test build (tools/r4_exp13.sh): every group takes the path the hardware never asks for
         inv = 0x80000000u;
 #endif
-        if (__ballot((int32_t)inv < 0) != 0ull) {
+        if (ballot64((int32_t)inv < 0) != 0ull) {
             static_for<0, cnt>([&](auto J) {
                 constexpr int j = decltype(J)::value;
                 q.c0[j] = reorder(base + 64u * (uint32_t)(g0 + j), q.kw[j], q.c0[j]);
@@ -374,7 +374,7 @@ __device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NC
         static_for<0, G>([&](auto J) {
             constexpr int j = decltype(J)::value;
             const uint32_t idx = base + 64u * (uint32_t)(g0 + j) + lane;
-            while (__ballot(q.dd[j] != 0u) != 0ull) step(hl.E[idx - q.dd[j]], q.ow[j], q.dd[j], found_[j]);
+            while (ballot64(q.dd[j] != 0u) != 0ull) step(hl.E[idx - q.dd[j]], q.ow[j], q.dd[j], found_[j]);
         });
         // confirm the candidates: the three bytes at idx - found against the own ones (none: the own position, trivially equal)
         uint32_t c0_[G], c1_[G];
@@ -390,20 +390,20 @@ __device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NC
             ev_[j] = (alignbyte(c1_[j], c0_[j], a) ^ q.kw[j]) << 8;          // != 0: a wrong candidate with the right tag
             anybad |= ev_[j];
         });
-        if (__ballot(anybad != 0u) != 0ull) {
+        if (ballot64(anybad != 0u) != 0ull) {
             // (rare: one candidate in 256 wrong ones) the lane goes on behind it -- serial walk and confirmation
             static_for<0, G>([&](auto J) {
                 constexpr int j = decltype(J)::value;
                 const uint32_t idx = base + 64u * (uint32_t)(g0 + j) + lane;
                 bool bad = ev_[j] != 0u;
-                while (__ballot(bad) != 0ull) {
+                while (ballot64(bad) != 0ull) {
                     uint32_t dd = 0u;
                     if (bad) {
                         const uint32_t nd = found_[j] + ((uint32_t)hl.E[idx - found_[j]] & 255u) + 1u;
                         dd = nd <= cw ? nd : 0u;
                         found_[j] = 0u;
                     }
-                    while (__ballot(dd != 0u) != 0ull) step(hl.E[idx - dd], q.ow[j], dd, found_[j]);
+                    while (ballot64(dd != 0u) != 0ull) step(hl.E[idx - dd], q.ow[j], dd, found_[j]);
                     const uint32_t a = idx - found_[j];
                     bad = bad && ((alignbyte(in[(a >> 2) + 1u], in[a >> 2], a) ^ q.kw[j]) << 8) != 0u;
                 }

@@ -40,6 +40,10 @@ __host__ __device__ inline uint32_t out_bound(uint32_t n) {
     return 6u + (uint32_t)((9ull * n + 10ull + 7ull) >> 3);
 }
 
+// wave64 ballot straight from the compare.  (HIP's __ballot(int) takes the predicate through a 0/1 VGPR: v_cndmask + v_cmp_ne per
+// call -- 19 such pairs in a round of k_inflate_tok.)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // compile-time counted loop: body(std::integral_constant<int, I>{}) for I in [B, E)
 template <int B, int E, class F>
 __host__ __device__ __forceinline__ void static_for(F&& f) {

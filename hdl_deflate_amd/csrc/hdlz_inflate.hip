@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
         myissue = issued - 1000u;                                                                           \
     } } while (0)
     if (active) { HDLZ_REQUEST(issued + 1u); }
-    if (__ballot(active && ip + 4u <= zn) != 0ull) issued += 1u;      // counts LDS-DMA instructions actually executed
+    if (ballot64(active && ip + 4u <= zn) != 0ull) issued += 1u;      // counts LDS-DMA instructions actually executed
 
 #define HDLZ_FAIL(code) do { status = (code); out_len = 0; active = false; } while (0)
 #define HDLZ_BITPOS() (8u * ip - bc)
@@ -196,12 +196,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
         // ------------------------------------------------------------ 0. input refill (uniform control flow)
         {
             const bool need = active && rem == 0u && bc <= 32u;
-            if (__ballot(need) != 0ull) {
+            if (ballot64(need) != 0ull) {
                 // loads complete in order: a request with `after` LDS-DMA instructions issued behind it has landed once at
                 // most `after` loads are outstanding; wait for the youngest request that is consumed now, no further
                 const uint32_t after = issued - myissue;
-                if (__ballot(need && after < 2u) == 0ull) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the usual case first
-                else if (__ballot(need && after < 1u) == 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                if (ballot64(need && after < 2u) == 0ull) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the usual case first
+                else if (ballot64(need && after < 1u) == 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 bool dma = false;
                 if (need) {
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
                     dma = ip + 4u <= zn;
                     HDLZ_REQUEST(issued + 1u);
                 }
-                if (__ballot(dma) != 0ull) issued += 1u;          // counts LDS-DMA instructions actually executed
+                if (ballot64(dma) != 0ull) issued += 1u;          // counts LDS-DMA instructions actually executed
             }
         }
         // ------------------------------------------------------------ 1a. fast path: literal / match inside a fixed block
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
             }
         }
         // ------------------------------------------------------------ 1b. slow path (wave-uniform branch, rare)
-        if (__ballot(slow) != 0ull) {
+        if (ballot64(slow) != 0ull) {
             while (slow && active && rem == 0u && srem == 0u && !have) {
                 HDLZ_REFILL();
                 if (need_header) {
@@ -317,9 +317,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
                 fbn = 0;
                 if (distance >= FAR_BUF_MIN) fpre = *reinterpret_cast<const u64_unaligned*>(out + (o - distance));
             }
-            any_stored = any_stored || (__ballot(active && srem != 0u) != 0ull);
+            any_stored = any_stored || (ballot64(active && srem != 0u) != 0ull);
         }
-        if (__ballot(active) == 0ull) break;
+        if (ballot64(active) == 0ull) break;
 
         // ------------------------------------------------------------ 2. one output byte per active lane
         bool wrote = false;        // this lane put a byte into the ring in this iteration
@@ -361,12 +361,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate(InflateArgs a) {
                 else if (final_) { out_len = o + 1u; active = false; }
                 else need_header = true;
             }
-            any_stored = __ballot(active && srem != 0u) != 0ull;    // leave stored mode when the last such block ended
+            any_stored = ballot64(active && srem != 0u) != 0ull;    // leave stored mode when the last such block ended
         }
 
         // ------------------------------------------------------------ 3. flush 64 bytes per stream every 64 iterations
         if ((o & (CHUNK - 1u)) == CHUNK - 1u) {
-            const uint64_t live = __ballot(wrote);      // lanes that filled this whole chunk (incl. one finishing on it)
+            const uint64_t live = ballot64(wrote);      // lanes that filled this whole chunk (incl. one finishing on it)
             const uint32_t c0 = o - (CHUNK - 1u);                       // first byte of the chunk
             const uint32_t w0 = (c0 & (RING_BYTES - 1u)) >> 2;          // its ring dword
             const uint32_t q = lane & 3u;

@@ -108,7 +108,7 @@ __device__ void canon_build(DynLds& L, int which, const uint8_t* len, uint16_t* 
 #pragma unroll
         for (uint32_t l = 1; l < 16u; l++) {
             const bool is = mylen == l;
-            const uint64_t m = __ballot(is);
+            const uint64_t m = ballot64(is);
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             rank = is ? below : rank;
             addv = lane == l ? (uint32_t)__popcll(m) : addv;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         const uint64_t x = bits64(bitpos);
                         const uint32_t el = L.lutl[(uint32_t)x & ((1u << LUTL) - 1u)];
                         len = el >> 9; sym = el & 511u;
-                        if (__ballot(el == 0u) != 0ull) {
+                        if (ballot64(el == 0u) != 0ull) {
                             uint32_t symi;
                             xwalk(XL, (uint32_t)x, len, symi);
                             sym = L.lsym[min(symi, 287u)];
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         const uint64_t x2 = x1 >> leb;
                         const uint32_t ed = L.lutd[(uint32_t)x2 & ((1u << LUTD) - 1u)];
                         dlen = ed >> 5; ds = ed & 31u;
-                        if (__ballot(ismatch && token < 29u && ed == 0u) != 0ull) {
+                        if (ballot64(ismatch && token < 29u && ed == 0u) != 0ull) {
                             uint32_t dsymi;
                             xwalk(XD, (uint32_t)x2, dlen, dsymi);
                             ds = L.dsym[min(dsymi, 31u)];
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     st = eobt ? ST_EOB : 0u;
 #endif
                     if (st == 0u && excl + outlen > WCAP) st = ST_CUT;                               // rest of the chain: next window
-                    const uint64_t special = __ballot(inchain && st != 0u);
+                    const uint64_t special = ballot64(inchain && st != 0u);
                     uint64_t commit = chain;
                     uint32_t consumed = cur, o_new;
                     if (special != 0ull) {
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     DYN_MARK("commit");
                     const bool mine = (commit >> lane) & 1ull;
                     if (mine && lit) L.ring[pos & (DRING - 1u)] = (uint8_t)sym;
-                    uint64_t mm = __ballot(mine && ismatch);
+                    uint64_t mm = ballot64(mine && ismatch);
 #ifdef HDLZ_DYN_X_NOCOPY
                     mm = 0ull;
 #endif
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         // match + its length) and inside the ring depend on nothing the window produces: four at a time, sixteen
                         // lanes each -- the serial loop below (~30 VALU + ~30 scalar instructions per match) keeps the others
                         const bool par = mine && ismatch && distance >= excl + tlen && distance + tlen <= DRING - 512u;
-                        const uint64_t pm = __ballot(par);
+                        const uint64_t pm = ballot64(par);
 #ifdef HDLZ_DYN_X_NOCOPY
                         const uint32_t np = 0u;
 #else

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) void k_par_spec(ParArgs a) {
         const uint32_t nsub = a.sub, fb = a.chbits / nsub;
         for (uint32_t sb = 1u; sb <= nsub; sb++) {
             const uint32_t bound = b_c + sb * fb;            // (the last one: the end of the piece)
-            while (__ballot(run && pos < bound) != 0ull) {
+            while (ballot64(run && pos < bound) != 0ull) {
                 if (run && pos < bound) token();
             }
             if (have && sb < nsub) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void k_par_spec(ParArgs a) {
         }
         if (run) exitc = pos - end;
     } else {
-        while (__ballot(run) != 0ull) {
+        while (ballot64(run) != 0ull) {
             if (run) {
                 token();
                 if (run && pos >= end) { exitc = pos - end; run = false; }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a, Chains 
     bool run = have;
     const uint32_t bit0 = 8u * ((b_c >> 3) & ~3u);
     const uint32_t* w_ = win[wv][half];
-    while (__ballot(run && pos < hb) != 0ull) {
+    while (ballot64(run && pos < hb) != 0ull) {
         if (run && pos < hb) {
             const uint32_t rel = pos - bit0;
             spec_token(__builtin_amdgcn_alignbit(w_[(rel >> 5) + 1u], w_[rel >> 5], rel), lit, dst, pos, nbytes, exitc, run, used);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a, Chains 
     if (run) atomicMin(&first[wv][half][key], e);
     __syncthreads();
     const bool leader = run && first[wv][half][key] == e;
-    const uint64_t lm = __ballot(leader);
+    const uint64_t lm = ballot64(leader);
     if (lane == 0u) wcount[wv] = (uint32_t)__popcll(lm);
     __syncthreads();
     if (tid == 0u) {
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64) void k_par_tail(ParArgs a, Chains ch) {
     bool run = have;
     for (uint32_t sb = 1u; sb <= nsub; sb++) {
         const uint32_t bound = b_c + sb * fb;
-        while (__ballot(run && pos < bound) != 0ull) {
+        while (ballot64(run && pos < bound) != 0ull) {
             if (run && pos < bound) {
                 if (bc <= 32u) { bb |= (uint64_t)nxt << bc; bc += 32u; ip += 4u; nxt = tok::load32(a.z, ip, a.zn); }
                 spec_token((uint32_t)bb, lit, dst, pos, nbytes, exitc, run, used);
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a) {
             const uint64_t before = sh_acc + incl - mine;
             if (lane < walked) op[lane] = (uint32_t)before;
             const bool over = lane < walked && before + mine > 0xFFFFFFFFull;
-            if (__ballot(over) != 0ull && lane == 0u) { sh_stop = 1u; sh_bad = 1u; }
+            if (ballot64(over) != 0ull && lane == 0u) { sh_stop = 1u; sh_bad = 1u; }
             if (lane == 63u) sh_acc += incl;
         }
         __syncthreads();
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
     // not matter here -- any failure hands the stream to the serial decoder, which reports the reference's status in the reference's
     // order.  A token is at most 32 bits long: the low dword of the bit buffer is all a step looks at.
     bool run = have, bad = false;
-    while (__ballot(run) != 0ull) {
+    while (ballot64(run) != 0ull) {
         if (run) {
             if (bc <= 32u) {
                 if (ROWS) { bb |= (uint64_t)rows_[jn * 64u + lane] << bc; jn++; }
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
         }
     }
     if (have) a.ntok[c] = n;
-    if (__ballot(bad) != 0ull && lane == 0u) atomicExch(&a.ctl[C_FALLBACK], 1u);
+    if (ballot64(bad) != 0ull && lane == 0u) atomicExch(&a.ctl[C_FALLBACK], 1u);
 }
 
 // ---- 3b. the bytes: one wave per piece, 64 tokens at a time.  A wave scan gives every token its output position; then the batch is
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
                 if (lane >= (uint32_t)ofs) incl += o;
             }
             // the batch: the leading tokens up to the first one that ends beyond SPAN bytes (that one included)
-            const uint64_t over = __ballot(k < n && incl > SPAN);
+            const uint64_t over = ballot64(k < n && incl > SPAN);
             const uint32_t cnt = min(over != 0ull ? (uint32_t)__builtin_ctzll(over) + 1u : 64u, n - base);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));      // bytes of the batch (<= SPAN + 258)
             // the token of a byte: token starts as a bitmap over the batch's bytes (one 64-bit word per 64-byte slice) + the
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
                     else if (pabs - s <= HREACH) { v = hb[s & (HRING - 1u)]; m = hm[s & (HRING - 1u)]; }      // the ring has it (final)
                     else farin = true;                                       // the piece's own output beyond the ring
                 }
-                if (__ballot(farin) != 0ull) {
+                if (ballot64(farin) != 0ull) {
                     // (rare) those bytes were stored to out[] / src[] by this wave in earlier batches: order the stores before the
                     // loads (workgroup-scope release / acquire; wave-uniform branch)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
                 }
                 // chains inside the slice: registers and the LDS crossbar (ds_bpermute), no memory -- a lane takes over its source
                 // lane's byte and marker once that lane is resolved, its pointer otherwise
-                while (__ballot(p != P_RES) != 0ull) {
+                while (ballot64(p != P_RES) != 0ull) {
                     const uint32_t sl = p != P_RES ? p : lane;
                     const uint32_t pp = (uint32_t)__shfl((int)p, (int)sl, 64), vv = (uint32_t)__shfl((int)v, (int)sl, 64),
                                    mm = (uint32_t)__shfl((int)m, (int)sl, 64);

@@ -269,9 +269,9 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
 #define TOK_BITPOS() (8u * ip - bc)
     // flush the completed 64-byte lines: batched -- when a quarter of the wave is ready or a lane is about to overrun its ring
 #define TOK_FLUSH() do {                                                                                \
-        const bool ready_ = exists && (o - flushed) >= CHUNK;                                              \
-        const uint64_t rm_ = __ballot(ready_);                                                             \
-        if (rm_ != 0ull && (__popcll(rm_) >= (int)BATCH || __ballot(exists && (o - flushed) >= URGENT) != 0ull)) { \
+        const bool ready_ = (o - flushed) >= CHUNK;        /* (a lane without a stream keeps o = flushed = 0) */ \
+        const uint64_t rm_ = ballot64(ready_);                                                             \
+        if (rm_ != 0ull && (__popcll(rm_) >= (int)BATCH || ballot64((o - flushed) >= URGENT) != 0ull)) {      \
             if (ready_) {                                                                                  \
                 const uint32_t* rp_ = &lds.ring[wave][((flushed & (RINGB - 1u)) >> 2) * 64u + lane];       \
                 uint8_t* dp_ = out + flushed;                                                              \
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     };
 
     if (active) { TOK_REQUEST(issued + 1u); }
-    if (__ballot(active && sbase + 16u <= zn) != 0ull) issued += 1u;
+    if (ballot64(active && sbase + 16u <= zn) != 0ull) issued += 1u;
     TOK_TIME_DECL();
 
     for (;;) {
@@ -484,8 +484,11 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         // Far copies (distance > NEAR) take no part in this loop: they move in ONE step of up to 16 bytes behind it (below), so the loop
         // holds no load at all -- round 3's form (8 far bytes per iteration, the next chunk requested inside the loop) made hipcc wait
         // vmcnt(0) in EVERY iteration, near branch included: for the flush stores and the input DMA too (profiles/r04_tok_round_timing.txt)
-        for (uint32_t mvi = 0; mvi < MOVES && __ballot(exists && (litn != 0u || (rem != 0u && dist <= NEAR))) != 0ull; mvi++) {
-            const bool mv = exists && (litn != 0u || (rem != 0u && dist <= NEAR));
+        // (the lane predicates of this loop are single integer compares: a compound bool goes through an SGPR lane mask, and a
+        // ballot of such a mask costs hipcc a v_cndmask + v_cmp_ne to put it back under exec; a lane without a stream never decodes)
+        for (uint32_t mvi = 0; mvi < MOVES; mvi++) {
+            const bool mv = (litn | (dist <= NEAR ? rem : 0u)) != 0u;
+            if (ballot64(mv) == 0ull) break;
             if (mv) {
                 uint32_t v = litv, k = litn;                       // 1..3 literals, or
                 if (litn == 0u) {                                  // near history: the ring (unflushed bytes live only here), 4 bytes
@@ -517,8 +520,8 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         // flushed long ago (URGENT) -- requested when the token was decoded (or by this step a round ago) and taken once the token's
         // literals are out.  The only place that waits for a history load, and only in rounds in which a lane takes one.
         {
-            const bool fc = exists && litn == 0u && rem != 0u && dist > NEAR;
-            if (__ballot(fc) != 0ull) {
+            const bool fc = (litn == 0u ? (dist > NEAR ? rem : 0u) : 0u) != 0u;
+            if (ballot64(fc) != 0ull) {
                 if (fc) {
                     const uint32_t k = min(rem, 16u);
                     const uint32_t s8 = (o & 3u) * 8u;
@@ -548,12 +551,12 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         // ------------------------------------------------------------ 0b. input refill (a lane waits only when it opens a new slot)
         {
             const bool need = active && bc <= 32u;
-            if (__ballot(need) != 0ull) {
+            if (ballot64(need) != 0ull) {
                 const bool fresh = need && ip == sbase;
-                if (__ballot(fresh) != 0ull) {
+                if (ballot64(fresh) != 0ull) {
                     const uint32_t after = issued - myissue;
-                    if (__ballot(fresh && after < 2u) == 0ull) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else if (__ballot(fresh && after < 1u) == 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    if (ballot64(fresh && after < 2u) == 0ull) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if (ballot64(fresh && after < 1u) == 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 bool dma = false, exhausted = false;
@@ -561,13 +564,13 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                     bb |= (uint64_t)inq[lane * SLOT_DW + ((ip - sbase) >> 2)] << bc; bc += 32u; ip += 4u;
                     exhausted = ip - sbase >= 16u;
                 }
-                if (__ballot(exhausted) != 0ull) {
+                if (ballot64(exhausted) != 0ull) {
                     if (exhausted) {
                         sbase = ip;
                         dma = sbase + 16u <= zn;
                         TOK_REQUEST(issued + 1u);
                     }
-                    if (__ballot(dma) != 0ull) issued += 1u;
+                    if (ballot64(dma) != 0ull) issued += 1u;
                 }
             }
         }
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         TOK_TIME(2);
         TOK_MARK("slow");
         // ------------------------------------------------------------ 1b. slow path (wave-uniform branch, rare)
-        if (__ballot(slow || (active && srem != 0u)) != 0ull) {
+        if (ballot64(slow || (active && srem != 0u)) != 0ull) {
             while (slow && active && rem == 0u && srem == 0u && litn == 0u) {
                 TOK_REFILL();
                 if (need_header) {
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         TOK_TIME(3);
         TOK_TIME_ROUND();
         TOK_MARK("loopend");
-        if (__ballot(active || rem != 0u || litn != 0u) == 0ull) break;
+        if (ballot64(active || rem != 0u || litn != 0u) == 0ull) break;
     }
     TOK_MARK("epilogue");
     // the lines completed since the last batch
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(256) void k_collect_dyn(const uint32_t* __restrict_
                                                       uint32_t* __restrict__ n, uint32_t code = HDLZ_E_DYNAMIC_UNSUPPORTED) {
     const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const bool mine = gid < nstreams && status[gid] == code;
-    const uint64_t m = __ballot(mine);
+    const uint64_t m = ballot64(mine);
     if (m == 0ull) return;
     uint32_t base = 0;
     if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(n, (uint32_t)__popcll(m));
