@@ -726,6 +726,47 @@ def test_inflate_small_streams_every_kind(engine, oracle):
             assert len(set(rs.tolist())) >= 3           # (the batch really holds good, cut and damaged streams)
 
 
+def test_inflate_length_binned_lanes(engine, oracle):
+    """round 4: the lane mapping hands a ragged batch of more than HDLZ_INFLATE_BIN_MIN streams to the lanes in the order of their
+    compressed-length class (pass 1 and the dynamic-tree pass).  Streams from a few bytes to ~100 KB, of every block type, damaged and
+    cut ones among them, in random order: status, length and bytes of every stream equal the oracle's -- for batch sizes on both sides
+    of the threshold -- and the rows stay where their stream index puts them."""
+    import torch
+    r = random.Random(21)
+    text = bytes(r.choice(b"the quick brown fox jumps over the lazy dog 0123456789\n") for _ in range(120000))
+    zs = []
+    for k in range(900):
+        n = int(10 ** r.uniform(0.3, 5.0))                  # 2 .. 100 000 plain bytes
+        blk = text[r.randrange(0, 1000):][:n]
+        if r.random() < 0.15:
+            blk = bytes(r.getrandbits(8) for _ in range(min(n, 20000)))
+        strat = r.choice((zlib.Z_FIXED, zlib.Z_FIXED, zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_HUFFMAN_ONLY))
+        c = zlib.compressobj(r.choice((0, 1, 6, 9)), zlib.DEFLATED, 15, 9, strat)
+        z = c.compress(blk) + c.flush()
+        q = r.random()
+        if q < 0.05 and len(z) > 8:
+            z = bytearray(z); z[r.randrange(2, len(z))] ^= 1 << r.randrange(8); z = bytes(z)
+        elif q < 0.10:
+            z = z[: r.randrange(0, len(z) + 1)]
+        zs.append(z)
+    pitch = 100000
+    from hdl_deflate_amd import INFLATE_LANE_PER_STREAM
+    for B in (64, 65, 900):
+        sel = zs[:B]
+        off = np.zeros(B + 1, np.int64)
+        np.cumsum([len(z) for z in sel], out=off[1:])
+        flat = np.frombuffer(b"".join(sel) + bytes(64), dtype=np.uint8).copy()
+        ref, rl, rs = oracle.inflate_batch(flat, off.astype(np.uint64), pitch, flags=0, nthreads=8)
+        m = np.arange(pitch)[None, :] < rl[:, None]
+        out, ol, st = engine.inflate_batch(torch.from_numpy(flat).cuda(), in_off=torch.from_numpy(off).cuda(), out_pitch=pitch,
+                                           flags=INFLATE_LANE_PER_STREAM)
+        torch.cuda.synchronize()
+        assert np.array_equal(st.cpu().numpy().astype(np.uint32), rs), B
+        assert np.array_equal(ol.cpu().numpy().astype(np.uint32), rl), B
+        assert np.array_equal(out.cpu().numpy()[m], ref[m]), B
+    assert len(set(rs.tolist())) >= 3 and int((rs == 0).sum()) > 700
+
+
 def test_inflate_error_statuses(engine, oracle):
     cases = [b"\x78\x9c" + bytes([0x07]) + bytes(8),                                  # BTYPE 3
              zlib.compress(DYN_TEXT, 9),               # dynamic block
