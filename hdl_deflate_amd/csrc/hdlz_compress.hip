@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
             pin(code); asm volatile("" : "+v"(incl), "+v"(lane_bits));
             PHASE_FENCE();
             HDLZ_MARK("scatter");
-            scatter_codes<scatter_pairs<NCH>()>(out8, code, base_bits + incl - lane_bits);                               // bit writer
+            scatter_codes(out8, code, base_bits + incl - lane_bits);                               // bit writer
             HDLZ_MARK("flush");
             __syncthreads();
 

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void k_compress_chunk(ChunkArgs a) {
         const uint32_t tile_bits_all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         pin(code); asm volatile("" : "+v"(incl), "+v"(lane_bits));
         PHASE_FENCE();
-        scatter_codes<scatter_pairs<NCH>()>(out8, code, base_bits + incl - lane_bits);
+        scatter_codes(out8, code, base_bits + incl - lane_bits);
         __syncthreads();
         if (!last) {
             const uint32_t end_bits = base_bits + tile_bits_all;

@@ -602,40 +602,23 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t lane) {
 
 // ---- phase 5b, the bit writer (put / do_flush, deflate.py:535-567): OR every token into the LDS bit buffer at its own
 // bit offset (ds_or_b32), the lane's first token at bit `bp`.
-// PAIRS (CWINDOW <= 32: a token has at most 15 bits -- 7 length + 5 distance + 3 extra, or a 9-bit literal): the codes of two
-// consecutive positions are joined first (a position that starts no token has zero bits) and go out as ONE 30-bit value: 32
-// ds_or per run instead of 64 and 11 instead of 14 VALU instructions per pair.
-template <bool PAIRS>
+// The codes of two consecutive positions are joined first and go out as ONE value: 32 ds_or pairs per run instead of 64, 11 instead
+// of 14 VALU instructions per pair.  A pair never holds two match tokens -- a match covers at least three positions, so the position
+// behind a match start starts nothing --: at most a 9-bit literal and a match of 7 + 5 + 6 bits (CWINDOW 256), 27 bits in a 32-bit
+// word.  (Round 4, first half: CWINDOW <= 32 only, reasoned from two 15-bit tokens; the bound above holds for every window.)
 __device__ __forceinline__ void scatter_codes(uint8_t* out8, const uint32_t (&code)[RUN], uint32_t bp) {
-    if constexpr (PAIRS) {
 #pragma unroll
-        for (int i = 0; i < RUN; i += 2) {
-            const uint32_t n0 = code[i] >> NB_SHIFT;
-            const uint32_t c = ((code[i + 1] & CODE_MASK) << n0) | (code[i] & CODE_MASK);
-            const uint64_t v = (uint64_t)c << (bp & 31u);
-            uint32_t* w = reinterpret_cast<uint32_t*>(out8 + ((bp >> 3) & ~3u));
-            __hip_atomic_fetch_or(w, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_or(w + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            bp += n0 + (code[i + 1] >> NB_SHIFT);
-            if ((i & 6) == 6) { asm volatile("" : "+v"(bp)); PHASE_FENCE(); }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < RUN; i++) {
-            const uint64_t v = (uint64_t)(code[i] & CODE_MASK) << (bp & 31u);
-            uint32_t* w = reinterpret_cast<uint32_t*>(out8 + ((bp >> 3) & ~3u));
-            __hip_atomic_fetch_or(w, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_or(w + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            bp += code[i] >> NB_SHIFT;
-            if ((i & 3) == 3) { asm volatile("" : "+v"(bp)); PHASE_FENCE(); }
-        }
+    for (int i = 0; i < RUN; i += 2) {
+        const uint32_t n0 = code[i] >> NB_SHIFT;
+        const uint32_t c = ((code[i + 1] & CODE_MASK) << n0) | (code[i] & CODE_MASK);
+        const uint64_t v = (uint64_t)c << (bp & 31u);
+        uint32_t* w = reinterpret_cast<uint32_t*>(out8 + ((bp >> 3) & ~3u));
+        __hip_atomic_fetch_or(w, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or(w + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bp += n0 + (code[i + 1] >> NB_SHIFT);
+        if ((i & 6) == 6) { asm volatile("" : "+v"(bp)); PHASE_FENCE(); }
     }
 }
-#ifdef HDLZ_NO_SCATTER_PAIRS
-template <int NCH> constexpr bool scatter_pairs() { return false; }
-#else
-template <int NCH> constexpr bool scatter_pairs() { return NCH == 1; }
-#endif
 
 // ---- phase 6, Adler-32 partials of the run (deflate.py:826-831, :888-897): sa = sum x_i, sc = sum i * x_i (i = 0..31)
 __device__ __forceinline__ void adler_run(const uint32_t (&ow)[12], uint32_t& sa, uint32_t& sc) {

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         pin(code); asm volatile("" : "+v"(incl), "+v"(lane_bits));
         PHASE_FENCE();
         // OR every token into the block's region of the LDS bit buffer (a lane without a block emits nothing: all codes are zero)
-        scatter_codes<scatter_pairs<NCH>()>(out8, code, lane_ok ? 32u * g * Wb + 19u + (incl - lane_bits - before_blk) : 0u);
+        scatter_codes(out8, code, lane_ok ? 32u * g * Wb + 19u + (incl - lane_bits - before_blk) : 0u);
         __syncthreads();
         // -------------------------------------------------------------- 7. per block: trailer, length, flush
         // the block's first lane finishes its block (R8/R9)

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
         }
         pin(code); asm volatile("" : "+v"(incl), "+v"(lane_bits));
         PHASE_FENCE();
-        scatter_codes<scatter_pairs<NCH>()>(out8, code, base_bits + incl - lane_bits);                               // bit writer
+        scatter_codes(out8, code, base_bits + incl - lane_bits);                               // bit writer
 
         __syncthreads();
         // the tile's bit string goes to its slot of the scratch buffer; k_stream_place shifts it to its final position
