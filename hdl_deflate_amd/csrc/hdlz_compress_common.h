@@ -123,12 +123,15 @@ __device__ __forceinline__ void load_own(const uint32_t* in, uint32_t run_dw, ui
 
 // ---- phase 2, match search (R3/R4; the reference's matcher3 x CWINDOW + first-set-bit pick, deflate.py:407-421, :975-994):
 // best[i] = 4 * (nearest distance d in [1, 32*NCH] with x[p-d .. p-d+2] == x[p .. p+2]) for own position i; a value > 128 * NCH
-// (NCH > 1: 0xFFFFFFFF) = none.
+// (NCH > 1: NO_MATCH4) = none.
 // Keys K = (3-byte string) << 8 | 4 * window index: Ko - Kc (u32 wrap) is 4*distance (<= 128) iff the strings are equal and
 // > 256 otherwise, so the MIN over a chunk of 32 candidates is four times the nearest matching distance: one v_sub and
 // half a v_min3 per compare.  Windows > 32 iterate chunks of 32 distances far -> near.
 // (The lane's own bytes are loaded here and die with the keys: the 32 own keys + 32 running minima + the candidate
 // bytes are the register peak of the whole kernel; later phases reload the 48 bytes from LDS, three ds_read_b128.)
+// wide windows (NCH > 1), "no candidate": a value every eligibility test rejects (> 4 * 256 + 124) whose distance field -- bits
+// 2..10, what make_tokens gathers with -- reads 1: one v_bfe instead of compare + select + shift per position
+constexpr uint32_t NO_MATCH4 = 0x8004u;
 template <int NCH>
 __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw, uint32_t (&best)[RUN]) {
     uint32_t ko[RUN];
@@ -142,7 +145,7 @@ __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw
     pin(ko); asm volatile("" : "+v"(ow0));
     PHASE_FENCE();
 #pragma unroll
-    for (int i = 0; i < RUN; i++) best[i] = 0xFFFFFFFFu;
+    for (int i = 0; i < RUN; i++) best[i] = NCH == 1 ? 0xFFFFFFFFu : NO_MATCH4;
 
 #pragma unroll 1
     for (int k = NCH - 1; k >= 0; k--) {                      // far chunks first, nearer ones overwrite
@@ -224,7 +227,7 @@ __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw
 // follows its chain, nearest first, comparing the exact three bytes, until they are equal (the answer), or the window is left;
 // positions with the same hash and another key are the only wasted steps (about CWINDOW / 2^HB per query).
 // Result: best[i] = 4 * distance for own position i of the lane's RUN (the layout of all later phases; transposed through LDS),
-// a value > 4 * CWINDOW = none.  The zero halo in front of a block's first tile only yields distances > p (rejected by
+// NO_MATCH4 = none.  The zero halo in front of a block's first tile only yields distances > p (rejected by
 // make_tokens' position test; a valid candidate is always nearer and therefore found first).
 template <int NCH> struct HashCfg {
 #ifndef HDLZ_HASH_BITS
@@ -412,7 +415,7 @@ __device__ __forceinline__ void match_search_hash(const uint32_t* in, HashLds<NC
         static_for<0, G>([&](auto J) {
             constexpr int j = decltype(J)::value;
             constexpr int r = g0 + j - PRE / 64;
-            const uint32_t f = found_[j] ? found_[j] : 0x3FFFu;
+            const uint32_t f = found_[j] ? found_[j] : (NO_MATCH4 >> 2);
             if constexpr ((r & 1) == 0) res2[r >> 1] = f << 2;
             else res2[r >> 1] |= f << 18;
         });
@@ -494,7 +497,7 @@ __device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run
         if constexpr (SCALAR_TAIL) okm &= ((uint32_t)i <= thr ? m_hi : m_lo);
         else okm &= __builtin_amdgcn_ballot_w64(nrem >= (uint32_t)(i + 5));
         // distance for the gather; for "no match" any in-range value will do (the result is discarded)
-        const uint32_t d = (NCH == 1) ? ((d4 & 0xFCu) >> 2) : (d4 <= cw4 ? (d4 >> 2) : 1u);
+        const uint32_t d = (NCH == 1) ? ((d4 & 0xFCu) >> 2) : __builtin_amdgcn_ubfe(d4, 2u, 9u);      // (NO_MATCH4 reads as 1)
         // R5: common prefix of x[p+3..p+10] and x[p-d+3..p-d+10]
         const uint32_t q = lds_run + (uint32_t)(i + 3) - d;   // byte offset of the candidate's 4th byte
         const uint32_t qd = q >> 2;
