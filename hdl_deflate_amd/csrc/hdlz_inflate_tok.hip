@@ -234,13 +234,17 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     uint64_t bb = 0;            // bit buffer (LSB first)
     uint32_t bc = 0;            // valid bits in bb
     uint32_t ip = 2;            // D0: next byte to load; the 2 zlib header bytes are skipped unvalidated
-    uint32_t sbase = 2;         // first stream byte held by this lane's input slot
+    uint32_t sbase = 2;         // first stream byte of this lane's input slot in LDS (the 16 bytes that are in flight or have landed)
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;   // the qn stream dwords in front of the slot, [ip, sbase): a slot is DRAINED into these
+                                // registers as soon as a lane opens it, and the next 16 bytes are requested at once -- four refills (two
+                                // in a literal run) before they are needed instead of one (round 4: the wave waited ~400 cycles per
+                                // round for a request made a round earlier, profiles/r04_tok_refill.txt); one ds_read_b128 per slot
     uint32_t o = 0;             // bytes produced by THIS lane
     uint32_t flushed = 0;       // ... of which in HBM (a multiple of 64)
     uint32_t pend = 0;          // the valid low bytes of the ring dword that holds position o
     uint32_t rem = 0, dist = 0; // pending LZ copy
     u32x4 far4 = {0u, 0u, 0u, 0u};                  // far copy: the next 16 source bytes, requested a round ahead
-    uint32_t litv = 0, litn = 0;// pending literal / stored byte (litn = 0 or 1)
+    uint32_t litv = 0, litn = 0;// pending literals (up to three) / a stored byte
     uint32_t srem = 0;          // pending stored bytes
     uint32_t final_ = 0;
     bool need_header = true;
@@ -255,15 +259,21 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         else for (uint32_t k_ = 0; k_ < SLOT_DW; k_++) inq[lane * SLOT_DW + k_] = load32(z, sbase + 4u * k_, zn); \
         myissue = (asyncv);                                                                               \
     } while (0)
-    // synchronous refill for the slow path
+    typedef __attribute__((address_space(3))) volatile u32x4 lds_v4;
+    // the next queued dword goes into the bit buffer
+#define TOK_POP() do { bb |= (uint64_t)q0 << bc; bc += 32u; ip += 4u; q0 = q1; q1 = q2; q2 = q3; qn -= 1u; } while (0)
+    // the lane's slot -> the queue (the slot must have landed); the slot then stands for the NEXT 16 bytes
+#define TOK_DRAIN() do { const u32x4 s4_ = *(lds_v4*)(inq + lane * SLOT_DW);                              \
+        q0 = s4_.x; q1 = s4_.y; q2 = s4_.z; q3 = s4_.w; qn = 4u; sbase += 16u; } while (0)
+    // synchronous refill for the slow path (divergent code: no LDS-DMA, `issued` stays wave-uniform)
 #define TOK_REFILL() do { if (bc <= 32u) {                                                              \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
-        bb |= (uint64_t)inq[lane * SLOT_DW + ((ip - sbase) >> 2)] << bc; bc += 32u; ip += 4u;              \
-        if (ip - sbase >= 16u) {                                                                           \
-            sbase = ip;                                                                                    \
+        if (qn == 0u) {                                                                                    \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+            TOK_DRAIN();                                                                                   \
             for (uint32_t k_ = 0; k_ < SLOT_DW; k_++) inq[lane * SLOT_DW + k_] = load32(z, sbase + 4u * k_, zn); \
             myissue = issued - 1000u;                                                                      \
         }                                                                                                  \
+        TOK_POP();                                                                                         \
     } } while (0)
 #define TOK_FAIL(code) do { status = (code); out_len = 0; active = false; } while (0)
 #define TOK_BITPOS() (8u * ip - bc)
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 }                                                                                          \
                 flushed += CHUNK;                                                                          \
             }                                                                                              \
+            issued += CHUNK / 16u;                         /* (VMEM instructions of the wave: see the refill) */ \
             /* (no fence: a far copy reads bytes that THIS lane stored -- program order of one thread; k_inflate's lines are */ \
             /* stored by other lanes and need the workgroup-scope release / acquire, a full store round trip per flush)     */ \
         }                                                                                                  \
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     // ---- DYN: restart the bit reader at an absolute bit position (the second pass over a block header)
 #define TOK_RESYNC(bitp) do {                                                                           \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* no LDS-DMA may land in the slot after this */ \
-        ip = (bitp) >> 3; sbase = ip;                                                                      \
+        ip = (bitp) >> 3; sbase = ip; qn = 0u;                                                             \
         for (uint32_t k_ = 0; k_ < SLOT_DW; k_++) inq[lane * SLOT_DW + k_] = load32(z, sbase + 4u * k_, zn); \
         myissue = issued - 1000u;                                                                          \
         bb = 0; bc = 0;                                                                                    \
@@ -552,26 +563,27 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         {
             const bool need = active && bc <= 32u;
             if (ballot64(need) != 0ull) {
-                const bool fresh = need && ip == sbase;
+                const bool fresh = need && qn == 0u;
                 if (ballot64(fresh) != 0ull) {
+                    // `issued` counts the wave's LDS-DMA instructions and flush stores, `myissue` is its value right after this lane's
+                    // request: at least `after` VMEM instructions are younger than the request (far loads are not counted: the wait
+                    // is then longer than it has to be, never shorter), and vmcnt retires in order
                     const uint32_t after = issued - myissue;
-                    if (ballot64(fresh && after < 2u) == 0ull) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    if (ballot64(fresh && after < 8u) == 0ull) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else if (ballot64(fresh && after < 4u) == 0ull) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (ballot64(fresh && after < 2u) == 0ull) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     else if (ballot64(fresh && after < 1u) == 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                bool dma = false, exhausted = false;
-                if (need) {
-                    bb |= (uint64_t)inq[lane * SLOT_DW + ((ip - sbase) >> 2)] << bc; bc += 32u; ip += 4u;
-                    exhausted = ip - sbase >= 16u;
-                }
-                if (ballot64(exhausted) != 0ull) {
-                    if (exhausted) {
-                        sbase = ip;
+                    bool dma = false;
+                    if (fresh) {
+                        TOK_DRAIN();
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot is read before the next request may overwrite it
                         dma = sbase + 16u <= zn;
                         TOK_REQUEST(issued + 1u);
                     }
                     if (ballot64(dma) != 0ull) issued += 1u;
                 }
+                if (need) TOK_POP();
             }
         }
         TOK_TIME(1);
