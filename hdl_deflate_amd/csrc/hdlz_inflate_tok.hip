@@ -49,6 +49,13 @@ constexpr uint32_t URGENT = RINGB - 52;       // a lane with this many unflushed
                                               // URGENT + 19 written bytes + 11 written ahead < RINGB.)
 constexpr uint32_t SLOT_DW = 4;               // input dwords fetched per lane and refill
 constexpr uint32_t BATCH = 16;             // lanes with a complete line that start a flush
+#ifndef HDLZ_TOK_STEP2_MIN
+#define HDLZ_TOK_STEP2_MIN 16
+#endif
+#ifndef HDLZ_TOK_S2_YIELD
+#define HDLZ_TOK_S2_YIELD 2u
+#endif
+constexpr uint32_t STEP2_MIN = HDLZ_TOK_STEP2_MIN;   // lanes of a wave that can take a SECOND group of tokens in a round (0 = never; fixed blocks)
 constexpr uint32_t MOVES = 3;              // move iterations (up to 4 bytes per lane each) per round; round 3, with the far copies in the loop: 2 / 3 / 4 / 6: 4.21 / 3.95 / 4.10 / 3.99 ms
 #ifdef HDLZ_TOK_MARKS                         // tools/phase_count.py --src hdlz_inflate_tok.hip -DHDLZ_TOK_MARKS: static counts per part
 #define TOK_MARK(name) asm volatile("; @@PHASE " name ::: "memory")
@@ -245,6 +252,15 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     uint32_t rem = 0, dist = 0; // pending LZ copy
     u32x4 far4 = {0u, 0u, 0u, 0u};                  // far copy: the next 16 source bytes, requested a round ahead
     uint32_t litv = 0, litn = 0;// pending literals (up to three) / a stored byte
+    // a SECOND pending group (fixed blocks): up to three literals and a NEAR match behind the first group.  A round decodes one group per lane
+    // -- at ~400 instructions per round a stream of short matches or of literals advanced 3..4 bytes per round --; when enough lanes of the
+    // wave have their first group pending and room for a second one, a second decode step fills it.  The move loop takes the groups in order.
+    [[maybe_unused]] uint32_t litv2 = 0, litn2 = 0, rem2 = 0, dist2 = 0;
+    // wave-uniform (SGPRs): some lane has a second group pending; rounds for which step 2 stays off, and the next such pause.  Streams whose
+    // matches are mostly FAR (stock zlib, 32 KiB window) rarely get a whole second group: a wave whose step 2 fills less than half of its
+    // lanes pauses it for 32, 64, ... 1024 rounds, and while nothing is pending the move loop's hand-over costs one scalar branch
+    [[maybe_unused]] bool s2_live = false;
+    [[maybe_unused]] uint32_t s2_hold = 0, s2_back = 32;
     uint32_t srem = 0;          // pending stored bytes
     uint32_t final_ = 0;
     bool need_header = true;
@@ -497,7 +513,14 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         // vmcnt(0) in EVERY iteration, near branch included: for the flush stores and the input DMA too (profiles/r04_tok_round_timing.txt)
         // (the lane predicates of this loop are single integer compares: a compound bool goes through an SGPR lane mask, and a
         // ballot of such a mask costs hipcc a v_cndmask + v_cmp_ne to put it back under exec; a lane without a stream never decodes)
+#define TOK_PROMOTE() do { if constexpr (!DYN && STEP2_MIN != 0u) { if (s2_live) {                     \
+            const bool pr_ = (litn | rem) == 0u;          /* the first group is done: the second one moves up (it may be empty) */ \
+            litn = pr_ ? litn2 : litn; litv = pr_ ? litv2 : litv; rem = pr_ ? rem2 : rem; dist = pr_ ? dist2 : dist;        \
+            litn2 = pr_ ? 0u : litn2; rem2 = pr_ ? 0u : rem2;                                              \
+            s2_live = ballot64((litn2 | rem2) != 0u) != 0ull;                                              \
+        } } } while (0)
         for (uint32_t mvi = 0; mvi < MOVES; mvi++) {
+            if (mvi != 0u) TOK_PROMOTE();                  // (at the top of a round the hand-over behind the far step has been made)
             const bool mv = (litn | (dist <= NEAR ? rem : 0u)) != 0u;
             if (ballot64(mv) == 0ull) break;
             if (mv) {
@@ -556,6 +579,8 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 }
             }
         }
+        TOK_PROMOTE();                                   // (behind the far step, which may have finished the first group: from here on a
+                                                         //  pending second group implies a pending first one -- the decode relies on it)
         TOK_FLUSH();
         TOK_TIME(0);
         TOK_MARK("refill");
@@ -592,7 +617,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         // fixed block.  (One token per round made the literal-heavy streams the lanes the whole wave waits for: 362 -> 390 GB/s with
         // literal triples, more with the match behind them.)
         bool slow = false;
-        if (active && srem == 0u && rem == 0u) {              // (a lane still copying takes no new token)
+        if (active && srem == 0u && (rem | litn) == 0u) {     // (a lane with a pending group takes its next one in step 2, if at all)
             slow = need_header;
             // input guard: after the refill bc >= 33, and a token is only taken when at least one buffered bit is left behind it, so
             // its bit position lies below byte ip; with ip + 3 <= zn both reference checks (deflate.py:1535-1539 after the symbol,
@@ -699,6 +724,61 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 slow = true;                                        // header, end of the input
             }
         }
+        // ------------------------------------------------------------ 1a'. a second group for the lanes whose first one is pending (fixed blocks):
+        // up to three literals and a NEAR match (a far one stays in the stream: its history load belongs to step 1), only what the fast path
+        // can take -- anything else (end of block, a header, the end of the input, a failing check) is left for step 1 of a later round,
+        // which sees it with nothing pending, as before.  The bit buffer may be short here (step 1 has eaten from it): one more dword is
+        // popped when the queue has one, and every symbol is taken only while a buffered bit is left behind it.  The group starts at
+        // ob = o + (bytes still pending), which is where its distance and capacity checks apply (deflate.py:1576-1585 at that position).
+        // Bounds: the move loop still moves at most MOVES * 4 bytes and the far step only the FIRST group's bytes, so a round advances o
+        // by at most 19 as before (flush / far-load safety, see URGENT).
+        if constexpr (!DYN && STEP2_MIN != 0u) {
+          if (s2_hold != 0u) s2_hold -= 1u;
+          else {
+            const bool s2 = active && !slow && !need_header && srem == 0u && (litn | rem) != 0u && (litn2 | rem2) == 0u;
+            const uint32_t ns2 = (uint32_t)__popcll(ballot64(s2));
+            if (ns2 >= STEP2_MIN) {
+                if (s2 && bc <= 32u && qn != 0u) TOK_POP();
+                if (s2 && ip + 3u <= zn) {
+                    const uint32_t ob = o + litn + rem;
+                    uint32_t nl = 0;
+#pragma unroll
+                    for (uint32_t extra = 0; extra < 3u; extra++) {
+                        const uint32_t e2 = lit_at((uint32_t)bb);
+                        if (nl == extra && ((e2 >> 13) & 3u) == (uint32_t)T_LIT && (e2 & 15u) < bc && ob + extra < cap) {
+                            litv2 = extra == 0u ? ((e2 >> 4) & 0xFFu) : (litv2 | (((e2 >> 4) & 0xFFu) << (8u * extra)));
+                            nl = extra + 1u;
+                            bb >>= (e2 & 15u); bc -= (e2 & 15u);
+                        }
+                    }
+                    litn2 = nl;
+                    const uint32_t e = lit_at((uint32_t)bb);
+                    const uint32_t nb = e & 15u, type = (e >> 13) & 3u;
+                    const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;
+                    uint64_t x = bb >> nb;
+                    const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));
+                    x >>= leb;
+                    uint32_t dnb;
+                    const uint32_t de = dst_at((uint32_t)x, dnb);
+                    const uint32_t deb = (de >> 16) & 15u;
+                    const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> dnb) & ((1u << deb) - 1u));
+                    const uint32_t mbits = nb + leb + dnb + deb;
+                    const uint32_t om = ob + nl;
+                    const bool len_ok = (type == (uint32_t)T_LEN) & (mbits < bc) & (de < NO_DCODE) & (distance <= om) &
+                                        (distance <= obsize) & (om + tlength <= cap) & (distance <= NEAR);
+                    if (len_ok) {
+                        bb >>= mbits; bc -= mbits;
+                        rem2 = tlength; dist2 = distance;
+                    }
+                }
+                // worth it when most of those lanes got a match or three literals; else pause, twice as long every time
+                const uint32_t ngood = (uint32_t)__popcll(ballot64(s2 && (rem2 != 0u || litn2 == 3u)));
+                s2_live = s2_live || ballot64((litn2 | rem2) != 0u) != 0ull;
+                if (HDLZ_TOK_S2_YIELD * ngood < ns2) { s2_hold = s2_back; s2_back = min(2u * s2_back, 1024u); }
+                else s2_back = 32u;
+            }
+          }
+        }
         TOK_TIME(2);
         TOK_MARK("slow");
         // ------------------------------------------------------------ 1b. slow path (wave-uniform branch, rare)
@@ -798,7 +878,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
         TOK_TIME(3);
         TOK_TIME_ROUND();
         TOK_MARK("loopend");
-        if (ballot64(active || rem != 0u || litn != 0u) == 0ull) break;
+        if (ballot64(active || (rem | litn | rem2 | litn2) != 0u) == 0ull) break;
     }
     TOK_MARK("epilogue");
     // the lines completed since the last batch

@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define HDLZ_VERSION 0x000400   /* round 4: + hdlz_release_scratch (bounded scratch pool); hdlz_compact_batch accepts a pinned-host destination; the opt-in
+#define HDLZ_VERSION 0x000401   /* 0x000401: same ABI, new inflate lane kernels (register-queue refill, second token group per round): the PMC records
+                                   of profiles/traffic.json are tied to the version.  0x000400, round 4: + hdlz_release_scratch (bounded scratch pool); hdlz_compact_batch accepts a pinned-host destination; the opt-in
                                    two-phase inflate of 0x000301 (HDLZ_INFLATE_TWO_PHASE = 64) was measured slower than the one-pass kernel and is gone */
 
 /* command codes of the reference port surface (deflate.py:18) -- used by the adapter */

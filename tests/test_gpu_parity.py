@@ -767,6 +767,60 @@ def test_inflate_length_binned_lanes(engine, oracle):
     assert len(set(rs.tolist())) >= 3 and int((rs == 0).sum()) > 700
 
 
+def test_inflate_second_token_group_per_round(engine, oracle):
+    """round 4: a round of the lane kernel decodes a SECOND group (up to three literals + a near match) for the lanes whose first group
+    is still pending, when enough lanes of the wave can take one.  Streams that live on it -- literals only, short matches only, a
+    literal run between two matches, near and far matches mixed, output rows that end inside a group (capacity), damaged and cut
+    streams -- against the oracle: status, length and bytes of every stream; own streams (CWINDOW 32 / 256) and stock zlib ones."""
+    import torch
+    from hdl_deflate_amd import INFLATE_LANE_PER_STREAM
+    r = random.Random(77)
+    blocks = []
+    for k in range(640):
+        kind = k % 5
+        n = r.choice((40, 700, 2048, 6000))
+        if kind == 0:
+            b = bytes(r.getrandbits(8) for _ in range(n))                                   # literals only
+        elif kind == 1:
+            b = bytes(r.choice(b"01") for _ in range(n))                                    # short matches only
+        elif kind == 2:
+            b = b"".join(b"Hi: %04d" % r.randrange(10000) for _ in range(n // 8 + 1))[:n]   # match, literal run, match
+        elif kind == 3:
+            w = [bytes(r.choice(b"abcdefgh") for _ in range(r.randrange(3, 12))) for _ in range(40)]
+            b = b" ".join(r.choice(w) for _ in range(n // 5 + 1))[:n]                       # near and far matches
+        else:
+            b = bytes([r.randrange(256)]) * n                                               # one long overlapping copy chain
+        blocks.append(b)
+    zs = []
+    for k, b in enumerate(blocks):
+        if k % 3 == 0:
+            c = zlib.compressobj(r.choice((1, 6, 9)), zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+            z = c.compress(b) + c.flush()
+        else:
+            rc, z = oracle.compress(b, cwindow=256 if k % 3 == 1 else 32, maxmatch=10)
+            assert rc == 0
+        q = r.random()
+        if q < 0.04 and len(z) > 8:
+            z = bytearray(z); z[r.randrange(2, len(z))] ^= 1 << r.randrange(8); z = bytes(z)
+        elif q < 0.08:
+            z = z[: r.randrange(0, len(z) + 1)]
+        zs.append(z)
+    B = len(zs)
+    off = np.zeros(B + 1, np.int64)
+    np.cumsum([len(z) for z in zs], out=off[1:])
+    flat = np.frombuffer(b"".join(zs) + bytes(64), dtype=np.uint8).copy()
+    for pitch in (6000, 2044):                               # the second: most rows end inside a group (E_OUT_CAPACITY from the right token)
+        ref, rl, rs = oracle.inflate_batch(flat, off.astype(np.uint64), pitch, flags=0, nthreads=8)
+        m = np.arange(pitch)[None, :] < rl[:, None]
+        out, ol, st = engine.inflate_batch(torch.from_numpy(flat).cuda(), in_off=torch.from_numpy(off).cuda(), out_pitch=pitch,
+                                           flags=INFLATE_LANE_PER_STREAM)
+        torch.cuda.synchronize()
+        assert np.array_equal(st.cpu().numpy().astype(np.uint32), rs), pitch
+        assert np.array_equal(ol.cpu().numpy().astype(np.uint32), rl), pitch
+        assert np.array_equal(out.cpu().numpy()[m], ref[m]), pitch
+    assert int((rs == 0).sum()) > 100 and len(set(rs.tolist())) >= 2
+
+
 def test_inflate_error_statuses(engine, oracle):
     cases = [b"\x78\x9c" + bytes([0x07]) + bytes(8),                                  # BTYPE 3
              zlib.compress(DYN_TEXT, 9),               # dynamic block
