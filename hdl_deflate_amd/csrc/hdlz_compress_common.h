@@ -497,7 +497,10 @@ __device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run
         if constexpr (SCALAR_TAIL) okm &= ((uint32_t)i <= thr ? m_hi : m_lo);
         else okm &= __builtin_amdgcn_ballot_w64(nrem >= (uint32_t)(i + 5));
         // distance for the gather; for "no match" any in-range value will do (the result is discarded)
-        const uint32_t d = (NCH == 1) ? ((d4 & 0xFCu) >> 2) : __builtin_amdgcn_ubfe(d4, 2u, 9u);      // (NO_MATCH4 reads as 1)
+        // (NCH == 1: a plain shift -- v_lshrrev is a full-rate instruction, v_bfe / v_and + shift are not, profiles/r04_ubench/ubench_valu_cycles2.txt;
+        //  a raw minimum that means "none" then gathers at some address below the run: the dword mask of the address keeps it inside the
+        //  first 8 KB of the LDS -- reads beyond the workgroup's allocation return zero -- and the result is discarded)
+        const uint32_t d = (NCH == 1) ? (d4 >> 2) : __builtin_amdgcn_ubfe(d4, 2u, 9u);      // (NO_MATCH4 reads as 1)
         // R5: common prefix of x[p+3..p+10] and x[p-d+3..p-d+10]
         const uint32_t q = lds_run + (uint32_t)(i + 3) - d;   // byte offset of the candidate's 4th byte
         const uint32_t qd = q >> 2;
@@ -512,7 +515,8 @@ __device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run
         const uint32_t zhi = ffbl((chi ^ ohi) | 0x80000000u) | 32u;
         uint32_t zlo;                                            // v_ffbl_b32(0) = 0xFFFFFFFF: "no difference in the low half"
         asm("v_ffbl_b32 %0, %1" : "=v"(zlo) : "v"(clo ^ olo));   // (asm: hipcc turns ffs()-1 + min into a compare and a select)
-        const uint32_t zb = min(zlo, zhi);
+        uint32_t zb;                                             // min(zlo, zhi): zhi <= 63 and zlo is a bit index or 0xFFFFFFFF, so the 16-bit
+        asm("v_min_u16 %0, %1, %2" : "=v"(zb) : "v"(zlo), "v"(zhi));   // minimum is the minimum (full rate; v_min_u32 is not), upper half zero
         // len - 3 = min(equal bytes, Kmax - 3, N-2-p - 3): a match never covers the last two bytes
         const uint32_t l3 = umin3(zb >> 3, kmax_m3, nrem_m5 - (uint32_t)i);
         // literal byte -> LUT offset 4*byte
