@@ -171,7 +171,8 @@ __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw
         uint32_t m[RUN];
 #pragma unroll
         for (int i = 0; i < RUN; i++) m[i] = 0xFFFFFFFFu;
-        // candidate-major order: two candidate keys live at a time, 32 running minima
+        // candidate-major order: two candidate keys live at a time, 32 running minima.  (Round 4: pairing the odd rows as (j+1, j+2) puts
+        // their 32 single v_min_u32 into v_min3 as well, -12 instructions -- but the third live key spills 8 bytes per lane: not adopted)
         static_for<0, 63>([&](auto J) {
             constexpr int j = decltype(J)::value;             // handles candidates j and j+1 (j even)
             if constexpr ((j & 1) == 0) {
@@ -460,7 +461,7 @@ template <int NCH> constexpr int waves_eu() { return NCH == 1 ? HDLZ_W1 : HDLZ_W
 
 
 // ---- phase 3, eligibility + extension (R3/R5; SEARCHF / SEARCH10, deflate.py:899-964, :1018-1062):
-// tok[i] = (len-1) << 16 | LUT byte offset of the token  (len-1 = 0 for a literal).
+// tok[i] = 4 * (len-1) << 16 | LUT byte offset of the token  (len-1 = 0 for a literal).
 //   lds_run  byte offset of the run in `in`;  nrem = positions of the block from the run's first position on (0 = none)
 //   p4_run   4 * min(block-relative position of the run, 32 * NCH): with that clamp `d4 <= p4_run + 4i` is at once R4's
 //            d <= p, the "a candidate exists" test AND -- for NCH == 1, where best[] holds raw minima -- the rejection of
@@ -484,10 +485,12 @@ __device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run
     const uint32_t thr = rem5 >= 0 ? ((uint32_t)rem5 & 31u) : 0u;                        // i <= thr: the larger count
     const int32_t cnt_hi = rem5 >= 0 ? (rem5 >> 5) + 1 : 0, cnt_lo = rem5 >= 0 ? (rem5 >> 5) : 0;
     const uint64_t m_hi = cnt_hi >= 64 ? ~0ull : ((1ull << cnt_hi) - 1ull), m_lo = cnt_lo >= 64 ? ~0ull : ((1ull << cnt_lo) - 1ull);
-    // token word of a match of length len = l3 + 3 at distance d:  (len-1) << 16 | LUT offset
-    //   CWINDOW <= 32: LUT [len-3][d-1] -> l3 * (65536 + 128) + 4d + K;   wider: LUT [d-1] -> l3 * 65536 + 4d + K
-    const uint32_t tok_k = (2u << 16) + LUT_MATCH_BYTE - 4u;
-    const uint32_t tok_mul = NCH == 1 ? 65664u : 65536u;
+    // token word of a match of length len = l3 + 3 at distance d:  4 * (len-1) << 16 | LUT offset
+    //   CWINDOW <= 32: LUT [len-3][d-1] -> l3 * (4 * 65536 + 128) + 4d + K;   wider: LUT [d-1] -> l3 * 4 * 65536 + 4d + K
+    // (the upper half holds 4 * (len-1): the parse shifts its nibble table by exactly that, the LUT_LEN offset is exactly that, and a plain
+    //  v_lshrrev is a full-rate instruction where the shift-and-scale forms are not)
+    const uint32_t tok_k = (2u << 18) + LUT_MATCH_BYTE - 4u;
+    const uint32_t tok_mul = NCH == 1 ? (4u * 65536u + 128u) : 4u * 65536u;
     static_for<0, RUN>([&](auto I) {
         constexpr int i = decltype(I)::value;
         const uint32_t d4 = best[i];
@@ -538,7 +541,7 @@ __device__ __forceinline__ uint64_t run_transfer(const uint32_t (&tok)[RUN]) {
     uint64_t P = 0x9876543210ull;
 #pragma unroll
     for (int i = RUN - 1; i >= 0; i--) {
-        const uint32_t sh = (tok[i] >> 16) * 4u;              // 4 * (len-1)
+        const uint32_t sh = tok[i] >> 16;                     // 4 * (len-1)
         const uint32_t e = (uint32_t)(P >> sh) & 15u;
         P = (P << 4) | e;
     }
@@ -579,17 +582,17 @@ template <int NCH, bool LIMIT>
 __device__ __forceinline__ uint32_t token_codes(const uint8_t* lut8, uint32_t (&tok)[RUN], uint32_t c0, uint32_t nlimit,
                                                 uint32_t (&code)[RUN]) {
     uint32_t lane_bits = 0;
-    uint32_t c = c0;
+    uint32_t c = 4u * c0;                                     // positions still covered by the last token, times four (the token word's unit)
     static_for<0, RUN>([&](auto I) {
         constexpr int i = decltype(I)::value;
         const uint32_t e = *reinterpret_cast<const uint32_t*>(lut8 + (tok[i] & 0xFFFFu));
         bool start = (c == 0u);
         if constexpr (LIMIT) start = start & ((uint32_t)i < nlimit);
-        const uint32_t lenm1 = tok[i] >> 16;
-        c = start ? lenm1 : (c - 1u);
+        const uint32_t lenm1x4 = tok[i] >> 16;
+        c = start ? lenm1x4 : (c - 4u);
         uint32_t ee = e;
         if constexpr (NCH != 1)                               // wide windows: [dist] LUT + the length code from its own small LUT
-            ee |= *reinterpret_cast<const uint32_t*>(lut8 + LUT_LEN_BYTE + 4u * lenm1);     // (computed: six VALU instructions per position)
+            ee |= *reinterpret_cast<const uint32_t*>(lut8 + LUT_LEN_BYTE + lenm1x4);        // (computed: six VALU instructions per position)
         code[i] = start ? ee : 0u;
         lane_bits += code[i] >> NB_SHIFT;
         if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(code); asm volatile("" : "+v"(c), "+v"(lane_bits)); PHASE_FENCE(); }
