@@ -677,6 +677,7 @@ hipError_t launch_inflate_dyn(const InflateArgs& a0, hipStream_t stream, bool al
     InflateArgs a = a0;
     if (all) a.flags |= DYN_ALL;
     uint64_t g = a.nstreams < 65536u ? a.nstreams : 65536u;
+    if (few_n && lane_min != 0u && g > lane_min) g = lane_min;       // (list mode runs for fewer than lane_min streams: no more blocks than that)
     hipLaunchKernelGGL(k_inflate_dyn<false>, dim3((unsigned)g), dim3(64), 0, stream, a, (hdlz_istate*)nullptr, 0u, few_n, lane_min);
     return hipGetLastError();
 }

@@ -912,13 +912,19 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
 // the share of such streams is (list[0 .. *n) in no particular order: the streams are independent)
 __global__ __launch_bounds__(256) void k_collect_dyn(const uint32_t* __restrict__ status, uint64_t nstreams, uint32_t* __restrict__ list,
                                                       uint32_t* __restrict__ n, uint32_t code = HDLZ_E_DYNAMIC_UNSUPPORTED) {
+    // ONE atomic per workgroup (round 4: one per wave was 4096 atomics on one counter for 262144 streams, 49 us of a 1.4 ms job)
+    __shared__ uint32_t wcnt[4], wbase;
     const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const bool mine = gid < nstreams && status[gid] == code;
     const uint64_t m = ballot64(mine);
-    if (m == 0ull) return;
-    uint32_t base = 0;
-    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(n, (uint32_t)__popcll(m));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u) wcnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    const uint32_t c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+    if (c0 + c1 + c2 + c3 == 0u) return;
+    if (threadIdx.x == 0u) wbase = atomicAdd(n, c0 + c1 + c2 + c3);
+    __syncthreads();
+    const uint32_t base = wbase + (wave > 0u ? c0 : 0u) + (wave > 1u ? c1 : 0u) + (wave > 2u ? c2 : 0u);
     if (mine) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)gid;
 }
 
