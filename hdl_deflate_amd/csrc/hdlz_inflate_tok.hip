@@ -52,9 +52,6 @@ constexpr uint32_t BATCH = 16;             // lanes with a complete line that st
 #ifndef HDLZ_TOK_STEP2_MIN
 #define HDLZ_TOK_STEP2_MIN 16
 #endif
-#ifndef HDLZ_TOK_S2_YIELD
-#define HDLZ_TOK_S2_YIELD 2u
-#endif
 constexpr uint32_t STEP2_MIN = HDLZ_TOK_STEP2_MIN;   // lanes of a wave that can take a SECOND group of tokens in a round (0 = never; fixed blocks)
 constexpr uint32_t MOVES = 3;              // move iterations (up to 4 bytes per lane each) per round; round 3, with the far copies in the loop: 2 / 3 / 4 / 6: 4.21 / 3.95 / 4.10 / 3.99 ms
 #ifdef HDLZ_TOK_MARKS                         // tools/phase_count.py --src hdlz_inflate_tok.hip -DHDLZ_TOK_MARKS: static counts per part
@@ -355,6 +352,44 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
             dist_info(ds, dbase, deb);
             return !valid ? NO_DCODE : ds >= 30u ? BAD_DCODE : (dbase | (deb << 16));
         }
+    };
+    // ---- fixed blocks, the fast path's GROUP: up to three literals and the match behind them, decoded at output position `at` into
+    // (lv, ln, rm, ds).  ONE source for both decode steps of a round: SECOND = false is step 1 (the lane has nothing pending; bc >= 33
+    // after the refill, so the literals need no bit count; a far match is taken and the caller requests its history), SECOND = true is
+    // step 2 (behind a pending group: every symbol only while a buffered bit is left behind it, near matches only).  A match is only taken
+    // with every check of deflate.py:1576-1585, :1597-1602 passing at `at` + the literals; returns 0 = no match, 1 = a near one, 2 = a far one.
+    auto fixed_group = [&](auto SECOND, const uint32_t at, uint32_t& lv, uint32_t& ln, uint32_t& rm, uint32_t& ds) -> uint32_t {
+        constexpr bool second = decltype(SECOND)::value;
+        uint32_t nl = 0;
+#pragma unroll
+        for (uint32_t extra = 0; extra < 3u; extra++) {
+            const uint32_t e2 = lit_at((uint32_t)bb);
+            if (nl == extra && ((e2 >> 13) & 3u) == (uint32_t)T_LIT && at + extra < cap && (!second || (e2 & 15u) < bc)) {
+                lv = extra == 0u ? ((e2 >> 4) & 0xFFu) : (lv | (((e2 >> 4) & 0xFFu) << (8u * extra)));
+                nl = extra + 1u;
+                bb >>= (e2 & 15u); bc -= (e2 & 15u);
+            }
+        }
+        ln = nl;
+        const uint32_t e = lit_at((uint32_t)bb);
+        const uint32_t nb = e & 15u, type = (e >> 13) & 3u;
+        const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;
+        uint64_t x = bb >> nb;
+        const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));
+        x >>= leb;
+        uint32_t dnb;
+        const uint32_t de = dst_at((uint32_t)x, dnb);
+        const uint32_t deb = (de >> 16) & 15u;
+        const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> dnb) & ((1u << deb) - 1u));
+        const uint32_t mbits = nb + leb + dnb + deb;
+        const uint32_t om = at + nl;                            // where the copy will start
+        const bool len_ok = (type == (uint32_t)T_LEN) & (mbits < bc) & (de < NO_DCODE) & (distance <= om) & (distance <= obsize) &
+                            (om + tlength <= cap) & (!second || distance <= NEAR);
+        if (len_ok) {
+            bb >>= mbits; bc -= mbits;
+            rm = tlength; ds = distance;
+        }
+        return !len_ok ? 0u : distance > NEAR ? 2u : 1u;
     };
     // ---- DYN: restart the bit reader at an absolute bit position (the second pass over a block header)
 #define TOK_RESYNC(bitp) do {                                                                           \
@@ -684,39 +719,12 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                     slow = true;                                    // EOB, invalid data, any failing check
                 }
               } else {
-                uint32_t nl = 0;
-#pragma unroll
-                for (uint32_t extra = 0; extra < 3u; extra++) {    // (the third look-up still has 33 - 9 - 9 = 15 valid bits;
-                    const uint32_t e2 = lit_at((uint32_t)bb);      //  DYN: codes of up to 15 bits, taken while a bit is left behind)
-                    if (nl == extra && ((e2 >> 13) & 3u) == (uint32_t)T_LIT && o + extra < cap && (!DYN || (e2 & 15u) < bc)) {
-                        litv = extra == 0u ? ((e2 >> 4) & 0xFFu) : (litv | (((e2 >> 4) & 0xFFu) << (8u * extra)));
-                        nl = extra + 1u;
-                        bb >>= (e2 & 15u); bc -= (e2 & 15u);
-                    }
-                }
-                litn = nl;
-                const uint32_t e = lit_at((uint32_t)bb);
-                const uint32_t nb = e & 15u, type = (e >> 13) & 3u;
-                const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;
-                uint64_t x = bb >> nb;
-                const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));
-                x >>= leb;
-                uint32_t dnb;
-                const uint32_t de = dst_at((uint32_t)x, dnb);
-                const uint32_t deb = (de >> 16) & 15u;
-                const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> dnb) & ((1u << deb) - 1u));
-                const uint32_t mbits = nb + leb + dnb + deb;
-                const uint32_t om = o + nl;                 // where the copy will start
-                const bool len_ok = (type == (uint32_t)T_LEN) & (mbits < bc) & (de < NO_DCODE) & (distance <= om) &
-                                    (distance <= obsize) & (om + tlength <= cap);
-                if (len_ok) {
-                    bb >>= mbits; bc -= mbits;
-                    rem = tlength; dist = distance;
-                    if (distance > NEAR) {
-                        // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 <= om - 97 < flushed)
-                        far4 = *reinterpret_cast<const u32x4_unaligned*>(out + (om - distance));
-                    }
-                } else if (nl == 0u) {
+                // (after the refill bc >= 33: the third literal look-up still has 33 - 9 - 9 = 15 valid bits, no bit count to check)
+                const uint32_t got = fixed_group(std::false_type{}, o, litv, litn, rem, dist);
+                if (got == 2u) {
+                    // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 <= om - 97 < flushed)
+                    far4 = *reinterpret_cast<const u32x4_unaligned*>(out + (o + litn - dist));
+                } else if (got == 0u && litn == 0u) {
                     slow = true;                                    // EOB, invalid data, any failing check
                 }
               }
@@ -739,42 +747,11 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
             const uint32_t ns2 = (uint32_t)__popcll(ballot64(s2));
             if (ns2 >= STEP2_MIN) {
                 if (s2 && bc <= 32u && qn != 0u) TOK_POP();
-                if (s2 && ip + 3u <= zn) {
-                    const uint32_t ob = o + litn + rem;
-                    uint32_t nl = 0;
-#pragma unroll
-                    for (uint32_t extra = 0; extra < 3u; extra++) {
-                        const uint32_t e2 = lit_at((uint32_t)bb);
-                        if (nl == extra && ((e2 >> 13) & 3u) == (uint32_t)T_LIT && (e2 & 15u) < bc && ob + extra < cap) {
-                            litv2 = extra == 0u ? ((e2 >> 4) & 0xFFu) : (litv2 | (((e2 >> 4) & 0xFFu) << (8u * extra)));
-                            nl = extra + 1u;
-                            bb >>= (e2 & 15u); bc -= (e2 & 15u);
-                        }
-                    }
-                    litn2 = nl;
-                    const uint32_t e = lit_at((uint32_t)bb);
-                    const uint32_t nb = e & 15u, type = (e >> 13) & 3u;
-                    const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;
-                    uint64_t x = bb >> nb;
-                    const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));
-                    x >>= leb;
-                    uint32_t dnb;
-                    const uint32_t de = dst_at((uint32_t)x, dnb);
-                    const uint32_t deb = (de >> 16) & 15u;
-                    const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> dnb) & ((1u << deb) - 1u));
-                    const uint32_t mbits = nb + leb + dnb + deb;
-                    const uint32_t om = ob + nl;
-                    const bool len_ok = (type == (uint32_t)T_LEN) & (mbits < bc) & (de < NO_DCODE) & (distance <= om) &
-                                        (distance <= obsize) & (om + tlength <= cap) & (distance <= NEAR);
-                    if (len_ok) {
-                        bb >>= mbits; bc -= mbits;
-                        rem2 = tlength; dist2 = distance;
-                    }
-                }
+                if (s2 && ip + 3u <= zn) fixed_group(std::true_type{}, o + litn + rem, litv2, litn2, rem2, dist2);
                 // worth it when most of those lanes got a match or three literals; else pause, twice as long every time
                 const uint32_t ngood = (uint32_t)__popcll(ballot64(s2 && (rem2 != 0u || litn2 == 3u)));
                 s2_live = s2_live || ballot64((litn2 | rem2) != 0u) != 0ull;
-                if (HDLZ_TOK_S2_YIELD * ngood < ns2) { s2_hold = s2_back; s2_back = min(2u * s2_back, 1024u); }
+                if (2u * ngood < ns2) { s2_hold = s2_back; s2_back = min(2u * s2_back, 1024u); }
                 else s2_back = 32u;
             }
           }

@@ -74,3 +74,18 @@ def test_tile_phases_have_one_source():
         assert "match_search<" in txt and "make_tokens<" in txt and "run_transfer(" in txt, f
         assert "umin3(m[i]" not in txt and "v_lshl_add_u32" not in txt, f      # no pasted phase bodies
     assert not os.path.exists(os.path.join(REPO, "tools", "gen_stream_kernel.py"))
+
+
+def test_inflate_group_decode_has_one_source():
+    """the fast path's group decode of the lane kernel (up to three literals + the match behind them, fixed blocks) lives ONCE -- the
+    `fixed_group` lambda of hdlz_inflate_tok.hip, called by both decode steps of a round --, the kernel file is not included twice
+    anywhere, and it keeps few preprocessor switches (VERDICT r3 #10)"""
+    csrc = os.path.join(REPO, "hdl_deflate_amd", "csrc")
+    txt = open(os.path.join(csrc, "hdlz_inflate_tok.hip")).read()
+    assert txt.count("auto fixed_group = [&]") == 1 and txt.count("fixed_group(std::") == 2
+    # the distance look-up behind a length: the group decode, the DYN fast path has its own (x_decode), the slow path
+    assert txt.count("dst_at((uint32_t)") == 2
+    assert sum(1 for ln in txt.splitlines() if ln.startswith("#if")) <= 5
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            assert '#include "hdlz_inflate_tok.hip"' not in open(os.path.join(csrc, f)).read(), f
