@@ -353,44 +353,43 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
             return !valid ? NO_DCODE : ds >= 30u ? BAD_DCODE : (dbase | (deb << 16));
         }
     };
-    // ---- fixed blocks, the fast path's GROUP: up to three literals and the match behind them, decoded at output position `at` into
-    // (lv, ln, rm, ds).  ONE source for both decode steps of a round: SECOND = false is step 1 (the lane has nothing pending; bc >= 33
-    // after the refill, so the literals need no bit count; a far match is taken and the caller requests its history), SECOND = true is
-    // step 2 (behind a pending group: every symbol only while a buffered bit is left behind it, near matches only).  A match is only taken
-    // with every check of deflate.py:1576-1585, :1597-1602 passing at `at` + the literals; returns 0 = no match, 1 = a near one, 2 = a far one.
-    auto fixed_group = [&](auto SECOND, const uint32_t at, uint32_t& lv, uint32_t& ln, uint32_t& rm, uint32_t& ds) -> uint32_t {
-        constexpr bool second = decltype(SECOND)::value;
-        uint32_t nl = 0;
-#pragma unroll
-        for (uint32_t extra = 0; extra < 3u; extra++) {
-            const uint32_t e2 = lit_at((uint32_t)bb);
-            if (nl == extra && ((e2 >> 13) & 3u) == (uint32_t)T_LIT && at + extra < cap && (!second || (e2 & 15u) < bc)) {
-                lv = extra == 0u ? ((e2 >> 4) & 0xFFu) : (lv | (((e2 >> 4) & 0xFFu) << (8u * extra)));
-                nl = extra + 1u;
-                bb >>= (e2 & 15u); bc -= (e2 & 15u);
-            }
-        }
-        ln = nl;
-        const uint32_t e = lit_at((uint32_t)bb);
-        const uint32_t nb = e & 15u, type = (e >> 13) & 3u;
-        const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;
-        uint64_t x = bb >> nb;
-        const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));
-        x >>= leb;
-        uint32_t dnb;
-        const uint32_t de = dst_at((uint32_t)x, dnb);
-        const uint32_t deb = (de >> 16) & 15u;
-        const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> dnb) & ((1u << deb) - 1u));
-        const uint32_t mbits = nb + leb + dnb + deb;
-        const uint32_t om = at + nl;                            // where the copy will start
-        const bool len_ok = (type == (uint32_t)T_LEN) & (mbits < bc) & (de < NO_DCODE) & (distance <= om) & (distance <= obsize) &
-                            (om + tlength <= cap) & (!second || distance <= NEAR);
-        if (len_ok) {
-            bb >>= mbits; bc -= mbits;
-            rm = tlength; ds = distance;
-        }
-        return !len_ok ? 0u : distance > NEAR ? 2u : 1u;
-    };
+    // ---- fixed blocks, the fast path's GROUP: up to three literals and the match behind them, decoded at output position AT into
+    // (LV, LN, RM, DS).  ONE source for both decode steps of a round -- a macro, not a lambda: called through a lambda the same text
+    // compiled to 3 VALU + 13 SALU instructions more per round (configs[4] round trip 401 -> 392 GB/s).  SECOND = false is step 1 (the lane
+    // has nothing pending; bc >= 33 after the refill, so the literals need no bit count -- the third look-up still has 33 - 9 - 9 = 15
+    // valid bits --; a far match is taken and the caller requests its history), SECOND = true is step 2 (behind a pending group: every
+    // symbol only while a buffered bit is left behind it, near matches only).  A match is only taken with every check of
+    // deflate.py:1576-1585, :1597-1602 passing at OM = AT + the literals; OK says whether one was taken.
+#define TOK_FIXED_GROUP(SECOND, AT, LV, LN, RM, DS, OM, OK) do {                                        \
+        uint32_t nl_ = 0;                                                                                  \
+        _Pragma("unroll") for (uint32_t extra = 0; extra < 3u; extra++) {                                  \
+            const uint32_t e2 = lit_at((uint32_t)bb);                                                      \
+            if (nl_ == extra && ((e2 >> 13) & 3u) == (uint32_t)T_LIT && (AT) + extra < cap && (!(SECOND) || (e2 & 15u) < bc)) { \
+                LV = extra == 0u ? ((e2 >> 4) & 0xFFu) : (LV | (((e2 >> 4) & 0xFFu) << (8u * extra)));     \
+                nl_ = extra + 1u;                                                                          \
+                bb >>= (e2 & 15u); bc -= (e2 & 15u);                                                       \
+            }                                                                                              \
+        }                                                                                                  \
+        LN = nl_;                                                                                          \
+        const uint32_t e = lit_at((uint32_t)bb);                                                           \
+        const uint32_t nb = e & 15u, type = (e >> 13) & 3u;                                                \
+        const uint32_t leb = (e >> 25) & 7u, lbase = (e >> 16) & 0x1FFu;                                   \
+        uint64_t x = bb >> nb;                                                                             \
+        const uint32_t tlength = lbase + ((uint32_t)x & ((1u << leb) - 1u));                               \
+        x >>= leb;                                                                                         \
+        uint32_t dnb;                                                                                      \
+        const uint32_t de = dst_at((uint32_t)x, dnb);                                                      \
+        const uint32_t deb = (de >> 16) & 15u;                                                             \
+        const uint32_t distance = (de & 0xFFFFu) + ((uint32_t)(x >> dnb) & ((1u << deb) - 1u));            \
+        const uint32_t mbits = nb + leb + dnb + deb;                                                       \
+        OM = (AT) + nl_;                                        /* where the copy will start */            \
+        OK = (type == (uint32_t)T_LEN) & (mbits < bc) & (de < NO_DCODE) & (distance <= OM) & (distance <= obsize) & \
+             (OM + tlength <= cap) & (!(SECOND) || distance <= NEAR);                                      \
+        if (OK) {                                                                                          \
+            bb >>= mbits; bc -= mbits;                                                                     \
+            RM = tlength; DS = distance;                                                                   \
+        }                                                                                                  \
+    } while (0)
     // ---- DYN: restart the bit reader at an absolute bit position (the second pass over a block header)
 #define TOK_RESYNC(bitp) do {                                                                           \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* no LDS-DMA may land in the slot after this */ \
@@ -720,11 +719,14 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
                 }
               } else {
                 // (after the refill bc >= 33: the third literal look-up still has 33 - 9 - 9 = 15 valid bits, no bit count to check)
-                const uint32_t got = fixed_group(std::false_type{}, o, litv, litn, rem, dist);
-                if (got == 2u) {
-                    // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 <= om - 97 < flushed)
-                    far4 = *reinterpret_cast<const u32x4_unaligned*>(out + (o + litn - dist));
-                } else if (got == 0u && litn == 0u) {
+                uint32_t om; bool len_ok;
+                TOK_FIXED_GROUP(false, o, litv, litn, rem, dist, om, len_ok);
+                if (len_ok) {
+                    if (dist > NEAR) {
+                        // (one 16-byte request: the TA is the busiest unit of this kernel; src + 16 <= om - 97 < flushed)
+                        far4 = *reinterpret_cast<const u32x4_unaligned*>(out + (om - dist));
+                    }
+                } else if (litn == 0u) {
                     slow = true;                                    // EOB, invalid data, any failing check
                 }
               }
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
             const uint32_t ns2 = (uint32_t)__popcll(ballot64(s2));
             if (ns2 >= STEP2_MIN) {
                 if (s2 && bc <= 32u && qn != 0u) TOK_POP();
-                if (s2 && ip + 3u <= zn) fixed_group(std::true_type{}, o + litn + rem, litv2, litn2, rem2, dist2);
+                if (s2 && ip + 3u <= zn) { uint32_t om2; bool ok2; TOK_FIXED_GROUP(true, o + litn + rem, litv2, litn2, rem2, dist2, om2, ok2); }
                 // worth it when most of those lanes got a match or three literals; else pause, twice as long every time
                 const uint32_t ngood = (uint32_t)__popcll(ballot64(s2 && (rem2 != 0u || litn2 == 3u)));
                 s2_live = s2_live || ballot64((litn2 | rem2) != 0u) != 0ull;
@@ -875,6 +877,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
 #undef TOK_REFILL
 #undef TOK_REQUEST
 #undef TOK_FLUSH
+#undef TOK_FIXED_GROUP
 
     // no LDS-DMA load may still be in flight when this wave's LDS is handed to another workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -885,57 +888,38 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     TOK_STORE_RESULT();
 }
 
-// the streams pass 1 flagged HDLZ_E_DYNAMIC_UNSUPPORTED, as a dense list: the lanes of k_inflate_tok<true> are then all busy whatever
-// the share of such streams is (list[0 .. *n) in no particular order: the streams are independent)
-__global__ __launch_bounds__(256) void k_collect_dyn(const uint32_t* __restrict__ status, uint64_t nstreams, uint32_t* __restrict__ list,
-                                                      uint32_t* __restrict__ n, uint32_t code = HDLZ_E_DYNAMIC_UNSUPPORTED) {
-    // ONE atomic per workgroup (round 4: one per wave was 4096 atomics on one counter for 262144 streams, 49 us of a 1.4 ms job)
-    __shared__ uint32_t wcnt[4], wbase;
-    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const bool mine = gid < nstreams && status[gid] == code;
-    const uint64_t m = ballot64(mine);
-    const uint32_t wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63u) == 0u) wcnt[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    const uint32_t c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
-    if (c0 + c1 + c2 + c3 == 0u) return;
-    if (threadIdx.x == 0u) wbase = atomicAdd(n, c0 + c1 + c2 + c3);
-    __syncthreads();
-    const uint32_t base = wbase + (wave > 0u ? c0 : 0u) + (wave > 1u ? c1 : 0u) + (wave > 2u ? c2 : 0u);
-    if (mine) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)gid;
-}
-
 // ---- length-binned lane assignment (round 4).  The 64 streams of a wave run in lockstep until the LAST of them is done, and a
 // round costs the same whatever its lanes have to do: a wave of mixed streams pays the rounds of its longest stream with the
 // instruction mix of its most demanding one (BASELINE configs[4] read back, blocks of four families side by side: 85.7 M cycles per
 // wave against 57 M / 40 M for waves of one family, profiles/r04_tok_round_timing.txt).  With a ragged archive the compressed
 // lengths are known before the launch, so the streams are handed to the lanes in the order of their length class -- quarter octaves,
-// longest first (the long streams start first, the short ones fill the tail): a counting sort in three small launches, the
-// permutation in stream-ordered scratch.  The order inside a class is whatever the atomics give: streams are independent,
-// results do not depend on it.
+// longest first (the long streams start first, the short ones fill the tail; the order is worth 13 % on the dynamic-tree entry) --: a
+// counting sort in two launches (counts + first slots by the last block to arrive, then the scatter), the permutation in
+// stream-ordered scratch.  The order inside a class is whatever the atomics give: streams are independent, results do not depend on it.
 constexpr uint32_t NBIN = 128;
+constexpr uint32_t BIN_WORDS = NBIN + 2u;   // bins[0 .. NBIN): counts, then cursors; bins[NBIN]: the list length; bins[NBIN + 1]: arrival ticket
 __device__ __forceinline__ uint32_t len_bin(uint64_t len64) {
     const uint32_t l = (uint32_t)(len64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : len64) | 4u;
     const uint32_t msb = 31u - (uint32_t)__builtin_clz(l);
     return (NBIN - 1u) - (4u * msb + ((l >> (msb - 2u)) & 3u));        // bin 0 = the longest streams
 }
-// (src / src_n: the streams to order are src[0 .. *src_n) -- the list of the dynamic-tree pass -- instead of 0 .. n - 1)
-__global__ __launch_bounds__(256) void k_bin_hist(const uint64_t* __restrict__ in_off, uint32_t n, uint32_t* __restrict__ hist,
-                                                   const uint32_t* __restrict__ src, const uint32_t* __restrict__ src_n) {
-    __shared__ uint32_t lh[NBIN];
-    if (src_n) n = min(n, *src_n);
-    if (blockIdx.x * 256u >= n) return;
-    if (threadIdx.x < NBIN) lh[threadIdx.x] = 0u;
+// the block's counts go to the global ones; the LAST of `nact` blocks to arrive turns them into first slots (exclusive scan, in place) and
+// stores the list length -- what was a launch of its own (k_bin_scan).  Called by all 256 threads of every participating block.
+__device__ __forceinline__ void bin_flush_and_finish(const uint32_t* lh, uint32_t* __restrict__ bins, uint32_t nact, const uint32_t* nlist_p,
+                                                     uint32_t nlist_max) {
+    __shared__ uint32_t last;
+    // (no __threadfence: an agent-scope fence writes the XCD's L2 back, 200 us over 4096 blocks.  The counts are only ever touched by
+    //  agent-scope atomics, which are performed at the coherence point; what is needed is their ORDER -- this block's adds acknowledged
+    //  before its ticket -- and the last block reading them with atomic loads)
+    if (threadIdx.x < NBIN && lh[threadIdx.x]) atomicAdd(&bins[threadIdx.x], lh[threadIdx.x]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) { const uint32_t sid = src ? src[i] : i; atomicAdd(&lh[len_bin(in_off[sid + 1] - in_off[sid])], 1u); }
+    if (threadIdx.x == 0u) last = atomicAdd(&bins[NBIN + 1u], 1u) == nact - 1u ? 1u : 0u;
     __syncthreads();
-    if (threadIdx.x < NBIN && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
-}
-// hist[0 .. NBIN) -> first slot per class (in place); ws[NBIN] = the list length the decode kernel reads
-__global__ __launch_bounds__(64) void k_bin_scan(uint32_t* __restrict__ ws, uint32_t n, const uint32_t* __restrict__ src_n) {
+    if (last == 0u || threadIdx.x >= 64u) return;
     const uint32_t lane = threadIdx.x;
-    const uint32_t c0 = ws[2u * lane], c1 = ws[2u * lane + 1u];
+    const uint32_t c0 = __hip_atomic_load(&bins[2u * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t c1 = __hip_atomic_load(&bins[2u * lane + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t v = c0 + c1;
 #pragma unroll
     for (int ofs = 1; ofs < 64; ofs <<= 1) {
@@ -943,8 +927,49 @@ __global__ __launch_bounds__(64) void k_bin_scan(uint32_t* __restrict__ ws, uint
         if (lane >= (uint32_t)ofs) v += o;
     }
     const uint32_t excl = v - (c0 + c1);
-    ws[2u * lane] = excl; ws[2u * lane + 1u] = excl + c0;
-    if (lane == 0u) ws[NBIN] = src_n ? min(n, *src_n) : n;
+    bins[2u * lane] = excl; bins[2u * lane + 1u] = excl + c0;
+    if (lane == 0u) {
+        const uint32_t nl = nlist_p ? __hip_atomic_load(nlist_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : nlist_max;
+        bins[NBIN] = min(nl, nlist_max);
+    }
+}
+
+// the streams pass 1 flagged HDLZ_E_DYNAMIC_UNSUPPORTED, as a dense list: the lanes of k_inflate_tok<true> are then all busy whatever
+// the share of such streams is (list[0 .. *n) in no particular order: the streams are independent).  With `in_off` / `bins` the kernel
+// also counts the length classes of the listed streams (and its last block makes the first slots of them): the counting sort of
+// the dynamic-tree pass then needs only the scatter.
+__global__ __launch_bounds__(256) void k_collect_dyn(const uint32_t* __restrict__ status, uint64_t nstreams, uint32_t* __restrict__ list,
+                                                      uint32_t* __restrict__ n, const uint64_t* __restrict__ in_off = nullptr,
+                                                      uint32_t* __restrict__ bins = nullptr, uint32_t code = HDLZ_E_DYNAMIC_UNSUPPORTED) {
+    // ONE atomic per workgroup (round 4: one per wave was 4096 atomics on one counter for 262144 streams, 49 us of a 1.4 ms job)
+    __shared__ uint32_t wcnt[4], wbase, lh[NBIN];
+    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const bool mine = gid < nstreams && status[gid] == code;
+    const uint64_t m = ballot64(mine);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u) wcnt[wave] = (uint32_t)__popcll(m);
+    if (bins && threadIdx.x < NBIN) lh[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+    if (c0 + c1 + c2 + c3 != 0u) {
+        if (threadIdx.x == 0u) wbase = atomicAdd(n, c0 + c1 + c2 + c3);
+        if (bins && mine) atomicAdd(&lh[len_bin(in_off[gid + 1] - in_off[gid])], 1u);
+        __syncthreads();
+        const uint32_t base = wbase + (wave > 0u ? c0 : 0u) + (wave > 1u ? c1 : 0u) + (wave > 2u ? c2 : 0u);
+        if (mine) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)gid;
+    }
+    if (bins) bin_flush_and_finish(lh, bins, gridDim.x, n, (uint32_t)min(nstreams, (uint64_t)0xFFFFFFFFull));
+}
+
+// (src / src_n: the streams to order are src[0 .. *src_n) -- the list of the dynamic-tree pass -- instead of 0 .. n - 1)
+__global__ __launch_bounds__(256) void k_bin_hist(const uint64_t* __restrict__ in_off, uint32_t n, uint32_t* __restrict__ bins) {
+    __shared__ uint32_t lh[NBIN];
+    if (threadIdx.x < NBIN) lh[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) atomicAdd(&lh[len_bin(in_off[i + 1] - in_off[i])], 1u);
+    __syncthreads();
+    bin_flush_and_finish(lh, bins, gridDim.x, nullptr, n);
 }
 __global__ __launch_bounds__(256) void k_bin_scatter(const uint64_t* __restrict__ in_off, uint32_t n, uint32_t* __restrict__ cursor,
                                                       uint32_t* __restrict__ list, const uint32_t* __restrict__ src,
@@ -963,16 +988,14 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint64_t* __restrict_
     if (i < n) list[lbase[bin] + rank] = sid;
 }
 
-// the three launches: bins[0 .. NBIN] (zeroed here) and `list` (n words) in caller-provided scratch; the decode kernel takes
-// `list` and the count at bins + NBIN
-static hipError_t bin_streams(const uint64_t* in_off, uint32_t n, uint32_t* bins, uint32_t* list, const uint32_t* src,
-                              const uint32_t* src_n, hipStream_t stream) {
-    hipError_t e = zero_words(bins, NBIN, stream);
+// pass 1's order: bins[0 .. BIN_WORDS) (zeroed here) and `list` (n words) in caller-provided scratch; the decode kernel takes `list`
+// and the count at bins + NBIN
+static hipError_t bin_streams(const uint64_t* in_off, uint32_t n, uint32_t* bins, uint32_t* list, hipStream_t stream) {
+    hipError_t e = zero_words(bins, BIN_WORDS, stream);
     if (e != hipSuccess) return e;
     const dim3 bgrid((n + 255u) / 256u), bblock(256);
-    hipLaunchKernelGGL(k_bin_hist, bgrid, bblock, 0, stream, in_off, n, bins, src, src_n);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(64), 0, stream, bins, n, src_n);
-    hipLaunchKernelGGL(k_bin_scatter, bgrid, bblock, 0, stream, in_off, n, bins, list, src, src_n);
+    hipLaunchKernelGGL(k_bin_hist, bgrid, bblock, 0, stream, in_off, n, bins);
+    hipLaunchKernelGGL(k_bin_scatter, bgrid, bblock, 0, stream, in_off, n, bins, list, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -985,14 +1008,14 @@ hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
     const dim3 grid((unsigned)((a.nstreams + per_wg - 1u) / per_wg)), block(64 * L::WAVES);
     // ragged input of more than one wave: the lanes take the streams in the order of their length class (see k_bin_*)
     if (a.in_off && a.nstreams > HDLZ_INFLATE_BIN_MIN && a.nstreams <= 0xFFFFFFFFull) {
-        uint32_t* ws = nullptr;                  // ws[0 .. NBIN): counts, then cursors; ws[NBIN]: n; the list from ws + NBIN + 1 on
+        uint32_t* ws = nullptr;                  // ws[0 .. BIN_WORDS): the bins (see tok::BIN_WORDS); the list behind them
         const uint32_t n = (uint32_t)a.nstreams;
-        hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * ((size_t)n + tok::NBIN + 1u), stream);
+        hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * ((size_t)n + tok::BIN_WORDS), stream);
         if (e == hipSuccess) {
-            e = tok::bin_streams(a.in_off, n, ws, ws + tok::NBIN + 1u, nullptr, nullptr, stream);
+            e = tok::bin_streams(a.in_off, n, ws, ws + tok::BIN_WORDS, stream);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL((tok::k_inflate_tok<false, tok::CAP_FULL>), grid, block, 0, stream, a,
-                                   (const uint32_t*)(ws + tok::NBIN + 1u), (const uint32_t*)(ws + tok::NBIN), 0u);
+                                   (const uint32_t*)(ws + tok::BIN_WORDS), (const uint32_t*)(ws + tok::NBIN), 0u);
                 e = hipGetLastError();
             }
             const hipError_t e2 = hipFreeAsync(ws, stream);
@@ -1014,31 +1037,43 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
     if (a.nstreams == 0 || (a.flags & HDLZ_INFLATE_ASSUME_FIXED)) return hipSuccess;
     const dim3 grid((unsigned)((a.nstreams + 63u) / 64u)), block(64);
     const dim3 cgrid((unsigned)((a.nstreams + 255u) / 256u)), cblock(256);
-    uint32_t* ws = nullptr;                      // ws[0], ws[1]: the two counts; the list from ws + 2 on (both stages: the launches are ordered)
+    // ws[0], ws[1]: the two counts; ws[2 .. 2 + BIN_WORDS): the bins of stage 1's counting sort (zeroed with the counts in one launch);
+    // the collected list behind them (both stages: the launches are ordered), the length-ordered list of stage 1 behind that
+    uint32_t* ws = nullptr;
     // (the explicit lane hint keeps every such stream in the lane kernels)
     const uint32_t lane_min = (a.flags & HDLZ_INFLATE_LANE_PER_STREAM) ? 0u : HDLZ_INFLATE_DYN_LANE_MIN;
-    // ragged input: stage 1 takes its streams in the order of their length class, like pass 1 (bins + the ordered list behind the list)
+    // ragged input: stage 1 takes its streams in the order of their length class, like pass 1: k_collect_dyn counts the classes of the
+    // streams it lists and its last block makes the first slots, so the sort adds ONE launch (the scatter)
     const bool binned = a.in_off != nullptr && a.nstreams > HDLZ_INFLATE_BIN_MIN && !all;
-    const size_t nws = (size_t)a.nstreams + 2u + (binned ? (size_t)a.nstreams + tok::NBIN + 1u : 0u);
+    const uint32_t head = 2u + tok::BIN_WORDS;
+    const size_t nws = (size_t)head + a.nstreams + (binned ? (size_t)a.nstreams : 0u);
     hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * nws, stream);
     if (e != hipSuccess) {                      // no scratch: the wave-per-stream pass needs none and finishes the job
         (void)hipGetLastError();
         return launch_inflate_dyn(a, stream, all);
     }
-    e = zero_words(ws, 2u, stream);
+    uint32_t* const bins = ws + 2;
+    uint32_t* const list0 = ws + head;
+    e = zero_words(ws, head, stream);
     if (e == hipSuccess) {
         if (all) {
             hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, (const uint32_t*)nullptr,
                                (const uint32_t*)nullptr, 0u);
             e = hipGetLastError();
         } else {
-            hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, ws + 2, ws);
-            const uint32_t* list1 = ws + 2;
+            const uint32_t* list1 = list0;
             if (binned) {
-                uint32_t* bins = ws + 2 + a.nstreams;
-                e = tok::bin_streams(a.in_off, (uint32_t)a.nstreams, bins, bins + tok::NBIN + 1u, ws + 2, ws, stream);
-                list1 = bins + tok::NBIN + 1u;
+                hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, list0, ws, a.in_off, bins,
+                                   (uint32_t)HDLZ_E_DYNAMIC_UNSUPPORTED);
+                uint32_t* const ordered = list0 + a.nstreams;
+                hipLaunchKernelGGL(tok::k_bin_scatter, cgrid, cblock, 0, stream, a.in_off, (uint32_t)a.nstreams, bins, ordered,
+                                   (const uint32_t*)list0, (const uint32_t*)ws);
+                list1 = ordered;
+            } else {
+                hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, list0, ws, (const uint64_t*)nullptr,
+                                   (uint32_t*)nullptr, (uint32_t)HDLZ_E_DYNAMIC_UNSUPPORTED);
             }
+            e = hipGetLastError();
             if (e == hipSuccess) {
                 hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, list1, (const uint32_t*)ws, lane_min);
                 e = hipGetLastError();
@@ -1048,8 +1083,9 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
     }
     // stage 2: what is still flagged
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, ws + 2, ws + 1);
-        hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_FULL>), grid, block, 0, stream, a, (const uint32_t*)(ws + 2),
+        hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, list0, ws + 1, (const uint64_t*)nullptr,
+                           (uint32_t*)nullptr, (uint32_t)HDLZ_E_DYNAMIC_UNSUPPORTED);
+        hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_FULL>), grid, block, 0, stream, a, (const uint32_t*)list0,
                            (const uint32_t*)(ws + 1), lane_min);
         e = hipGetLastError();
         if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws + 1, lane_min);
