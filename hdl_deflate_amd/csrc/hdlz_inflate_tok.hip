@@ -909,9 +909,12 @@ __device__ __forceinline__ void bin_flush_and_finish(const uint32_t* lh, uint32_
                                                      uint32_t nlist_max) {
     __shared__ uint32_t last;
     // (no __threadfence: an agent-scope fence writes the XCD's L2 back, 200 us over 4096 blocks.  The counts are only ever touched by
-    //  agent-scope atomics, which are performed at the coherence point; what is needed is their ORDER -- this block's adds acknowledged
-    //  before its ticket -- and the last block reading them with atomic loads)
-    if (threadIdx.x < NBIN && lh[threadIdx.x]) atomicAdd(&bins[threadIdx.x], lh[threadIdx.x]);
+    //  agent-scope atomics, which are performed at the coherence point; what is needed is their ORDER -- this block's adds performed (their
+    //  old values returned) before its ticket -- and the last block reading them with atomic loads)
+    if (threadIdx.x < NBIN && lh[threadIdx.x]) {
+        const uint32_t old = atomicAdd(&bins[threadIdx.x], lh[threadIdx.x]);     // RETURNING: the value is back = the add has been performed
+        asm volatile("" :: "v"(old) : "memory");
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0u) last = atomicAdd(&bins[NBIN + 1u], 1u) == nact - 1u ? 1u : 0u;

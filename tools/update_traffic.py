@@ -56,8 +56,11 @@ for fn, key, kern, tag in SPEC:
          "kernel": kern, "grid": grid[0], "hdlz_version": VERSION,
          "valu_insts": val("SQ_INSTS_VALU"), "salu_insts": val("SQ_INSTS_SALU"), "gui_active": val("GRBM_GUI_ACTIVE"),
          "cycles_per_valu_inst": 4.0,
-         "issue_note": "est_issue_cycles = SQ_INSTS_VALU x 4 cycles (a wave64 instruction on a 16-lane SIMD; profiles/r04_ubench/ubench_valu_cycles.txt: "
-                       "1.96 .. 3.3 cycles at 4 waves per SIMD for the cheapest ops, 4.8 at one wave) / 1024 SIMDs; kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs",
+         "issue_note": "est_issue_cycles = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs: an UPPER price -- measured in shader cycles "
+                       "(profiles/r04_ubench/ubench_valu_cycles*.txt) a wave64 instruction costs 1.96 (add/sub/and/or/xor/lshr/ashr/mov/min_u16/bitop3) "
+                       "or 3.25 cycles (everything else) at >= 4 waves per SIMD, 2.4 / 4.4 at two waves, 4.9 at one; the compress tile mixes 59 % / 41 % "
+                       "of the two classes (tools/phase_count.py); kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs (GRBM_GUI_ACTIVE / wall time = 2.4 GHz; "
+                       "s_memtime / wall time = 1.8-2.1 GHz under these loads)",
          "note": "round 4, %s: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE" % kern}
     rd, wr = val("TCC_EA0_RDREQ"), val("TCC_EA0_WRREQ")
     if rd is not None:
