@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
                 }
             }
             // zero the bit buffer, seed the carry
-            if constexpr (!HASH) for (uint32_t w = lane; w < OUT_WORDS; w += 64) lout[w] = (w == 0) ? carry_word : 0u;
+            if constexpr (!HASH) zero_bit_buffer(lout, lane, carry_word);
             __syncthreads();
 
             // -------------------------------------------------------------- 2..6: the shared tile phases (hdlz_compress_common.h)
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
             HDLZ_MARK("search");
             if constexpr (HASH) {
                 match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);               // 2. R3/R4, wide windows
-                for (uint32_t w = lane; w < OUT_WORDS; w += 64) lout[w] = (w == 0) ? carry_word : 0u;      // (ordered before the scatter by the fences below)
+                zero_bit_buffer(lout, lane, carry_word);                                           // (ordered before the scatter by the fences below)
             } else match_search<NCH>(lds.in, run_dw, best);                                        // 2. R3/R4
             {
                 HDLZ_MARK("adler");
@@ -186,10 +186,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
                 const uint32_t ninv = t0 + TILE - n;
                 const uint32_t end_bits = base_bits + tile_bits_all - 8u * ninv;
                 // wipe everything behind the real end: partial word masked, later words zeroed
+                // (only the words that go out: the partial word, the EOB / pad bits and the trailer end within four words of `ew`, and
+                //  ew + 3 <= (19 + 9 * 2048) / 32 + 3 < OUT_WORDS; the rest of the buffer is zeroed when the next tile is staged)
                 {
                     const uint32_t ew = end_bits >> 5, rb = end_bits & 31u;
-                    for (uint32_t w = ew + lane; w < OUT_WORDS; w += 64)
-                        lout[w] = (w == ew) ? (lout[w] & ((1u << rb) - 1u)) : 0u;
+                    if (lane < 4u) lout[ew + lane] = (lane == 0u) ? (lout[ew] & ((1u << rb) - 1u)) : 0u;
                 }
                 // R8: EOB = 7 zero bits, zero pad to a byte, Adler-32 big-endian (s2 then s1)
                 uint32_t s1 = ad_a % ADLER_MOD, s2 = ad_w;

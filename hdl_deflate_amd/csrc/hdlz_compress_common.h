@@ -551,20 +551,30 @@ __device__ __forceinline__ uint64_t run_transfer(const uint32_t (&tok)[RUN]) {
 // ---- phase 4b: compose the 64 run functions across the wave (serial, on the scalar unit).  s: in = entry skip of lane 0,
 // out = exit skip of lane 63; returns this lane's entry skip.
 __device__ __forceinline__ uint32_t chain_skips(uint64_t P, uint32_t lane, uint32_t& s) {
-    const uint32_t plo = (uint32_t)P, phi = (uint32_t)(P >> 32);
+    const uint32_t plo = (uint32_t)P;
+    // the upper part of a function is 8 bits (entry skips 8 and 9): the four of a quad of lanes are packed into ONE register first (two
+    // quad-permute moves), so the scalar chain reads 64 + 16 lanes instead of 2 x 64 (v_readlane is a 3.25-cycle instruction)
+    uint32_t ph4 = (uint32_t)(P >> 32) & 0xFFu;
+    ph4 |= (uint32_t)__builtin_amdgcn_mov_dpp((int)ph4, 0xB1, 0xF, 0xF, true) << 8;      // quad_perm [1,0,3,2]: lanes 0 / 2 of a quad get their neighbour
+    ph4 |= (uint32_t)__builtin_amdgcn_mov_dpp((int)ph4, 0x4E, 0xF, 0xF, true) << 16;     // quad_perm [2,3,0,1]: lane 0 gets the pair of lanes 2, 3
     uint64_t sv[4] = {0, 0, 0, 0};     // entry skips of all 64 lanes, one nibble each (scalar regs)
-    // 4 segments of 16 lanes; the scheduling barriers keep the compiler from hoisting all 128
+    // 4 segments of 16 lanes; the scheduling barriers keep the compiler from hoisting all the
     // readlanes to the top (that needed ~260 SGPR spills = v_writelane/v_readlane traffic)
     static_for<0, 4>([&](auto G) {
         constexpr int g = decltype(G)::value;
         uint64_t acc = 0;
 #pragma unroll
-        for (int l = 0; l < 16; l++) {
-            acc |= (uint64_t)s << (4 * l);
+        for (int q = 0; q < 4; q++) {
             // NB: readlane returns a signed int -- cast before widening or bit 31 smears into the high half
-            const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, g * 16 + l) << 32) |
-                               (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)plo, g * 16 + l);
-            s = (uint32_t)(f >> (4u * s)) & 15u;
+            const uint32_t hi4 = (uint32_t)__builtin_amdgcn_readlane((int)ph4, g * 16 + q * 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int l = q * 4 + k;
+                acc |= (uint64_t)s << (4 * l);
+                const uint64_t f = ((uint64_t)((hi4 >> (8 * k)) & 0xFFu) << 32) |
+                                   (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)plo, g * 16 + l);
+                s = (uint32_t)(f >> (4u * s)) & 15u;
+            }
         }
         sv[g] = acc;
         __builtin_amdgcn_sched_barrier(0);
@@ -639,6 +649,13 @@ __device__ __forceinline__ void adler_run(const uint32_t (&ow)[12], uint32_t& sa
         const uint32_t wts = (uint32_t)(4 * k) | ((uint32_t)(4 * k + 1) << 8) | ((uint32_t)(4 * k + 2) << 16) | ((uint32_t)(4 * k + 3) << 24);
         sc = __builtin_amdgcn_udot4(ow[k], wts, sc, false);
     }
+}
+
+// zero the bit buffer of a tile and seed its first word (16-byte stores: 3 LDS instructions per lane instead of 10)
+__device__ __forceinline__ void zero_bit_buffer(uint32_t* lout, uint32_t lane, uint32_t carry_word) {
+    static_assert(OUT_WORDS % 4 == 0, "16-byte stores");
+    for (uint32_t q = lane; q < (uint32_t)OUT_WORDS / 4u; q += 64u)
+        *reinterpret_cast<uint4*>(lout + 4u * q) = make_uint4(q == 0u ? carry_word : 0u, 0u, 0u, 0u);
 }
 
 // fill the per-wave LUTs (literal: [byte] -> code|nbits; match: [len-3][dist-1] (CWINDOW <= 32) or [dist-1])
