@@ -193,12 +193,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
                     if (lane < 4u) lout[ew + lane] = (lane == 0u) ? (lout[ew] & ((1u << rb) - 1u)) : 0u;
                 }
                 // R8: EOB = 7 zero bits, zero pad to a byte, Adler-32 big-endian (s2 then s1)
-                uint32_t s1 = ad_a % ADLER_MOD, s2 = ad_w;
-#pragma unroll
-                for (int ofs = 32; ofs > 0; ofs >>= 1) {
-                    s1 += __shfl_xor(s1, ofs, 64);
-                    s2 += __shfl_xor(s2, ofs, 64);
-                }
+                uint32_t s1 = wave_sum(ad_a % ADLER_MOD), s2 = wave_sum(ad_w);
                 s1 = (s1 + 1u) % ADLER_MOD;
                 s2 = (s2 + n % ADLER_MOD) % ADLER_MOD;
                 const uint32_t nbytes = (end_bits + 7u + 7u) >> 3;

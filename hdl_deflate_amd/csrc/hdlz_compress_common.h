@@ -610,13 +610,16 @@ __device__ __forceinline__ uint32_t token_codes(const uint8_t* lut8, uint32_t (&
     return lane_bits;
 }
 
-// inclusive wave scan (all 64 lanes must call it)
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int ofs = 1; ofs < 64; ofs <<= 1) {
-        const uint32_t o = __shfl_up(v, ofs, 64);
-        if (lane >= (uint32_t)ofs) v += o;
-    }
+// inclusive wave scan (all 64 lanes must call it): Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8; a lane without a source adds 0),
+// then the row totals across (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3) -- six DPP adds; the shuffle form
+// (__shfl_up = ds_bpermute + compare + select per step) was 38 VALU + 6 LDS instructions
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);     // row_bcast15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast31 -> rows 2, 3
     return v;
 }
 
@@ -649,6 +652,17 @@ __device__ __forceinline__ void adler_run(const uint32_t (&ow)[12], uint32_t& sa
         const uint32_t wts = (uint32_t)(4 * k) | ((uint32_t)(4 * k + 1) << 8) | ((uint32_t)(4 * k + 2) << 16) | ((uint32_t)(4 * k + 3) << 24);
         sc = __builtin_amdgcn_udot4(ow[k], wts, sc, false);
     }
+}
+
+// sum of v over the 64 lanes, as a wave-uniform value: four DPP adds inside the rows of 16 (quad permutes, half mirror, mirror: every lane
+// then holds its row's sum) and four v_readlane -- the xor butterfly through ds_bpermute was 36 VALU + 12 LDS instructions for two sums
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);      // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);      // row_mirror
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 // zero the bit buffer of a tile and seed its first word (16-byte stores: 3 LDS instructions per lane instead of 10)
