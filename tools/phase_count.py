@@ -2,7 +2,7 @@
 """Static per-phase instruction count of k_compress's tile body: hipcc -S, then count the instructions between the
 `; @@PHASE name` marks (HDLZ_MARK in hdlz_compress.hip).  The tile body is straight-line code executed once per tile,
 so static counts = dynamic counts per wave-tile; issue cycles are priced with the measured table of
-tools/ubench/valu_rate*.hip (2.8 cycles for v_add/sub/and/or/xor/lshr/mov, 4.25 for every other VALU op, @2.4 GHz).
+tools/ubench/valu_cycles*.hip (1.96 shader cycles for v_add/sub/and/or/xor/lshr/ashr/mov/min_u16/bitop3, 3.25 for every other VALU op).
 Usage: tools/phase_count.py [-DNAME ...] [--kernel MANGLED_SUBSTR] [--src FILE.hip]
 (k_inflate_tok: --src hdlz_inflate_tok.hip -DHDLZ_TOK_MARKS --kernel k_inflate_tokILb1E -- parts of the round loop, branches counted once)"""
 import collections
@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 FAST = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_mov_b32", "v_min_u16",
-        "v_add_co_u32", "v_not_b32")
+        "v_add_co_u32", "v_not_b32", "v_ashrrev_i32", "v_bitop3_b32", "v_max_i16")      # 1.96 cycles (profiles/r04_ubench/ubench_valu_cycles*.txt)
 defs = [a for a in sys.argv[1:] if a.startswith("-D")]
 kern = "k_compressILi1ELb1ELb1E"
 srcname = "hdlz_compress.hip"
@@ -43,7 +43,7 @@ for ln in body.splitlines():
     if op.startswith("v_"):
         if op.startswith(("v_readlane", "v_writelane", "v_readfirstlane")):
             c["valu_slow"] += 1
-        elif base in FAST:
+        elif base in FAST and not op.endswith(("_sdwa", "_dpp")):     # (every SDWA / DPP form runs at the slow rate)
             c["valu_fast"] += 1
         else:
             c["valu_slow"] += 1
@@ -58,7 +58,7 @@ print("%-10s %6s %6s %6s %5s %5s %5s %9s" % ("phase", "VALU", "fast", "slow", "S
 tot = collections.Counter()
 tile = collections.Counter()
 for ph, c in cnt.items():
-    cyc = 2.8 * c["valu_fast"] + 4.25 * c["valu_slow"]
+    cyc = 1.96 * c["valu_fast"] + 3.25 * c["valu_slow"]
     print("%-10s %6d %6d %6d %5d %5d %5d %9.0f" % (ph, c["valu_fast"] + c["valu_slow"], c["valu_fast"], c["valu_slow"], c["salu"], c["lds"], c["vmem"], cyc))
     if ph != "prologue":
         tile.update(c)
