@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
             if constexpr (HASH) {
                 match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);               // 2. R3/R4, wide windows
                 zero_bit_buffer(lout, lane, carry_word);                                           // (ordered before the scatter by the fences below)
-            } else match_search<NCH>(lds.in, run_dw, best);                                        // 2. R3/R4
+            } else match_search<NCH, ONE_TILE && NCH == 1>(lds.in, run_dw, best);                  // 2. R3/R4 (a one-tile block: candidate keys by DPP)
             {
                 HDLZ_MARK("adler");
                 uint32_t ow[12];                                      // own 32 bytes + 16 look-ahead (reloaded: see match_search)

@@ -132,7 +132,13 @@ __device__ __forceinline__ void load_own(const uint32_t* in, uint32_t run_dw, ui
 // wide windows (NCH > 1), "no candidate": a value every eligibility test rejects (> 4 * 256 + 124) whose distance field -- bits
 // 2..10, what make_tokens gathers with -- reads 1: one v_bfe instead of compare + select + shift per position
 constexpr uint32_t NO_MATCH4 = 0x8004u;
-template <int NCH>
+// PREV_DPP (NCH == 1, a tile that starts its block): the 32 candidates in front of the run are the own positions of the PREVIOUS lane, so
+// their keys are that lane's own keys minus 128 (tag 4 (j + 32) -> 4 j): one DPP add each instead of two 16-byte LDS loads and ~1.5
+// shift / align / mask instructions per key.  The DPP is a ROTATE (wave_ror:1): lane 0 has no previous lane and takes lane 63's keys --
+// real keys with candidate tags, so whatever they match lies i + 32 - j > i = p positions back: in front of the block's first byte.  A
+// nearer in-block candidate always wins the minimum, and a result from out there fails the position test of make_tokens like "none" does.
+// (wave_shr with bound_ctrl would feed lane 0 the constant -128, which an own key FF FF FF | tag turns into a distance <= p: wrong.)
+template <int NCH, bool PREV_DPP = false>
 __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw, uint32_t (&best)[RUN]) {
     uint32_t ko[RUN];
     uint32_t ow0;
@@ -151,7 +157,13 @@ __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw
     for (int k = NCH - 1; k >= 0; k--) {                      // far chunks first, nearer ones overwrite
         uint32_t cd[17];                                      // 64 candidate positions + 2 bytes
         const uint32_t cdw = run_dw - 8u * (uint32_t)(k + 1);
-        {
+        [[maybe_unused]] uint32_t m128 = 0xFFFFFF80u;         // (-128 in a register: the DPP form takes no literal)
+        if constexpr (PREV_DPP) {
+            static_assert(NCH == 1, "own keys double as the next lane's candidates only for a 32-wide window");
+            asm volatile("" : "+v"(m128));
+#pragma unroll
+            for (int j = 0; j < 17; j++) cd[j] = 0;
+        } else {
             const uint4 c0 = *reinterpret_cast<const uint4*>(&in[cdw]);
             const uint4 c1 = *reinterpret_cast<const uint4*>(&in[cdw + 4]);
             cd[0] = c0.x; cd[1] = c0.y; cd[2] = c0.z; cd[3] = c0.w;
@@ -182,6 +194,10 @@ __device__ __forceinline__ void match_search(const uint32_t* in, uint32_t run_dw
                     asm volatile("" : "+v"(ko[j - 32]), "+v"(ko[j - 31]));
                     kc0 = ko[j - 32];
                     kc1 = ko[j - 31];
+                } else if constexpr (PREV_DPP) {
+                    // (the builtin, not inline asm: hipcc folds the move into v_add_u32_dpp and keeps the DPP read-after-write wait states)
+                    kc0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ko[j], 0x13C, 0xF, 0xF, false) + m128;          // wave_ror:1
+                    kc1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ko[j + 1], 0x13C, 0xF, 0xF, false) + m128;
                 } else {
                     kc0 = key3<j>(cd, (uint32_t)(4 * j));
                     kc1 = key3<j + 1>(cd, (uint32_t)(4 * (j + 1)));

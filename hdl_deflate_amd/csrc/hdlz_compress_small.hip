@@ -116,7 +116,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // positions are block-relative: a block's first run has no history (d <= p)
         const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);   // dword index of the run in lds.in
         uint32_t best[RUN], tok[RUN], code[RUN];
-        match_search<NCH>(lds.in, run_dw, best);                                                   // 2. R3/R4
+        match_search<NCH, NCH == 1>(lds.in, run_dw, best);     // 2. R3/R4 (candidate keys by DPP: a run in front of a block's first run belongs to
+                                                               //    another block -- or is lane 63 -- and only yields distances beyond the position)
         {
             uint32_t ow[12];                                          // own 32 bytes + 16 look-ahead (reloaded: see match_search)
             load_own(lds.in, run_dw, ow);

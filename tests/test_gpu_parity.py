@@ -128,6 +128,39 @@ def test_compress_every_block_vs_oracle_dense_matches(engine, oracle):
         assert ((ho == ro) | ~mask).all(), (nsym, cw, mm)
 
 
+def test_compress_one_tile_block_starts(engine, oracle):
+    """round 4: in the one-tile kernels the candidates in front of a lane's run are the previous lane's own keys (a DPP rotate), and lane 0
+    -- the first 32 bytes of the block -- takes lane 63's: whatever they match must lie in front of the block and be rejected.  Blocks
+    whose first bytes are 0xFF / 0x00 runs, whose END repeats their START (what the rotate feeds lane 0), one-symbol alphabets, lengths
+    around the tile size: every block against the oracle, uniform batch (k_compress<1, ., true>) and ragged."""
+    import torch
+    r = random.Random(41)
+    blocks = []
+    for n in (2048, 2047, 2016, 1990, 1025, 64, 37, 5):
+        blocks.append(bytes([0xFF]) * n)
+        blocks.append(bytes(n))
+        blocks.append((bytes([0, 0, 0]) + bytes([0xFF]) * 40 + bytes(r.getrandbits(8) for _ in range(n)))[:n])
+        head = bytes(r.getrandbits(8) for _ in range(40))
+        body = bytes(r.choice(b"ab") for _ in range(n))
+        blocks.append((head + body)[: max(n - 40, 0)] + head[: n - max(n - 40, 0)])      # the block ends with its own first bytes
+        blocks.append((bytes([0xFF, 0xFF, 0xFF]) * 12 + bytes(r.choice(b"xyz") for _ in range(n)))[: max(n - 36, 0)] + (bytes([0xFF]) * 36)[: n - max(n - 36, 0)])
+        blocks.append(bytes(r.choice(b"\xff\x00") for _ in range(n)))
+    for cw in (32, 17):
+        got, st = _ragged(torch, engine, blocks, cwindow=cw, maxmatch=10)
+        for k, b in enumerate(blocks):
+            rc, ref = oracle.compress(b, cwindow=cw, maxmatch=10)
+            assert st[k] == rc and got[k] == ref, (cw, k, len(b))
+    # the uniform batch: 2048-byte blocks through the one-tile kernel with a fixed pitch
+    full = [b for b in blocks if len(b) == 2048]
+    d = torch.frombuffer(bytearray(b"".join(full)), dtype=torch.uint8).cuda().reshape(len(full), 2048)
+    out, ol, st = engine.compress_batch(d, cwindow=32, maxmatch=10)
+    torch.cuda.synchronize()
+    out, ol = out.cpu().numpy(), ol.cpu().numpy()
+    for k, b in enumerate(full):
+        rc, ref = oracle.compress(b, cwindow=32, maxmatch=10)
+        assert rc == 0 and bytes(out[k, :ol[k]].tobytes()) == ref, k
+
+
 def test_compress_wide_windows_large_blocks_every_block(engine, oracle):
     """CWINDOW=64 and 256 (k_compress<2>, <8>) on 64 KiB multi-tile blocks of pseudo-English and of the
     families, MATCH10 on/off: every block against the threaded oracle"""
