@@ -36,6 +36,40 @@
 
 namespace hdlz {
 
+#ifdef HDLZ_TILE_TIMING       // diagnostic build (tools/exp_tile_timing.py): s_memtime at the phase boundaries of the tile; the j-th block a wave
+                              // processed reports the wave's total of part j (cycles, 32 bits) in out_len INSTEAD of its result
+#define TT_DECL() uint32_t tacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (uint32_t)__builtin_readcyclecounter()
+#define TT(k) do { const uint32_t t_ = (uint32_t)__builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#define TT_TILE() tacc[12] += 1u
+#else
+#define TT_DECL() do {} while (0)
+#define TT(k) do {} while (0)
+#define TT_TILE() do {} while (0)
+#endif
+
+// lsrc[0 .. words) (LDS, 16-byte aligned) -> dst (HBM, 4-byte aligned): 16-byte stores, then the one to three words that are left.
+// Returns the number of VMEM instructions the WAVE issued -- at least: the stage's counted wait may leave that many in flight.
+__device__ __forceinline__ uint32_t store_words(uint32_t* __restrict__ dst, const uint32_t* lsrc, uint32_t words, uint32_t lane) {
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const uint32_t nq = words >> 2;
+    uint32_t cnt = 0;
+    for (uint32_t q0 = 0; q0 < nq; q0 += 64u) {
+        const uint32_t q = q0 + lane;
+        if (q < nq) {
+            const v4 v = *reinterpret_cast<const v4*>(lsrc + 4u * q);
+            // (one 16-byte store whatever the alignment of the row: gfx950 asks for 4 bytes; s_nop: the data registers of a store wider
+            //  than 8 bytes must not be written in the next two wait states, and the hazard recognizer does not look into inline asm)
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dst + 4u * q), "v"(v) : "memory");
+        }
+        cnt += 1u;
+    }
+    if (words & 3u) {
+        if (lane < (words & 3u)) dst[4u * nq + lane] = lsrc[4u * nq + lane];
+        cnt += 1u;
+    }
+    return cnt;
+}
+
 // NCH = ceil(cwindow / 32): 1, 2 or 8 chunks of 32 candidate distances; FULLWIN: cwindow == 32 * NCH (the reference's
 // own windows 32 and 256, and 64), which spares the per-position window compare; ONE_TILE: every block of the batch fits one
 // wave-tile (N <= 2048: BASELINE configs[1]'s block size and the reference's own IBSIZE scale) -- no tile loop, no halo
@@ -59,36 +93,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
     const uint8_t* lut8 = reinterpret_cast<const uint8_t*>(lds.lut);
     uint8_t* out8 = reinterpret_cast<uint8_t*>(lout);
 
-    for (uint64_t blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
-        uint64_t off;
-        uint32_t n;
-        if (a.in_off) {
-            off = a.in_off[blk];
-            const uint64_t len64 = a.in_off[blk + 1] - off;      // in_off must ascend; a block is limited to 2 GiB - 1
-            if (len64 >= 0x80000000ull) {                         // (descending offsets wrap to a huge value)
-                if (lane == 0) { a.out_len[blk] = 0; a.status[blk] = HDLZ_E_BAD_PARAM; }
-                continue;
-            }
-            n = (uint32_t)len64;
-        } else {
-            off = blk * a.in_pitch;
+    // ---- a block: where it starts, how long it is, whether the reference would run it at all (R0) and whether its output fits
+    // (fixed-pitch batches: the three checks are the same for every block and made once)
+    const uint32_t fixed_st = a.in_len < 5u ? (uint32_t)HDLZ_E_SHORT_INPUT                           // R0: the reference never starts
+                            : (ONE_TILE && a.in_len > (uint32_t)TILE) ? (uint32_t)HDLZ_E_BAD_PARAM   // (the caller's bound on the lengths was wrong)
+                            : (uint64_t)out_bound(a.in_len) > a.out_pitch ? (uint32_t)HDLZ_E_OUT_CAPACITY : (uint32_t)HDLZ_OK;
+    auto block_params = [&](uint64_t blk, const uint8_t*& src, uint32_t& n) -> uint32_t {
+        if (!a.in_off) {
+            src = a.in + blk * a.in_pitch;
             n = a.in_len;
+            return fixed_st;
         }
-        const uint8_t* __restrict__ src = a.in + off;
-        uint32_t* __restrict__ outw = reinterpret_cast<uint32_t*>(a.out + blk * a.out_pitch);
+        const uint64_t off = a.in_off[blk];
+        const uint64_t len64 = a.in_off[blk + 1] - off;          // in_off must ascend; a block is limited to 2 GiB - 1
+        if (len64 >= 0x80000000ull) return HDLZ_E_BAD_PARAM;      // (descending offsets wrap to a huge value)
+        n = (uint32_t)len64;
+        src = a.in + off;
+        if (n < 5u) return HDLZ_E_SHORT_INPUT;
+        if (ONE_TILE && n > (uint32_t)TILE) return HDLZ_E_BAD_PARAM;
+        if ((uint64_t)out_bound(n) > a.out_pitch) return HDLZ_E_OUT_CAPACITY;
+        return HDLZ_OK;
+    };
+    // ---- round 5: the tile's input comes through LDS-DMA, requested while the PREVIOUS tile is still being parsed and emitted.
+    // profiles/r05_tile_timing.txt: a wave spent 9.5 % of its time in the stage -- __syncthreads() waited for the output stores of the
+    // last tile, then the loads went out and the wave sat through a whole HBM latency -- and with five waves per SIMD the VALU pipe
+    // needs at least four of them issuing.  The request for tile i+1 is issued right behind make_tokens of tile i (the last reader
+    // of lds.in), lands during parse / codes / scatter / flush, and the stage waits with a COUNTED vmcnt that leaves the flush
+    // stores issued behind the request in flight.  Only whole 16-byte chunks inside the block are requested (a source of any
+    // alignment: the bytes land where they belong); the chunk the block ends in comes through registers, masked, at the stage.
+    constexpr uint32_t NCHUNK = (TILE + LOOKAHEAD) / 16;        // 129 16-byte chunks behind the halo
+    const uint32_t in_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(lin8)) + (uint32_t)HALO;
+    auto request_tile = [&](const uint8_t* tsrc, uint32_t nfull) {       // chunks [0, nfull) of the tile that starts at tsrc
+        if (lane < nfull) lds_dma16(tsrc + 16u * lane, in_base);
+        if (lane + 64u < nfull) lds_dma16(tsrc + 16u * (lane + 64u), in_base + 1024u);
+        if (nfull > 128u) { if (lane == 0u) lds_dma16(tsrc + 2048u, in_base + 2048u); }
+    };
+    bool pf = false;            // lds.in holds -- or will, once vmcnt says so -- the tile that is staged next
+    uint32_t pf_st = 0;         // VMEM instructions (output stores) issued behind that request
 
-        if (n < 5u) {                               // R0: the reference never starts
-            if (lane == 0) { a.out_len[blk] = 0; a.status[blk] = HDLZ_E_SHORT_INPUT; }
+    TT_DECL();
+    for (uint64_t blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
+        const uint8_t* src;
+        uint32_t n;
+        const uint32_t bst = block_params(blk, src, n);
+        if (bst != HDLZ_OK) {                        // (never a requested block: the request makes the same checks)
+            if (lane == 0) { a.out_len[blk] = 0; a.status[blk] = bst; }
             continue;
         }
-        if (ONE_TILE && n > (uint32_t)TILE) {       // (the caller's bound on the block lengths was wrong)
-            if (lane == 0) { a.out_len[blk] = 0; a.status[blk] = HDLZ_E_BAD_PARAM; }
-            continue;
-        }
-        if ((uint64_t)out_bound(n) > a.out_pitch) {
-            if (lane == 0) { a.out_len[blk] = 0; a.status[blk] = HDLZ_E_OUT_CAPACITY; }
-            continue;
-        }
+        uint32_t* __restrict__ outw = reinterpret_cast<uint32_t*>(a.out + blk * a.out_pitch);
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
         const bool aligned16 = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
 
@@ -103,35 +155,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
 
         for (uint32_t t0 = 0; t0 < n; t0 += TILE) {       // (ONE_TILE: one iteration; left as a loop -- hipcc spills when it is peeled)
             // -------------------------------------------------------------- 1. stage the tile
+            TT(0);                                                // block prologue / loop overhead
             HDLZ_MARK("stage");
-            uint32_t keep = 0;
-            if (t0 != 0) keep = lds.in[(TILE / 4) + lane];      // last HALO bytes of the previous tile
-            __syncthreads();                                     // (also orders the previous flush reads)
-            lds.in[lane] = keep;                                 // tile 0: zero halo (never matched: d <= p)
+            const uint32_t nfull = min((n - t0) >> 4, NCHUNK);    // whole chunks of the block in this tile
+            if (!pf) {                                            // (a wave's first tile, or the block in front failed its checks)
+                wave_lds_order();                                 // (the previous tile's reads of lds.in are done)
+                lds.in[lane] = t0 != 0 ? lds.in[(TILE / 4) + lane] : 0u;     // last HALO bytes of the previous tile / tile 0: zero halo (never matched: d <= p)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                request_tile(src + t0, nfull);
+                pf_st = 0;
+            }
+            wait_vm_le(pf_st);
+            pf = false;
+            // zeros behind the block's end, and the chunk the block ends in: through registers, bytes at or beyond N read as zero.  (Two
+            // loops: a store whose value MAY come from a load makes hipcc wait vmcnt(0) in front of it -- for the flush stores too.)
             {
-                const uint32_t nchunk = (TILE + LOOKAHEAD) / 16;     // 129 16-byte chunks
-                for (uint32_t c = lane; c < nchunk; c += 64) {
-                    const uint32_t p = t0 + c * 16u;                 // first position of the chunk
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (p < n) v = load_chunk16(src, p, n, aligned16, mis);
-                    *reinterpret_cast<uint4*>(lin8 + HALO + c * 16u) = v;
+                const uint32_t part = (nfull < NCHUNK && ((n - t0) & 15u) != 0u) ? 1u : 0u;
+                for (uint32_t c = nfull + part + lane; c < NCHUNK; c += 64) *reinterpret_cast<uint4*>(lin8 + HALO + c * 16u) = make_uint4(0, 0, 0, 0);
+                if (part) {
+                    if (lane == 0u) *reinterpret_cast<uint4*>(lin8 + HALO + nfull * 16u) = load_chunk16(src, t0 + nfull * 16u, n, aligned16, mis);
                 }
             }
             // zero the bit buffer, seed the carry
             if constexpr (!HASH) zero_bit_buffer(lout, lane, carry_word);
-            __syncthreads();
+            wave_lds_order();
 
             // -------------------------------------------------------------- 2..6: the shared tile phases (hdlz_compress_common.h)
             const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);   // dword index of the run in lds.in
             const uint32_t p_run = t0 + lane * RUN;                   // first position of this run
             const uint32_t nrem = n - min(p_run, n);                  // positions of the block from p_run on
             uint32_t best[RUN], tok[RUN], code[RUN];
+            TT(1);                                                // stage (HBM latency, LDS writes, bit buffer zeroing)
             HDLZ_MARK("search");
             if constexpr (HASH) {
                 match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);               // 2. R3/R4, wide windows
                 zero_bit_buffer(lout, lane, carry_word);                                           // (ordered before the scatter by the fences below)
             } else match_search<NCH, ONE_TILE && NCH == 1>(lds.in, run_dw, best);                  // 2. R3/R4 (a one-tile block: candidate keys by DPP)
             {
+                TT(2);
                 HDLZ_MARK("adler");
                 uint32_t ow[12];                                      // own 32 bytes + 16 look-ahead (reloaded: see match_search)
                 load_own(lds.in, run_dw, ow);
@@ -146,37 +207,70 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
                     if (((t0 >> 11) & 0x3FFFFu) == 0x3FFFFu) ad_a %= ADLER_MOD;      // (every 2^18 tiles: ad_a grows by <= 8160 per tile)
                     asm volatile("" : "+v"(ad_a), "+v"(ad_w), "+v"(wm));              // computed HERE, while the bytes are in registers
                 }
+                TT(3);
                 HDLZ_MARK("extend");
                 make_tokens<NCH, FULLWIN, true>(lds.in, HALO + lane * RUN, ow, best, cw4, kmax, 4u * min(p_run, 32u * NCH), nrem, tok, (int32_t)(n - t0));   // 3. R5
             }
             pin(tok);
             PHASE_FENCE();
+            // -------------------------------------------------------------- 1'. request the NEXT tile (lds.in has no reader left)
+            {
+                const uint8_t* nsrc = src;
+                uint32_t nn = n, nt0 = t0 + (uint32_t)TILE;
+                bool have = !ONE_TILE && nt0 < n;                 // the next tile of this block, or the first one of the wave's next block
+#ifdef HDLZ_NO_PREFETCH                                           // A/B build: every tile is requested at its own stage
+                if (false) {
+#else
+                if (!have) {
+#endif
+                    const uint64_t nblk = blk + gridDim.x;
+                    nt0 = 0;
+                    if (nblk < a.nblocks) have = block_params(nblk, nsrc, nn) == HDLZ_OK;
+                }
+#ifdef HDLZ_NO_PREFETCH
+                have = false;
+#endif
+                if (have) {
+                    lds.in[lane] = nt0 != 0 ? lds.in[(TILE / 4) + lane] : 0u;     // the halo (read back before the request may overwrite it)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    request_tile(nsrc + nt0, min((nn - nt0) >> 4, NCHUNK));
+                    pf = true;
+                    pf_st = 0;
+                }
+            }
+            TT(4);
             HDLZ_MARK("parse");
             const uint64_t P = run_transfer(tok);                                                  // 4. greedy parse
+            TT(5);
             HDLZ_MARK("chain");
             uint32_t myskip = chain_skips(P, lane, skip_in);          // (skip_in: carried into the next tile)
             pin(tok); asm volatile("" : "+v"(myskip));
             PHASE_FENCE();
+            TT(6);
             HDLZ_MARK("codes");
             uint32_t lane_bits = token_codes<NCH, false>(lut8, tok, myskip, 0u, code);             // 5. R6/R7
             pin(code);
             PHASE_FENCE();
+            TT(7);
             HDLZ_MARK("scan");
             uint32_t incl = wave_scan_incl(lane_bits, lane);
             const uint32_t tile_bits_all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             pin(code); asm volatile("" : "+v"(incl), "+v"(lane_bits));
             PHASE_FENCE();
+            TT(8);
             HDLZ_MARK("scatter");
             scatter_codes(out8, code, base_bits + incl - lane_bits);                               // bit writer
+            TT(9);
             HDLZ_MARK("flush");
-            __syncthreads();
+            wave_lds_order();
+            TT(10);                                               // (kept for the table's layout)
 
             // -------------------------------------------------------------- 7. flush
             const bool last = ONE_TILE || (t0 + TILE >= n);
             if (!last) {
                 const uint32_t end_bits = base_bits + tile_bits_all;
                 const uint32_t full = end_bits >> 5;
-                for (uint32_t w = lane; w < full; w += 64) outw[gw + w] = lout[w];
+                pf_st += store_words(outw + gw, lout, full, lane);
                 carry_word = lout[full];
                 gw += full;
                 base_bits = end_bits & 31u;
@@ -197,24 +291,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
                 s1 = (s1 + 1u) % ADLER_MOD;
                 s2 = (s2 + n % ADLER_MOD) % ADLER_MOD;
                 const uint32_t nbytes = (end_bits + 7u + 7u) >> 3;
-                __syncthreads();
+                wave_lds_order();
                 if (lane == 0) {
                     out8[nbytes] = (uint8_t)(s2 >> 8);
                     out8[nbytes + 1] = (uint8_t)s2;
                     out8[nbytes + 2] = (uint8_t)(s1 >> 8);
                     out8[nbytes + 3] = (uint8_t)s1;
                 }
-                __syncthreads();
+                wave_lds_order();
                 const uint32_t total = nbytes + 4u;
                 const uint32_t words = (total + 3u) >> 2;
-                for (uint32_t w = lane; w < words; w += 64) outw[gw + w] = lout[w];
+                pf_st += store_words(outw + gw, lout, words, lane);
                 if (lane == 0) {
                     a.out_len[blk] = gw * 4u + total;     // R9
                     a.status[blk] = HDLZ_OK;
                 }
             }
+            TT(11);                                               // flush
+            TT_TILE();
         }
     }
+#ifdef HDLZ_TILE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        uint64_t blk = blockIdx.x;
+#pragma unroll
+        for (int k = 0; k < 13; k++, blk += gridDim.x)
+            if (blk < a.nblocks) { a.out_len[blk] = tacc[k]; a.status[blk] = 0u; }
+    }
+#endif
 }
 
 template __global__ void k_compress<1, true, true>(CompressArgs);

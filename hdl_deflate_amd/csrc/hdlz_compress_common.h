@@ -564,9 +564,43 @@ __device__ __forceinline__ uint64_t run_transfer(const uint32_t (&tok)[RUN]) {
     return P;
 }
 
-// ---- phase 4b: compose the 64 run functions across the wave (serial, on the scalar unit).  s: in = entry skip of lane 0,
-// out = exit skip of lane 63; returns this lane's entry skip.
+// ---- phase 4b: compose the 64 run functions across the wave.  s: in = entry skip of lane 0, out = exit skip of lane 63; returns this
+// lane's entry skip.
+// Round 5: a run function is almost always CONSTANT -- whatever the entry skip, the parse of 32 positions falls into step at the first
+// literal or cut-short match (0 / 0 / 0 / 4 % of the runs of the four bench families are not constant; data whose matches follow each
+// other at full length through the whole run -- zeros, short periods -- is what keeps a function a rotation).  A lane behind a constant
+// function knows its entry skip at once, a lane behind a chain of k others after k steps of "take the previous lane's exit through my own
+// function" (one DPP move + a nibble pick per step, all lanes at once).  Up to CHAIN_STEPS such steps; a wave that still has an open lane
+// then takes the serial composition on the scalar unit, which is exact for every input (64 steps of ~6 dependent scalar instructions:
+// 7.7 k of the 52.6 k cycles a wave spent per tile, profiles/r05_tile_timing.txt -- a wave in that loop issues nothing else).
+constexpr int CHAIN_STEPS = 4;
+__device__ __forceinline__ uint32_t chain_skips_serial(uint64_t P, uint32_t lane, uint32_t& s);
 __device__ __forceinline__ uint32_t chain_skips(uint64_t P, uint32_t lane, uint32_t& s) {
+    const uint32_t plo = (uint32_t)P, phi = (uint32_t)(P >> 32) & 0xFFu;
+#ifndef HDLZ_CHAIN_SERIAL_ONLY
+    // all ten nibbles equal  <=>  P ^ (P >> 4) has no bit in its low 36
+    const uint32_t dl = plo ^ __builtin_amdgcn_alignbit(phi, plo, 4u), dh = (phi ^ (phi >> 4)) & 15u;
+    uint32_t x = (dl | dh) == 0u ? (plo & 15u) : 16u;           // this lane's EXIT skip, 16 = not known yet
+#ifdef HDLZ_CHAIN_FORCE_SERIAL                                   // test build: every wave takes the scalar composition
+    x = 16u;
+#endif
+    bool open = ballot64(x >= 16u) != 0ull;
+#pragma unroll 1
+    for (int it = 0; it < CHAIN_STEPS && open; it++) {
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)s, (int)x, 0x138, 0xF, 0xF, false);      // wave_shr:1; lane 0 keeps s
+        const uint32_t via = (uint32_t)(P >> (4u * (prev & 15u))) & 15u;
+        x = (x >= 16u && prev < 16u) ? via : x;
+        open = ballot64(x >= 16u) != 0ull;
+    }
+    if (!open) {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_update_dpp((int)s, (int)x, 0x138, 0xF, 0xF, false);
+        s = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+        return e;
+    }
+#endif
+    return chain_skips_serial(P, lane, s);
+}
+__device__ __forceinline__ uint32_t chain_skips_serial(uint64_t P, uint32_t lane, uint32_t& s) {
     const uint32_t plo = (uint32_t)P;
     // the upper part of a function is 8 bits (entry skips 8 and 9): the four of a quad of lanes are packed into ONE register first (two
     // quad-permute moves), so the scalar chain reads 64 + 16 lanes instead of 2 x 64 (v_readlane is a 3.25-cycle instruction)
