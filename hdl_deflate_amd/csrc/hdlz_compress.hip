@@ -114,13 +114,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
         if ((uint64_t)out_bound(n) > a.out_pitch) return HDLZ_E_OUT_CAPACITY;
         return HDLZ_OK;
     };
-    // ---- round 5: the tile's input comes through LDS-DMA, requested while the PREVIOUS tile is still being parsed and emitted.
-    // profiles/r05_tile_timing.txt: a wave spent 9.5 % of its time in the stage -- __syncthreads() waited for the output stores of the
-    // last tile, then the loads went out and the wave sat through a whole HBM latency -- and with five waves per SIMD the VALU pipe
-    // needs at least four of them issuing.  The request for tile i+1 is issued right behind make_tokens of tile i (the last reader
-    // of lds.in), lands during parse / codes / scatter / flush, and the stage waits with a COUNTED vmcnt that leaves the flush
-    // stores issued behind the request in flight.  Only whole 16-byte chunks inside the block are requested (a source of any
-    // alignment: the bytes land where they belong); the chunk the block ends in comes through registers, masked, at the stage.
+    // ---- round 5: the tile's input comes through LDS-DMA -- no VGPR round trip, and the zeroing of the tile's tail and of the bit buffer
+    // runs while the bytes are on their way.  Only whole 16-byte chunks inside the block are requested (a source of any alignment: the
+    // bytes land where they belong); the chunk the block ends in comes through registers, masked.
+    // (Requesting tile i+1 behind make_tokens of tile i -- lds.in has no reader left there -- with a COUNTED vmcnt at the stage that leaves
+    // the flush stores in flight was built and measured: 4.786 against 4.773 ms on configs[1], profiles/r05_compress_ab.txt.  Five waves
+    // per SIMD hide the stage; what counted was the serial skip chain.  Not kept: a counted wait is a hazard for no gain.)
     constexpr uint32_t NCHUNK = (TILE + LOOKAHEAD) / 16;        // 129 16-byte chunks behind the halo
     const uint32_t in_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(lin8)) + (uint32_t)HALO;
     auto request_tile = [&](const uint8_t* tsrc, uint32_t nfull) {       // chunks [0, nfull) of the tile that starts at tsrc
@@ -128,8 +127,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
         if (lane + 64u < nfull) lds_dma16(tsrc + 16u * (lane + 64u), in_base + 1024u);
         if (nfull > 128u) { if (lane == 0u) lds_dma16(tsrc + 2048u, in_base + 2048u); }
     };
-    bool pf = false;            // lds.in holds -- or will, once vmcnt says so -- the tile that is staged next
-    uint32_t pf_st = 0;         // VMEM instructions (output stores) issued behind that request
 
     TT_DECL();
     for (uint64_t blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
@@ -158,15 +155,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
             TT(0);                                                // block prologue / loop overhead
             HDLZ_MARK("stage");
             const uint32_t nfull = min((n - t0) >> 4, NCHUNK);    // whole chunks of the block in this tile
-            if (!pf) {                                            // (a wave's first tile, or the block in front failed its checks)
-                wave_lds_order();                                 // (the previous tile's reads of lds.in are done)
-                lds.in[lane] = t0 != 0 ? lds.in[(TILE / 4) + lane] : 0u;     // last HALO bytes of the previous tile / tile 0: zero halo (never matched: d <= p)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                request_tile(src + t0, nfull);
-                pf_st = 0;
-            }
-            wait_vm_le(pf_st);
-            pf = false;
+            wave_lds_order();                                     // (the previous tile's reads of lds.in are done)
+            lds.in[lane] = t0 != 0 ? lds.in[(TILE / 4) + lane] : 0u;     // last HALO bytes of the previous tile / tile 0: zero halo (never matched: d <= p)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (read back before the request may overwrite it)
+            request_tile(src + t0, nfull);
             // zeros behind the block's end, and the chunk the block ends in: through registers, bytes at or beyond N read as zero.  (Two
             // loops: a store whose value MAY come from a load makes hipcc wait vmcnt(0) in front of it -- for the flush stores too.)
             {
@@ -178,6 +170,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
             }
             // zero the bit buffer, seed the carry
             if constexpr (!HASH) zero_bit_buffer(lout, lane, carry_word);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile has landed (and the last tile's output stores have left)
             wave_lds_order();
 
             // -------------------------------------------------------------- 2..6: the shared tile phases (hdlz_compress_common.h)
@@ -213,31 +206,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
             }
             pin(tok);
             PHASE_FENCE();
-            // -------------------------------------------------------------- 1'. request the NEXT tile (lds.in has no reader left)
-            {
-                const uint8_t* nsrc = src;
-                uint32_t nn = n, nt0 = t0 + (uint32_t)TILE;
-                bool have = !ONE_TILE && nt0 < n;                 // the next tile of this block, or the first one of the wave's next block
-#ifdef HDLZ_NO_PREFETCH                                           // A/B build: every tile is requested at its own stage
-                if (false) {
-#else
-                if (!have) {
-#endif
-                    const uint64_t nblk = blk + gridDim.x;
-                    nt0 = 0;
-                    if (nblk < a.nblocks) have = block_params(nblk, nsrc, nn) == HDLZ_OK;
-                }
-#ifdef HDLZ_NO_PREFETCH
-                have = false;
-#endif
-                if (have) {
-                    lds.in[lane] = nt0 != 0 ? lds.in[(TILE / 4) + lane] : 0u;     // the halo (read back before the request may overwrite it)
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    request_tile(nsrc + nt0, min((nn - nt0) >> 4, NCHUNK));
-                    pf = true;
-                    pf_st = 0;
-                }
-            }
             TT(4);
             HDLZ_MARK("parse");
             const uint64_t P = run_transfer(tok);                                                  // 4. greedy parse
@@ -270,7 +238,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
             if (!last) {
                 const uint32_t end_bits = base_bits + tile_bits_all;
                 const uint32_t full = end_bits >> 5;
-                pf_st += store_words(outw + gw, lout, full, lane);
+                store_words(outw + gw, lout, full, lane);
                 carry_word = lout[full];
                 gw += full;
                 base_bits = end_bits & 31u;
@@ -301,7 +269,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
                 wave_lds_order();
                 const uint32_t total = nbytes + 4u;
                 const uint32_t words = (total + 3u) >> 2;
-                pf_st += store_words(outw + gw, lout, words, lane);
+                store_words(outw + gw, lout, words, lane);
                 if (lane == 0) {
                     a.out_len[blk] = gw * 4u + total;     // R9
                     a.status[blk] = HDLZ_OK;

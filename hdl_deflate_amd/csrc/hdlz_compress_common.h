@@ -13,6 +13,12 @@ namespace hdlz {
 #define HDLZ_W1 5
 #endif
 
+#ifndef HDLZ_EXT_GROUP
+#define HDLZ_EXT_GROUP 4
+#endif
+#ifndef HDLZ_CODE_GROUP
+#define HDLZ_CODE_GROUP 4
+#endif
 constexpr int RUN = 32;             // positions per lane
 constexpr int TILE = 64 * RUN;      // 2048 positions per wave-tile
 constexpr int HALO = 256;           // bytes kept in front of the tile (max CWINDOW)
@@ -33,6 +39,9 @@ struct __attribute__((aligned(16))) WaveLds {
     uint32_t out[OUT_WORDS];        // bit buffer of the current tile
     uint32_t lut[LUT_LIT + LUT_MATCH + LUT_LEN];
 };
+
+constexpr uint32_t GATHER_SPAN = 4u * (0x3FFu + 3u);      // bytes behind `in` that make_tokens' masked gather may touch (GMASK = 0x3FF)
+static_assert(sizeof(WaveLds) >= GATHER_SPAN, "make_tokens: masked gather inside the LDS block");
 
 struct __attribute__((aligned(16))) WaveLdsNoOut {       // kernels with the hash finder: the bit buffer lives in HashLds::D's memory
     uint32_t in[IN_BYTES / 4];
@@ -488,7 +497,11 @@ template <int NCH> constexpr int waves_eu() { return NCH == 1 ? HDLZ_W1 : HDLZ_W
 //   SCALAR_TAIL: the lane runs are consecutive pieces of ONE block and tile_rem = positions of the block from the tile's first
 //            position on: R3's "p <= N-5" then holds for a PREFIX of the lanes, so it is evaluated on the scalar unit --
 //            at most two different lane masks per tile -- and and-ed into the compare's lane mask (else: per lane, from nrem)
-template <int NCH, bool FULLWIN, bool SCALAR_TAIL = false>
+//   GMASK    dword-index mask of the extension's gather: the gather of a position WITHOUT a candidate (NCH == 1: a raw minimum up to
+//            2^32 - 1 stands for "none") would address LDS far outside `in`; masked, it stays inside the first 4 (GMASK + 3) bytes behind
+//            `in` -- which every caller's LDS block covers (static_assert there) -- and its result is discarded as before.  The mask
+//            replaces the ~3 of the dword address: no instruction more.  (an out-of-allocation LDS read.)
+template <int NCH, bool FULLWIN, bool SCALAR_TAIL = false, uint32_t GMASK = 0x3FFu>
 __device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run, uint32_t (&ow)[12], uint32_t (&best)[RUN],
                                             uint32_t cw4, uint32_t kmax, uint32_t p4_run, uint32_t nrem, uint32_t (&tok)[RUN],
                                             int32_t tile_rem = 0) {
@@ -517,12 +530,11 @@ __device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run
         else okm &= __builtin_amdgcn_ballot_w64(nrem >= (uint32_t)(i + 5));
         // distance for the gather; for "no match" any in-range value will do (the result is discarded)
         // (NCH == 1: a plain shift -- v_lshrrev is a full-rate instruction, v_bfe / v_and + shift are not, profiles/r04_ubench/ubench_valu_cycles2.txt;
-        //  a raw minimum that means "none" then gathers at some address below the run: the dword mask of the address keeps it inside the
-        //  first 8 KB of the LDS -- reads beyond the workgroup's allocation return zero -- and the result is discarded)
+        //  a raw minimum that means "none" then gathers at some masked address inside the caller's LDS block, see GMASK; the result is discarded)
         const uint32_t d = (NCH == 1) ? (d4 >> 2) : __builtin_amdgcn_ubfe(d4, 2u, 9u);      // (NO_MATCH4 reads as 1)
         // R5: common prefix of x[p+3..p+10] and x[p-d+3..p-d+10]
         const uint32_t q = lds_run + (uint32_t)(i + 3) - d;   // byte offset of the candidate's 4th byte
-        const uint32_t qd = q >> 2;
+        const uint32_t qd = (q >> 2) & GMASK;
         const uint32_t a0 = in[qd], a1 = in[qd + 1], a2 = in[qd + 2];
         const uint32_t clo = alignbyte(a1, a0, q), chi = alignbyte(a2, a1, q);      // (v_alignbyte takes the shift from q[1:0])
         constexpr int o = i + 3;
@@ -546,7 +558,9 @@ __device__ __forceinline__ void make_tokens(const uint32_t* in, uint32_t lds_run
         uint32_t mt;     // l3 * tok_mul + d4 + tok_k  (hipcc folds the C form into a quarter-rate v_mul_lo_u32)
         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(mt) : "v"(l3), "s"(tok_mul), "v"(d4 + tok_k));
         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(tok[i]) : "v"(lit), "v"(mt), "s"(okm));      // tok = ok ? mt : lit
-        if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(tok); PHASE_FENCE(); }
+        // (positions per scheduling group: the gathers of a group are in flight together; profiles/r05_tile_timing.txt)
+        constexpr int EG = HDLZ_EXT_GROUP;
+        if constexpr ((i & (EG - 1)) == EG - 1) { pin_range<(i & ~(EG - 1)), (i & ~(EG - 1)) + EG>(tok); PHASE_FENCE(); }
     });
 }
 
@@ -655,7 +669,8 @@ __device__ __forceinline__ uint32_t token_codes(const uint8_t* lut8, uint32_t (&
             ee |= *reinterpret_cast<const uint32_t*>(lut8 + LUT_LEN_BYTE + lenm1x4);        // (computed: six VALU instructions per position)
         code[i] = start ? ee : 0u;
         lane_bits += code[i] >> NB_SHIFT;
-        if constexpr ((i & 3) == 3) { pin_range<(i & ~3), (i & ~3) + 4>(code); asm volatile("" : "+v"(c), "+v"(lane_bits)); PHASE_FENCE(); }
+        constexpr int CG = HDLZ_CODE_GROUP;
+        if constexpr ((i & (CG - 1)) == CG - 1) { pin_range<(i & ~(CG - 1)), (i & ~(CG - 1)) + CG>(code); asm volatile("" : "+v"(c), "+v"(lane_bits)); PHASE_FENCE(); }
     });
     return lane_bits;
 }

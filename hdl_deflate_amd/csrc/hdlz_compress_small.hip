@@ -28,6 +28,8 @@ struct __attribute__((aligned(16))) SmallLds {
     uint32_t ad[2][64];                       // per-lane Adler partials, summed per block by its first lane
 };
 
+static_assert(sizeof(SmallLds) >= GATHER_SPAN && offsetof(SmallLds, in) == 0, "make_tokens: masked gather inside the LDS block");
+
 template <bool RAGGED, bool FULLWIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_compress_small(CompressArgs a) {
     constexpr int NCH = 1;

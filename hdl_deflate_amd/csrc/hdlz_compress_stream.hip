@@ -482,7 +482,10 @@ __global__ __launch_bounds__(256) void k_stream_place(StreamArgs a) {
 template <int NCH> struct TailLds {
     static constexpr uint32_t HALO_DW = 8u * NCH;                    // CWINDOW bytes of history, in dwords
     static constexpr uint32_t STRIDE_DW = HALO_DW + 20u;             // + 32 own bytes + 16 look-ahead + 32 bytes of padding / bank spread
-    uint32_t in[64 * STRIDE_DW + 8];
+    static constexpr uint32_t GMASK = NCH == 1 ? 0x7FFu : 0x3FFFu;      // (NCH == 1: 64 * 28 + 8 = 1800 dwords, padded to the mask's span)
+    static constexpr uint32_t IN_DW = 64u * STRIDE_DW + 8u;
+    uint32_t in[NCH == 1 ? (IN_DW > GMASK + 3u ? IN_DW : GMASK + 3u) : IN_DW];
+    static_assert(NCH != 1 || IN_DW <= GMASK + 1u, "make_tokens: every real gather address below the mask");
 };
 
 template <int NCH>
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(64) void k_stream_tails(StreamArgs a) {
     {
         uint32_t ow[12];
         load_own(lds.in, run_dw, ow);
-        make_tokens<NCH, FULLWIN>(lds.in, lds_run, ow, best, cw4, kmax, 4u * min(p_run, 32u * NCH), nrem, tok);   // 3. R5
+        make_tokens<NCH, FULLWIN, false, TailLds<NCH>::GMASK>(lds.in, lds_run, ow, best, cw4, kmax, 4u * min(p_run, 32u * NCH), nrem, tok);   // 3. R5
     }
     pin(tok);
     PHASE_FENCE();

@@ -52,16 +52,8 @@ __device__ __forceinline__ void lds_dma16(const uint8_t* gptr, uint32_t lds_base
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(save) : "v"(gptr), "s"(lds_base) : "memory");
 }
-// s_waitcnt vmcnt(min(k, 3)) for a wave-uniform k: at most that many of the wave's youngest VMEM instructions may still be in flight
-__device__ __forceinline__ void wait_vm_le(uint32_t k) {
-    if (k >= 3u) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (k == 2u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (k == 1u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
 // ordering point between the LDS accesses of ONE wave (single-wave workgroups): the LDS executes a wave's instructions in order, so
-// all it takes is that the compiler keeps them in order.  (__syncthreads() also waits vmcnt(0): for the output stores of the last
-// tile, and it would drain an LDS-DMA prefetch right where it is issued.)
+// all it takes is that the compiler keeps them in order.  (__syncthreads() also waits vmcnt(0) -- for output stores issued a moment ago.)
 __device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory"); }
 
 // compile-time counted loop: body(std::integral_constant<int, I>{}) for I in [B, E)

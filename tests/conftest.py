@@ -21,6 +21,10 @@ def pytest_sessionstart(session):
     if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
         import subprocess
         subprocess.check_call(["bash", os.path.join(REPO, "hdl_deflate_amd", "csrc", "build.sh")], stdout=subprocess.DEVNULL)
+    forced = os.path.join(REPO, "hdl_deflate_amd", "lib", "libhdlz_forced.so")      # (tests/test_gpu_forced_paths.py)
+    if not os.path.exists(forced) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+        subprocess.check_call(["bash", os.path.join(REPO, "hdl_deflate_amd", "csrc", "build.sh"), "forced"], stdout=subprocess.DEVNULL)
 
 
 def load_golden(name):
