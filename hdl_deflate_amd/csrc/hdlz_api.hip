@@ -155,12 +155,15 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     if (nstreams > 0x7FFFFFFFull * 32) return fail_param("nstreams too large for one launch");
     if (nstreams && (!d_in || !d_out || !d_out_len || !d_status)) return fail_param("null device pointer");
     if (flags & ~(HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_ONEBLOCK |
-                  HDLZ_INFLATE_TOKEN_ROUNDS | HDLZ_INFLATE_BYTE_LOCKSTEP))
+                  HDLZ_INFLATE_TOKEN_ROUNDS | HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_GROUP_PER_STREAM))
         return fail_param("unknown flag");
     // the kernels keep stream lengths and bit positions in 32 bits (8 * length must not wrap)
     if (!d_in_off && in_len >= 0x10000000u) return fail_param("in_len too large (streams are limited to 256 MiB - 1)");
     if (!d_in_off && nstreams > 1 && in_pitch < in_len) return fail_param("in_pitch < in_len");
-    if ((flags & HDLZ_INFLATE_LANE_PER_STREAM) && (flags & HDLZ_INFLATE_WAVE_PER_STREAM)) return fail_param("contradictory mapping flags");
+    {
+        const uint32_t mf = flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_GROUP_PER_STREAM);
+        if (mf & (mf - 1u)) return fail_param("contradictory mapping flags");
+    }
     if ((out_pitch & 3u) || (reinterpret_cast<uintptr_t>(d_out) & 3u)) return fail_param("d_out / out_pitch must be 4-byte aligned");
     int rc = check_device();
     if (rc != HDLZ_OK) return rc;
@@ -170,8 +173,14 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     // mapping: one LANE per stream (k_inflate, 64 streams in lockstep per wave) needs ~10^5 streams to fill the GPU;
     // below HDLZ_INFLATE_WAVE_THRESHOLD streams one WAVE per stream (k_inflate_dyn, window decode) is faster, for
     // any block type
-    const bool wave_all = (flags & HDLZ_INFLATE_WAVE_PER_STREAM) ||
-                          (!(flags & HDLZ_INFLATE_LANE_PER_STREAM) && nstreams <= HDLZ_INFLATE_WAVE_THRESHOLD);
+    const uint32_t hint = flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_GROUP_PER_STREAM |
+                                   HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_TOKEN_ROUNDS);
+    // in between: 16 lanes per stream (k_inflate_grp, round 5) -- from HDLZ_INFLATE_GROUP_MIN streams on it beats a wave per stream,
+    // up to HDLZ_INFLATE_GROUP_MAX a lane per stream; the streams it flags (dynamic-tree blocks) take the second pass below
+    const bool group = (flags & HDLZ_INFLATE_GROUP_PER_STREAM) ||
+                       (hint == 0u && nstreams >= HDLZ_INFLATE_GROUP_MIN && nstreams <= HDLZ_INFLATE_GROUP_MAX);
+    const bool wave_all = !group && ((flags & HDLZ_INFLATE_WAVE_PER_STREAM) ||
+                                     (!(flags & HDLZ_INFLATE_LANE_PER_STREAM) && nstreams <= HDLZ_INFLATE_WAVE_THRESHOLD));
     // ONE large stream: cut into 1 KiB pieces and decoded by the whole GPU (hdlz_inflate_par.hip) when it is a single fixed block --
     // what STARTC writes --, by one wave otherwise (decided on the device); the explicit mapping hints keep the batch kernels
     if (nstreams == 1 && !d_in_off && in_len >= HDLZ_INFLATE_PAR_MIN &&
@@ -206,7 +215,8 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     }
     // lane per stream: one TOKEN per round (k_inflate_tok, round 2: 362 GB/s on BASELINE configs[3]) unless the caller asks for
     // round 1's one-byte-per-iteration kernel (k_inflate, 278 GB/s)
-    hipError_t e = (flags & HDLZ_INFLATE_BYTE_LOCKSTEP) ? hdlz::launch_inflate(a, st) : hdlz::launch_inflate_tok(a, st);
+    hipError_t e = group ? hdlz::launch_inflate_grp(a, st)
+                 : (flags & HDLZ_INFLATE_BYTE_LOCKSTEP) ? hdlz::launch_inflate(a, st) : hdlz::launch_inflate_tok(a, st);
     if (e != hipSuccess) return fail_hip(e, "launch k_inflate");
     // second pass, same stream: streams in which pass 1 met a dynamic-tree block (status 6) are redone, again one lane each
     // (k_inflate_tok<true>; HDLZ_INFLATE_BYTE_LOCKSTEP keeps round 1's pair: one wave per such stream); everything else is

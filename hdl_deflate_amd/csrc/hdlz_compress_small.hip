@@ -12,6 +12,8 @@
 // kernel (and to the reference).  Fixed-pitch, 16-byte aligned batches take two 16-byte loads per lane; ragged batches
 // (in_off, with in_len = an upper bound on the block lengths: every block gets ceil(bound/32) lanes) re-align their
 // bytes from aligned dword loads.
+// (Round 5: single-wave workgroups order their LDS accesses with wave_lds_order() -- __syncthreads() also waited vmcnt(0) for the
+// output stores of the previous group, three times per group.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         const uint32_t nrem = lane_ok ? nb - min(p_run, nb) : 0u; // positions of the block from this run on
         // -------------------------------------------------------------- 1. stage: every lane loads its own run
-        __syncthreads();
+        wave_lds_order();
         {
             uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
             if (nrem != 0u) {
@@ -109,10 +111,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             lds.in[lane] = 0;                                                  // halo in front of lane 0
             if (lane < LOOKAHEAD / 4) lds.in[(HALO + TILE) / 4 + lane] = 0;    // look-ahead behind lane 63
         }
-        for (uint32_t w = lane; w < (uint32_t)SMALL_OUT_WORDS; w += 64) lds.out[w] = 0u;
-        __syncthreads();
+        static_assert(SMALL_OUT_WORDS % 4 == 0, "16-byte stores");
+        for (uint32_t q = lane; q < (uint32_t)SMALL_OUT_WORDS / 4u; q += 64) *reinterpret_cast<uint4*>(&lds.out[4u * q]) = make_uint4(0, 0, 0, 0);
+        wave_lds_order();
         if (lane_ok && r == 0u) lds.out[g * Wb] = 0x78u | (0x9Cu << 8) | (0x3u << 16);   // R1 per block
-        __syncthreads();
+        wave_lds_order();
 
         // -------------------------------------------------------------- 2..5: the shared tile phases (hdlz_compress_common.h);
         // positions are block-relative: a block's first run has no history (d <= p)
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         PHASE_FENCE();
         // OR every token into the block's region of the LDS bit buffer (a lane without a block emits nothing: all codes are zero)
         scatter_codes(out8, code, lane_ok ? 32u * g * Wb + 19u + (incl - lane_bits - before_blk) : 0u);
-        __syncthreads();
+        wave_lds_order();
         // -------------------------------------------------------------- 7. per block: trailer, length, flush
         // the block's first lane finishes its block (R8/R9)
         const uint32_t last_lane = min(first_lane + Rb - 1u, 63u);
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             a.out_len[blk] = total;
             a.status[blk] = HDLZ_OK;
         }
-        __syncthreads();
+        wave_lds_order();
         for (uint32_t gg = 0; gg < G; gg++) {                       // flush block by block, coalesced dwords
             const uint64_t b2 = grp * G + gg;
             if (b2 >= a.nblocks) break;

@@ -69,6 +69,7 @@ hipError_t launch_compress(const CompressArgs& a, hipStream_t stream);
 hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int ncu);
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t stream);
 hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream);
+hipError_t launch_inflate_grp(const InflateArgs& a, hipStream_t stream);
 hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool all);
 hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used);
 hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream, bool all, const uint32_t* few_n = nullptr, uint32_t lane_min = 0);

@@ -185,13 +185,16 @@ __device__ __forceinline__ void x_decode(const uint32_t (&X)[NL], uint32_t bits,
     idx = (m & 511u) - ((m >> 16) >> (15u - len));
 }
 
+constexpr uint32_t ORDER_BAD = 0xFFFFFFFFu;      // list length word of a counting sort whose counts did not add up (see bin_flush_and_finish)
 template <bool DYN, uint32_t CAP>
 __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, const uint32_t* __restrict__ list,
-                                                                const uint32_t* __restrict__ list_n, uint32_t lane_min
+                                                                const uint32_t* __restrict__ list_n, uint32_t lane_min,
+                                                                const uint32_t* __restrict__ order_word = nullptr,
+                                                                const uint32_t* __restrict__ list_alt = nullptr
                                                                 ) {
     constexpr uint32_t WAVES = Lds<DYN, CAP>::WAVES;
     __shared__ Lds<DYN, CAP> lds;
-    if (list != nullptr && (uint64_t)blockIdx.x * (64u * WAVES) >= (uint64_t)*list_n) return;      // (the grid covers the longest possible list)
+    if (list != nullptr && *list_n != ORDER_BAD && (uint64_t)blockIdx.x * (64u * WAVES) >= (uint64_t)*list_n) return;      // (the grid covers the longest possible list)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     if constexpr (!DYN) {
@@ -203,7 +206,10 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     const uint64_t gid = ((uint64_t)blockIdx.x * WAVES + wave) * 64u + lane;
     uint64_t sid = gid;
     bool exists = gid < a.nstreams;
-    if (list) {                                                    // (DYN = false: the streams phase A of the two-phase path handed back)
+    // the length-ordered list is only used when the counting sort vouched for it (bin_flush_and_finish: ORDER_BAD = its counts did not
+    // add up): else the unordered list it was made from (dynamic-tree pass) or plain stream order (pass 1) -- slower lanes, same results
+    if (list && order_word && *order_word == ORDER_BAD) list = list_alt;
+    if (list) {
         if (*list_n < lane_min) return;                            // few such streams: k_inflate_dyn takes them, one wave each
         exists = gid < (uint64_t)*list_n;
         sid = exists ? (uint64_t)list[gid] : 0ull;
@@ -921,20 +927,29 @@ __device__ __forceinline__ void bin_flush_and_finish(const uint32_t* lh, uint32_
     __syncthreads();
     if (last == 0u || threadIdx.x >= 64u) return;
     const uint32_t lane = threadIdx.x;
-    const uint32_t c0 = __hip_atomic_load(&bins[2u * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t c1 = __hip_atomic_load(&bins[2u * lane + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t v = c0 + c1;
+    const uint32_t nl = nlist_p ? __hip_atomic_load(nlist_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : nlist_max;
+    const uint32_t expect = min(nl, nlist_max);
+    // the ordering above is argued, not fenced -- so it is CHECKED: the counts must add up to the number of listed streams.
+    // A count that is still on its way is read again (it is an atomic at the coherence point: it arrives); if the sum never matches, the
+    // list length word says so and the decode kernel does not use the ordered list (a wrong permutation would decode streams twice
+    // and leave rows unwritten, silently).
+    uint32_t c0 = 0, c1 = 0, v = 0, total = 0;
+    for (uint32_t tries = 0; tries < 1024u; tries++) {
+        c0 = __hip_atomic_load(&bins[2u * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c1 = __hip_atomic_load(&bins[2u * lane + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = c0 + c1;
 #pragma unroll
-    for (int ofs = 1; ofs < 64; ofs <<= 1) {
-        const uint32_t o = __shfl_up(v, ofs, 64);
-        if (lane >= (uint32_t)ofs) v += o;
+        for (int ofs = 1; ofs < 64; ofs <<= 1) {
+            const uint32_t o = __shfl_up(v, ofs, 64);
+            if (lane >= (uint32_t)ofs) v += o;
+        }
+        total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+        if (total == expect) break;
+        __builtin_amdgcn_s_sleep(8);
     }
     const uint32_t excl = v - (c0 + c1);
     bins[2u * lane] = excl; bins[2u * lane + 1u] = excl + c0;
-    if (lane == 0u) {
-        const uint32_t nl = nlist_p ? __hip_atomic_load(nlist_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : nlist_max;
-        bins[NBIN] = min(nl, nlist_max);
-    }
+    if (lane == 0u) bins[NBIN] = total == expect ? expect : ORDER_BAD;
 }
 
 // the streams pass 1 flagged HDLZ_E_DYNAMIC_UNSUPPORTED, as a dense list: the lanes of k_inflate_tok<true> are then all busy whatever
@@ -978,6 +993,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint64_t* __restrict_
                                                       uint32_t* __restrict__ list, const uint32_t* __restrict__ src,
                                                       const uint32_t* __restrict__ src_n) {
     __shared__ uint32_t lh[NBIN], lbase[NBIN];
+    if (cursor[NBIN] == ORDER_BAD) return;                  // (the counts did not add up: nobody reads the ordered list)
     if (src_n) n = min(n, *src_n);
     if (blockIdx.x * 256u >= n) return;
     if (threadIdx.x < NBIN) lh[threadIdx.x] = 0u;
@@ -1018,7 +1034,8 @@ hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
             e = tok::bin_streams(a.in_off, n, ws, ws + tok::BIN_WORDS, stream);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL((tok::k_inflate_tok<false, tok::CAP_FULL>), grid, block, 0, stream, a,
-                                   (const uint32_t*)(ws + tok::BIN_WORDS), (const uint32_t*)(ws + tok::NBIN), 0u);
+                                   (const uint32_t*)(ws + tok::BIN_WORDS), (const uint32_t*)(ws + tok::NBIN), 0u,
+                                   (const uint32_t*)(ws + tok::NBIN), (const uint32_t*)nullptr);
                 e = hipGetLastError();
             }
             const hipError_t e2 = hipFreeAsync(ws, stream);
@@ -1027,7 +1044,7 @@ hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
         (void)hipGetLastError();                 // no scratch: stream order
     }
     hipLaunchKernelGGL((tok::k_inflate_tok<false, tok::CAP_FULL>), grid, block, 0, stream, a, (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, 0u);
+                       (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -1041,13 +1058,14 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
     const dim3 grid((unsigned)((a.nstreams + 63u) / 64u)), block(64);
     const dim3 cgrid((unsigned)((a.nstreams + 255u) / 256u)), cblock(256);
     // ws[0], ws[1]: the two counts; ws[2 .. 2 + BIN_WORDS): the bins of stage 1's counting sort (zeroed with the counts in one launch);
-    // the collected list behind them (both stages: the launches are ordered), the length-ordered list of stage 1 behind that
+    // the collected list behind them (both stages: the launches are ordered; 4 bytes per stream), the length-ordered list of stage 1
+    // behind that (4 more per stream when binned)
     uint32_t* ws = nullptr;
     // (the explicit lane hint keeps every such stream in the lane kernels)
     const uint32_t lane_min = (a.flags & HDLZ_INFLATE_LANE_PER_STREAM) ? 0u : HDLZ_INFLATE_DYN_LANE_MIN;
     // ragged input: stage 1 takes its streams in the order of their length class, like pass 1: k_collect_dyn counts the classes of the
     // streams it lists and its last block makes the first slots, so the sort adds ONE launch (the scatter)
-    const bool binned = a.in_off != nullptr && a.nstreams > HDLZ_INFLATE_BIN_MIN && !all;
+    const bool binned = a.in_off != nullptr && a.nstreams > HDLZ_INFLATE_BIN_MIN && a.nstreams <= 0xFFFFFFFFull && !all;   // (32-bit stream ids in the lists)
     const uint32_t head = 2u + tok::BIN_WORDS;
     const size_t nws = (size_t)head + a.nstreams + (binned ? (size_t)a.nstreams : 0u);
     hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * nws, stream);
@@ -1061,7 +1079,7 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
     if (e == hipSuccess) {
         if (all) {
             hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, (const uint32_t*)nullptr,
-                               (const uint32_t*)nullptr, 0u);
+                               (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
             e = hipGetLastError();
         } else {
             const uint32_t* list1 = list0;
@@ -1078,7 +1096,8 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
             }
             e = hipGetLastError();
             if (e == hipSuccess) {
-                hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, list1, (const uint32_t*)ws, lane_min);
+                hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_SMALL>), grid, block, 0, stream, a, list1, (const uint32_t*)ws, lane_min,
+                                   binned ? (const uint32_t*)(bins + tok::NBIN) : (const uint32_t*)nullptr, (const uint32_t*)list0);
                 e = hipGetLastError();
             }
             if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws, lane_min);   // (one of the two returns at once)
@@ -1089,7 +1108,7 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
         hipLaunchKernelGGL(tok::k_collect_dyn, cgrid, cblock, 0, stream, a.status, a.nstreams, list0, ws + 1, (const uint64_t*)nullptr,
                            (uint32_t*)nullptr, (uint32_t)HDLZ_E_DYNAMIC_UNSUPPORTED);
         hipLaunchKernelGGL((tok::k_inflate_tok<true, tok::CAP_FULL>), grid, block, 0, stream, a, (const uint32_t*)list0,
-                           (const uint32_t*)(ws + 1), lane_min);
+                           (const uint32_t*)(ws + 1), lane_min, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
         e = hipGetLastError();
         if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws + 1, lane_min);
     }

@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define HDLZ_VERSION 0x000401   /* 0x000401: same ABI, new inflate lane kernels (register-queue refill, second token group per round): the PMC records
+#define HDLZ_VERSION 0x000500   /* 0x000500, round 5: + a third inflate mapping, 16 lanes per stream with the stream's history in LDS (HDLZ_INFLATE_GROUP_PER_STREAM = 64,
+                                   the default for batches of HDLZ_INFLATE_GROUP_MIN .. _MAX streams); new compress kernels (same bytes).  0x000401: same ABI, new inflate lane kernels (register-queue refill, second token group per round): the PMC records
                                    of profiles/traffic.json are tied to the version.  0x000400, round 4: + hdlz_release_scratch (bounded scratch pool); hdlz_compact_batch accepts a pinned-host destination; the opt-in
                                    two-phase inflate of 0x000301 (HDLZ_INFLATE_TWO_PHASE = 64) was measured slower than the one-pass kernel and is gone */
 
@@ -81,6 +82,14 @@ enum {
  * the device, same results); scratch: stream-ordered, 8 bytes per possible output byte (min(out_pitch, 172 * in_len)).
  * A batch of a FEW such streams (fixed pitch, nstreams * 2 KiB <= in_len) goes through the same path stream by stream. */
 #define HDLZ_INFLATE_PAR_MIN 16384u
+/* 16 lanes per stream (hdlz_inflate_grp.hip; round 5): the stream's history in a 2 KiB LDS ring, input and output in full lines, four
+ * streams per wave -- the mapping for batches too small to fill the GPU one lane per stream and too large to give every stream a
+ * wave: the default for HDLZ_INFLATE_GROUP_MIN <= nstreams <= HDLZ_INFLATE_GROUP_MAX (measured crossovers, tools/bench_inflate_mapping.py),
+ * and for any batch when the flag is given.  Streams with dynamic-tree blocks take the usual second pass.  (The value 64 was the
+ * two-phase inflate of 0x000301, rejected as unknown by 0x000400 / 0x000401.) */
+#define HDLZ_INFLATE_GROUP_PER_STREAM 64u
+#define HDLZ_INFLATE_GROUP_MIN 8192u
+#define HDLZ_INFLATE_GROUP_MAX 16384u
 /* lane-per-stream kernel variant (results are identical): the default and 16 = one token per round (k_inflate_tok),
  * 32 = one output byte per lockstep iteration (k_inflate, the round-1 kernel) */
 #define HDLZ_INFLATE_TOKEN_ROUNDS 16u

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_bound_and_strings():
     from hdl_deflate_amd import _lib, out_bound
     L = _lib.load()
-    assert L.hdlz_version() == 0x000401
+    assert L.hdlz_version() == 0x000500
     for n in (0, 5, 256, 2048, 65536, 1 << 24):
         assert L.hdlz_out_bound(n) == out_bound(n) == 6 + (9 * n + 10 + 7) // 8
     assert L.hdlz_status_string(0) == b"OK" and b"SHORT" in L.hdlz_status_string(1)

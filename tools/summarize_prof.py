@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-OURS = ("k_compress", "k_inflate", "k_par_", "k_stream_", "k_collect", "k_emit")
+OURS = ("k_compress", "k_inflate", "k_par_", "k_stream_", "k_collect", "k_emit", "k_compact", "k_archive")
 
 
 def find(sub, pat):
