@@ -179,6 +179,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
             const uint32_t nrem = n - min(p_run, n);                  // positions of the block from p_run on
             uint32_t best[RUN], tok[RUN], code[RUN];
             TT(1);                                                // stage (HBM latency, LDS writes, bit buffer zeroing)
+            // Wave priorities (round 5): the search is the one phase that is pure VALU work; every other phase is a chain of LDS round
+            // trips, scalar work or memory waits with little to issue.  With the search at the LOWEST priority a wave in any other phase
+            // issues the moment it can -- it leaves those phases sooner, and the search of the other four waves fills every slot it does
+            // not need: 4.79 -> 4.57 ms on configs[1] (profiles/r05_compress_ab.txt; the opposite assignment: 4.85).  The hash finder of
+            // the wide windows is LDS-bound itself: no gain there, left alone.
+            if constexpr (!HASH) __builtin_amdgcn_s_setprio(0);
             HDLZ_MARK("search");
             if constexpr (HASH) {
                 match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);               // 2. R3/R4, wide windows
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
                     asm volatile("" : "+v"(ad_a), "+v"(ad_w), "+v"(wm));              // computed HERE, while the bytes are in registers
                 }
                 TT(3);
+                if constexpr (!HASH) __builtin_amdgcn_s_setprio(1);
                 HDLZ_MARK("extend");
                 make_tokens<NCH, FULLWIN, true>(lds.in, HALO + lane * RUN, ow, best, cw4, kmax, 4u * min(p_run, 32u * NCH), nrem, tok, (int32_t)(n - t0));   // 3. R5
             }

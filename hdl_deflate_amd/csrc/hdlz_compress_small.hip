@@ -121,6 +121,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // positions are block-relative: a block's first run has no history (d <= p)
         const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);   // dword index of the run in lds.in
         uint32_t best[RUN], tok[RUN], code[RUN];
+        __builtin_amdgcn_s_setprio(0);                         // (the search at the lowest priority, every other phase above it: hdlz_compress.hip)
         match_search<NCH, NCH == 1>(lds.in, run_dw, best);     // 2. R3/R4 (candidate keys by DPP: a run in front of a block's first run belongs to
                                                                //    another block -- or is lane 63 -- and only yields distances beyond the position)
         {
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 lds.ad[0][lane] = sa;                                 // <= 8160
                 lds.ad[1][lane] = nrem * sa - sc;                     // sum (N - p) x_p over the run, < 2^24 for N <= 1024
             }
+            __builtin_amdgcn_s_setprio(1);
             make_tokens<NCH, FULLWIN>(lds.in, HALO + lane * RUN, ow, best, cw4, kmax, 4u * min(p_run, 32u * NCH), nrem, tok);   // 3. R5
         }
         pin(tok);

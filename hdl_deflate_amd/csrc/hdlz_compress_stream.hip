@@ -343,7 +343,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? H
         if constexpr (HASH) {
             match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);                   // 2. R3/R4, wide windows
             for (uint32_t w = lane; w < OUT_WORDS; w += 64) lout[w] = 0u;                          // (the bit buffer: in the finder's dead tables)
-        } else match_search<NCH>(lds.in, run_dw, best);                                            // 2. R3/R4
+        } else {
+            __builtin_amdgcn_s_setprio(0);                       // (the search at the lowest priority, every other phase above it: hdlz_compress.hip)
+            match_search<NCH>(lds.in, run_dw, best);                                               // 2. R3/R4
+            __builtin_amdgcn_s_setprio(1);
+        }
         {
             uint32_t ow[12];
             load_own(lds.in, run_dw, ow);
