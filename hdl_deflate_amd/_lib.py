@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HDLZ_LIB") or os.path.join(_HERE, "lib", "libhdlz.so")   # HDLZ_LIB: A/B builds
 EXPORTS = ("hdlz_version", "hdlz_status_string", "hdlz_last_error", "hdlz_device_count", "hdlz_out_bound",
-           "hdlz_compress_batch", "hdlz_inflate_batch", "hdlz_compact_batch",
+           "hdlz_compress_batch", "hdlz_inflate_batch", "hdlz_compact_batch", "hdlz_archive_batch",
            "hdlz_stream_work_bytes", "hdlz_compress_stream", "hdlz_streams_work_bytes", "hdlz_compress_streams",
            "hdlz_compress_chunk", "hdlz_inflate_chunk", "hdlz_release_scratch")
 _lib = None
@@ -38,6 +38,8 @@ def load():
     L.hdlz_inflate_batch.argtypes = [vp, vp, u64, u32, u64, u32, u32, vp, u64, vp, vp, vp]
     L.hdlz_compact_batch.restype = ci
     L.hdlz_compact_batch.argtypes = [vp, u64, vp, vp, u64, vp, vp]
+    L.hdlz_archive_batch.restype = ci
+    L.hdlz_archive_batch.argtypes = [vp, u64, vp, u64, vp, u64, vp, vp]
     L.hdlz_stream_work_bytes.restype = ctypes.c_size_t
     L.hdlz_stream_work_bytes.argtypes = [ctypes.c_size_t]
     L.hdlz_compress_stream.restype = ci

@@ -21,6 +21,9 @@
 
 namespace hdlz {
 
+#ifndef HDLZ_WS
+#define HDLZ_WS 4
+#endif
 constexpr int SMALL_OUT_WORDS = 704;          // G * ceil(out_bound(N)/4) is largest for N = 32: 64 * 11
 
 struct __attribute__((aligned(16))) SmallLds {
@@ -33,7 +36,7 @@ struct __attribute__((aligned(16))) SmallLds {
 static_assert(sizeof(SmallLds) >= GATHER_SPAN && offsetof(SmallLds, in) == 0, "make_tokens: masked gather inside the LDS block");
 
 template <bool RAGGED, bool FULLWIN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_compress_small(CompressArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLZ_WS, HDLZ_WS))) void k_compress_small(CompressArgs a) {
     constexpr int NCH = 1;
     __shared__ SmallLds lds;
     const uint32_t lane = threadIdx.x;

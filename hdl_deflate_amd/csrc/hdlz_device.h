@@ -94,4 +94,7 @@ hipError_t zero_words(uint32_t* p, uint32_t n, hipStream_t stream);
 hipError_t launch_compact(const uint8_t* rows, uint64_t pitch, const uint32_t* len, const uint64_t* off,
                           uint64_t nblocks, uint8_t* archive, hipStream_t stream);
 
+hipError_t launch_archive(const uint8_t* rows, uint64_t pitch, const uint32_t* len, uint64_t nblocks, uint8_t* archive, uint64_t cap,
+                          uint64_t* off, hipStream_t stream);
+
 }  // namespace hdlz

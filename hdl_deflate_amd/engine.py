@@ -153,6 +153,26 @@ class Engine(object):
         self._check(rc, "hdlz_compact_batch")
         return archive, offsets
 
+    @_on_device
+    def archive(self, rows, lens, archive=None, offsets=None):
+        """rows uint8[B, pitch], lens int32[B] -> (archive uint8[cap], offsets int64[B + 1]) in ONE launch (hdlz_archive_batch): the
+        exclusive scan of the lengths is made on the device, offsets[B] is the archive's length (no host sync: read it when needed),
+        offsets is directly the `in_off` of a ragged inflate / compress call.  `archive` defaults to a buffer of B * pitch bytes."""
+        assert rows.is_cuda and rows.dtype == torch.uint8 and rows.dim() == 2 and rows.is_contiguous() and rows.device == self.device
+        assert lens.is_cuda and lens.dtype == torch.int32 and lens.numel() == rows.shape[0]
+        B, pitch = rows.shape
+        lens = lens.contiguous()
+        if archive is None:
+            archive = torch.empty(B * pitch, dtype=torch.uint8, device=rows.device)
+        if offsets is None:
+            offsets = torch.empty(B + 1, dtype=torch.int64, device=rows.device)
+        assert archive.is_cuda and archive.dtype == torch.uint8 and archive.is_contiguous()
+        assert offsets.is_cuda and offsets.dtype == torch.int64 and offsets.numel() == B + 1 and offsets.is_contiguous()
+        rc = self.lib.hdlz_archive_batch(rows.data_ptr(), pitch, lens.data_ptr(), B, archive.data_ptr(), archive.numel(),
+                                         offsets.data_ptr(), self._stream())
+        self._check(rc, "hdlz_archive_batch")
+        return archive, offsets
+
     # -- the job from HOST buffers: the PCIe hops overlapped with the kernels
     @_on_device
     def compress_host(self, h_in, cwindow=32, maxmatch=10, chunk_blocks=None, h_archive=None, h_len=None, keep_buffers=True):
@@ -160,7 +180,7 @@ class Engine(object):
         the blocks' zlib streams back to back in pinned host memory (`h_archive[:total]`; block b at the exclusive scan of
         `h_len`), their lengths, and the number of blocks whose status is not OK (0 unless n < 5 / the capacity is wrong).
         The batch goes through the GPU in chunks of `chunk_blocks` blocks on three streams -- H2D of chunk k + 1, compress +
-        scan + hdlz_compact_batch of chunk k, D2H of chunk k - 1's ARCHIVE (not its pitched rows) -- so the job costs about
+        hdlz_archive_batch (scan + gather) of chunk k, D2H of chunk k - 1's ARCHIVE (not its pitched rows) -- so the job costs about
         the slower PCIe direction instead of H2D + kernel + D2H.  One host sync per chunk (its archive size).
         The three side streams and the staging buffers are kept on the Engine between calls (`keep_buffers=False` or
         release_host_buffers() drops them); compress_host / inflate_host of ONE Engine must not run from two threads at once."""
@@ -231,11 +251,9 @@ class Engine(object):
                     if ev_out[j] is not None:
                         s_k.wait_event(ev_out[j])             # the D2H that read d_arch[j] / d_len[j] two chunks ago
                     _, ol, st = self.compress_batch(d_in[j][:nb], cwindow=cwindow, maxmatch=maxmatch, out=d_rows[:nb], out_pitch=pitch)
-                    l64 = ol.to(torch.int64)
-                    off = torch.cumsum(l64, 0) - l64
-                    self.compact(d_rows[:nb], ol, offsets=off, archive=d_arch[j])
+                    _, off = self.archive(d_rows[:nb], ol, archive=d_arch[j])      # scan + gather in one launch (hdlz_archive_batch)
                     d_len[j][:nb].copy_(ol)
-                    d_tot[j][0] = l64.sum()
+                    d_tot[j][0] = off[nb]
                     d_tot[j][1] = (st != 0).sum()
                     ev_k[j] = torch.cuda.Event()
                     ev_k[j].record(s_k)

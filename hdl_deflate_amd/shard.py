@@ -86,20 +86,30 @@ def archive_offsets(all_len):
     return incl - l64, int(incl[-1].item()) if l64.numel() else 0
 
 
-def gather_archive(local_archive, nbytes_local, group=None):
-    """concatenate the per-rank archives on every rank (payload gather; NOT on the timed path):
-    all-gather of sizes, pad to the largest, all-gather, trim.  Returns uint8 [sum of sizes]."""
+def gather_archive(local_archive, nbytes_local, group=None, sizes=None):
+    """concatenate the per-rank archives on every rank (payload gather; NOT on the timed path): rank r's bytes are broadcast into
+    their place of ONE result buffer -- exact sizes, no padding to the largest archive, no concatenation copy (round 4 padded every
+    rank to the maximum and all-gathered: 8 x the largest archive staged per rank).  `sizes` (bytes per rank, e.g. from the gathered
+    lengths) spares the size all-gather and its host sync.  Returns uint8 [sum of sizes]."""
     if not (dist.is_available() and dist.is_initialized()):
         return local_archive[:nbytes_local]
     world = dist.get_world_size(group)          # (world == 1 included: the first real multi-GPU run must not be the first RCCL payload gather)
+    rank = dist.get_rank(group)
     dev = local_archive.device
     cdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
-    sizes = torch.zeros(world, dtype=torch.int64, device=cdev)
-    dist.all_gather_into_tensor(sizes, torch.tensor([nbytes_local], dtype=torch.int64, device=cdev), group=group)
-    sizes = sizes.tolist()
-    mx = max(sizes) if sizes else 0
-    pad = torch.zeros(mx, dtype=torch.uint8, device=cdev)
-    pad[:nbytes_local] = local_archive[:nbytes_local].to(cdev)
-    full = torch.empty(world * mx, dtype=torch.uint8, device=cdev)
-    dist.all_gather_into_tensor(full, pad, group=group)
-    return torch.cat([full[r * mx: r * mx + sizes[r]] for r in range(world)]).to(dev)
+    if sizes is None:
+        t = torch.zeros(world, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(t, torch.tensor([nbytes_local], dtype=torch.int64, device=cdev), group=group)
+        sizes = t.tolist()
+    sizes = [int(x) for x in sizes]
+    assert len(sizes) == world and sizes[rank] == int(nbytes_local)
+    out = torch.empty(sum(sizes), dtype=torch.uint8, device=cdev)
+    pos = 0
+    for r in range(world):
+        piece = out[pos:pos + sizes[r]]
+        if r == rank:
+            piece.copy_(local_archive[:nbytes_local])
+        if sizes[r]:
+            dist.broadcast(piece, src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+        pos += sizes[r]
+    return out if cdev == dev else out.to(dev)

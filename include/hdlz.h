@@ -156,6 +156,16 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
 int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, const uint64_t* d_off,
                        uint64_t nblocks, uint8_t* d_archive, void* stream);
 
+/*
+ * The same gather with the scan inside (round 5): d_off[0 .. nblocks] is WRITTEN -- d_off[b] = sum of d_len[0 .. b), d_off[nblocks] =
+ * the archive's length -- and row b is copied to d_archive + d_off[b], all in one launch (a ticketed decoupled look-back over tiles
+ * of 256 rows; stream-ordered scratch: 8 bytes per tile).  d_off is at once the ragged-input index hdlz_inflate_batch / hdlz_compress_batch
+ * take (d_in_off).  archive_cap: bytes writable at d_archive; rows that would end beyond it are not copied -- compare d_off[nblocks]
+ * with archive_cap after the call (sum of row bounds = always enough).  d_archive must be device memory.
+ */
+int hdlz_archive_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, uint64_t nblocks,
+                       uint8_t* d_archive, uint64_t archive_cap, uint64_t* d_off, void* stream);
+
 /* ---- one LARGE stream on the whole GPU ---------------------------------------------------------------------
  * Same STARTC semantics and bit-identical output as hdlz_compress_batch with nblocks = 1
  * (deflate.py:616-633 IDLE/STARTC ... :884-897 CHECKSUM: the reference handles one stream per START), but the

@@ -928,6 +928,50 @@ def test_compact_archive(engine, oracle):
     assert int((bs != 0).sum()) == 0 and torch.equal(back[:, :n], d)
 
 
+def test_archive_scan_and_gather_in_one_launch(engine):
+    """hdlz_archive_batch (round 5): offsets by a device-side decoupled look-back + the gather, one launch -- against the two-pass form
+    (exclusive scan on the host + hdlz_compact_batch) byte for byte, for batches below / at / above a tile of 256 rows and far above
+    the number of tiles one look-back step covers (64); the offsets are a valid ragged inflate input; a too small archive is reported
+    through offsets[B] and nothing is written beyond it"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    r = random.Random(61)
+    for B, pitch in ((0, 64), (1, 64), (255, 100), (256, 96), (257, 2320), (5000, 304), (70000, 64), (40000, 2320)):
+        lens = np.array([r.randrange(0, pitch + 1) for _ in range(B)], dtype=np.int32)
+        if B > 10:
+            lens[3] = 0; lens[B - 1] = pitch; lens[7:9] = 0
+        rows = torch.randint(0, 256, (B, pitch), dtype=torch.uint8, device="cuda")
+        d_len = torch.from_numpy(lens).cuda()
+        arch, offs = engine.archive(rows, d_len)
+        torch.cuda.synchronize()
+        ho = offs.cpu().numpy()
+        ref_off = np.zeros(B + 1, np.int64); np.cumsum(lens, out=ref_off[1:])
+        assert np.array_equal(ho, ref_off), (B, pitch)
+        if B:
+            a2, _ = engine.compact(rows, d_len)
+            assert torch.equal(arch[:int(ref_off[-1])], a2), (B, pitch)
+    # a compress job end to end: archive + offsets feed the ragged inflate directly
+    B, n = 3000, 1500
+    d = make_blocks(B, n, "cuda", seed=78)
+    out, ol, st = engine.compress_batch(d)
+    arch, offs = engine.archive(out, ol)
+    a2, o2 = engine.compact(out, ol)
+    total = int(offs[-1].item())
+    assert total == a2.numel() and torch.equal(arch[:total], a2) and torch.equal(offs[:-1], o2)
+    back, bl, bs = engine.inflate_batch(torch.cat([arch[:total], torch.zeros(64, dtype=torch.uint8, device="cuda")]), in_off=offs, out_pitch=1504)
+    assert int((bs != 0).sum()) == 0 and torch.equal(back[:, :n], d)
+    # capacity: rows that would end beyond the archive are skipped, the total still says what was needed
+    small = torch.full((total // 2,), 0xEE, dtype=torch.uint8, device="cuda")
+    guard = small.clone()
+    _, offs3 = engine.archive(out, ol, archive=small)
+    torch.cuda.synchronize()
+    assert int(offs3[-1].item()) == total
+    hs, ha, hof, hl = small.cpu().numpy(), a2.cpu().numpy(), o2.cpu().numpy(), ol.cpu().numpy()
+    fit = hof + hl <= small.numel()
+    last = int((hof + hl)[fit].max())
+    assert np.array_equal(hs[:last], ha[:last]) and (hs[last:] == 0xEE).all()
+
+
 def test_compact_into_pinned_host_memory(engine):
     """hdlz_compact_batch with a PINNED HOST archive (k_compact_host, chosen by hipPointerGetAttributes -- ADVICE r4: nothing exercised
     it): rows of every length 0 .. 67 and multiples of 16, at 16-byte aligned destinations (the 16-byte branch: pitch and offsets
