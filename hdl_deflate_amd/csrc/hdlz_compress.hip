@@ -36,6 +36,12 @@
 
 namespace hdlz {
 
+// wave priorities of the wide-window (hash finder) kernels by phase: the finder is a chain of LDS round trips -- it goes first
+#ifndef HDLZ_HP_SEARCH
+#define HDLZ_HP_SEARCH 1
+#define HDLZ_HP_EXTEND 0
+#define HDLZ_HP_REST 0
+#endif
 #ifdef HDLZ_TILE_TIMING       // diagnostic build (tools/exp_tile_timing.py): s_memtime at the phase boundaries of the tile; the j-th block a wave
                               // processed reports the wave's total of part j (cycles, 32 bits) in out_len INSTEAD of its result
 #define TT_DECL() uint32_t tacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (uint32_t)__builtin_readcyclecounter()
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
             // not need: 4.79 -> 4.57 ms on configs[1] (profiles/r05_compress_ab.txt; the opposite assignment: 4.85).  The hash finder of
             // the wide windows is LDS-bound itself: no gain there, left alone.
             if constexpr (!HASH) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(HDLZ_HP_SEARCH);
             HDLZ_MARK("search");
             if constexpr (HASH) {
                 match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);               // 2. R3/R4, wide windows
@@ -208,12 +215,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
                 }
                 TT(3);
                 if constexpr (!HASH) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(HDLZ_HP_EXTEND);
                 HDLZ_MARK("extend");
                 make_tokens<NCH, FULLWIN, true>(lds.in, HALO + lane * RUN, ow, best, cw4, kmax, 4u * min(p_run, 32u * NCH), nrem, tok, (int32_t)(n - t0));   // 3. R5
             }
             pin(tok);
             PHASE_FENCE();
             TT(4);
+            if constexpr (HASH) __builtin_amdgcn_s_setprio(HDLZ_HP_REST);
             HDLZ_MARK("parse");
             const uint64_t P = run_transfer(tok);                                                  // 4. greedy parse
             TT(5);
