@@ -65,7 +65,7 @@ def measured_counters(key, kname=None, grid=None):
 
 def compress_grid(nblocks, ncu=256):
     """threads hdlz_compress_batch launches for the one-block-per-wave kernels (hdlz_compress.hip: launch_compress)"""
-    return min(ncu * 64, nblocks) * 64
+    return min(ncu * 256, nblocks) * 64
 
 
 def kname_for(cwindow, n=1 << 16):

@@ -44,7 +44,8 @@ namespace hdlz {
 #endif
 #ifdef HDLZ_TILE_TIMING       // diagnostic build (tools/exp_tile_timing.py): s_memtime at the phase boundaries of the tile; the j-th block a wave
                               // processed reports the wave's total of part j (cycles, 32 bits) in out_len INSTEAD of its result
-#define TT_DECL() uint32_t tacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (uint32_t)__builtin_readcyclecounter()
+#define TT_DECL() uint32_t tacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (uint32_t)__builtin_readcyclecounter(); \
+        const uint32_t tt_c0 = tlast, tt_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime()
 #define TT(k) do { const uint32_t t_ = (uint32_t)__builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
 #define TT_TILE() tacc[12] += 1u
 #else
@@ -302,6 +303,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
 #pragma unroll
         for (int k = 0; k < 13; k++, blk += gridDim.x)
             if (blk < a.nblocks) { a.out_len[blk] = tacc[k]; a.status[blk] = 0u; }
+        // the wave's lifetime in s_memtime ticks and in s_memrealtime ticks (100 MHz): their ratio is the clock the first one counts
+        if (blk < a.nblocks) { a.out_len[blk] = (uint32_t)__builtin_readcyclecounter() - tt_c0; a.status[blk] = 0u; }
+        blk += gridDim.x;
+        if (blk < a.nblocks) { a.out_len[blk] = (uint32_t)__builtin_amdgcn_s_memrealtime() - tt_r0; a.status[blk] = 0u; }
     }
 #endif
 }
@@ -317,7 +322,7 @@ template __global__ void k_compress<8, false, false>(CompressArgs);
 
 hipError_t launch_compress(const CompressArgs& a, hipStream_t stream) {
     if (a.nblocks == 0) return hipSuccess;
-    // persistent single-wave workgroups: 64 per CU queued (16 resident at 4 waves/SIMD) so that the
+    // persistent single-wave workgroups: 256 per CU queued (20 resident at 5 waves/SIMD) so that the
     // hardware dispatcher balances uneven blocks; each wave strides over the batch
     // (the CU count is cached per DEVICE: a process may drive several GPUs)
     static int ncu_of[64] = {0};
@@ -334,7 +339,10 @@ hipError_t launch_compress(const CompressArgs& a, hipStream_t stream) {
     if (a.cwindow <= 32 && a.in_len >= 5u && a.in_len <= 1024u && a.out_pitch >= (uint64_t)out_bound(a.in_len) &&
         (a.in_off || ((a.in_pitch & 15u) == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0)))
         return launch_compress_small(a, stream, ncu);
-    uint64_t g = (uint64_t)ncu * 64u;
+    // (round 5: 256 waves queued per CU instead of 64 -- a wave's blocks all belong to one family when the families alternate with a
+    //  period that divides the grid, and waves of different families differ 3x in their run time (profiles/r05_tile_timing.txt); the
+    //  shorter a wave lives, the shorter the tail in which the GPU drains: 4.585 -> 4.475 ms on configs[1], 128: 4.515, 512: 4.475, 1024: 4.51)
+    uint64_t g = (uint64_t)ncu * 256u;
     if (g > a.nblocks) g = a.nblocks;
     const dim3 grid((unsigned)g), block(64);
     // every block within one wave-tile (fixed size, or a ragged batch whose caller states such a bound in in_len)

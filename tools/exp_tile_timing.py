@@ -20,8 +20,8 @@ ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=
 ev0.record(); zo, zl, st = e.compress_batch(d, cwindow=cw, maxmatch=10); ev1.record(); torch.cuda.synchronize()
 ms = ev0.elapsed_time(ev1)
 ncu = torch.cuda.get_device_properties(0).multi_processor_count
-G = min(B, ncu * 64)
-v = zl.cpu().numpy().astype(np.uint32)[: 13 * G].reshape(13, G).astype(np.float64)      # [part][wave]
+G = min(B, ncu * 256)
+v = zl.cpu().numpy().astype(np.uint32)[: 15 * G].reshape(15, G).astype(np.float64)      # [part][wave]
 names = ["block prologue", "stage (HBM wait, LDS fill)", "search", "adler", "extend", "parse", "chain", "codes", "scan", "scatter",
          "scatter drain (barrier)", "flush"]
 tiles = v[12]
@@ -31,3 +31,6 @@ for k in range(12):
     print("  %-28s %9.0f cycles per tile  %5.1f %%" % (names[k], (v[k] / tiles).mean(), 100 * v[k].sum() / tot.sum()))
 print("  total %.0f wave cycles per tile; per wave %.3f M cycles (slowest %.3f M, fastest %.3f M)" % (
     (tot / tiles).mean(), tot.mean() / 1e6, tot.max() / 1e6, tot.min() / 1e6))
+print("  s_memtime ticks per wave lifetime / s_memrealtime ticks (100 MHz): the counter runs at %.3f GHz; launch %.3f ms = %.0f ticks per SIMD" % (
+    (v[13] / v[14]).mean() * 0.1, ms, ms * 1e6 * (v[13] / v[14]).mean() * 0.1))
+from hdl_deflate_amd.data import make_blocks as _mb
