@@ -100,13 +100,19 @@ def roofline(kname, algo_bytes, k_ms, traffic_key=None, extra=None, grid=None, i
          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": e["traffic_bytes"] if e else None, "traffic_source": tsrc,
          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg, 4), "kernel_ms_median": round(median(k_ms), 4),
          "kernel_ms_min": round(min(k_ms), 4), "launches_timed": len(k_ms)}
-    if e and e.get("valu_insts") and e.get("gui_active"):
-        cpi = e.get("cycles_per_valu_inst", 4.0)
+    if e and e.get("valu_insts") and e.get("valu_fast_frac") is not None:
+        # VALU-pipe occupancy, priced with the measured two-class table (VERDICT r4 #3a): a wave64 instruction holds its SIMD's VALU pipe
+        # for 1.96 (add/sub/and/or/xor/lshr/ashr/mov/min_u16/bitop3) or 3.25 shader cycles (everything else), counted in s_memtime ticks
+        # (profiles/r04_ubench/ubench_valu_cycles*.txt); the kernel's own mix of the two classes comes from its ISA (tools/valu_mix.py),
+        # the launch's cycles in the SAME ticks from its duration x the counter's clock under this load (tools/exp_tile_timing.py)
+        ff = e["valu_fast_frac"]
+        cpi = 1.96 * ff + 3.25 * (1.0 - ff)
         est = e["valu_insts"] * cpi / 1024.0
-        cyc = e["gui_active"] / 8.0
+        cyc = k_avg * 1e-3 * e.get("shader_clock_ghz", 2.3) * 1e9
         r["issue"] = {"valu_insts_per_launch": int(e["valu_insts"]), "salu_insts_per_launch": int(e.get("salu_insts") or 0),
                       "valu_insts_per_byte": round(e["valu_insts"] / in_bytes, 3) if in_bytes else None,
-                      "cycles_per_valu_inst": cpi, "est_issue_cycles": int(est), "kernel_cycles": int(cyc), "frac": round(est / cyc, 3),
+                      "valu_fast_frac": round(ff, 3), "cycles_per_valu_inst": round(cpi, 3), "est_valu_pipe_cycles": int(est),
+                      "kernel_cycles": int(cyc), "shader_clock_ghz": e.get("shader_clock_ghz", 2.3), "frac": round(est / cyc, 3),
                       "source": e.get("source"), "note": e.get("issue_note")}
     if extra:
         r.update(extra)
@@ -388,6 +394,9 @@ def main_single(a):
         # -- streams with dynamic-tree blocks (stock zlib, default strategy): pass 1 flags them, k_inflate_tok<true>
         #    decodes them one lane each; the same streams one wave each beside it
         sec.append(bench_inflate(a, eng, cpu=False, streams=min(a.streams, 1 << 18), strategy="default"))
+        # -- round 5: the same configs[3] streams through the 16-lanes-per-stream mapping (history in LDS: traffic ~1.0x algorithmic; the
+        #    default for batches of HDLZ_INFLATE_GROUP_MIN .. _MAX streams), a quarter of them -- the measured answer to VERDICT r4 #1
+        sec.append(bench_inflate(a, eng, cpu=False, streams=min(a.streams, 1 << 18), kernel="group", name="configs[3], 16 lanes per stream"))
         # -- the reference's own use: ONE stream at a time.  STARTC then STARTD on one 16 MiB stream (the most a port with LMAX = 24
         #    holds), each on the whole GPU (k_stream_*, k_par_*)
         sec.append(bench_single_stream(torch, eng, dev, a))
@@ -449,6 +458,7 @@ def bench_single_stream(torch, eng, dev, a, n=1 << 24):
     kc = kernel_ms(torch, step_c, max(3, a.steps))
     kd = kernel_ms(torch, step_d, max(3, a.steps))
     ms_c, ms_d = sum(kc) / len(kc), sum(kd) / len(kd)
+    algo = n + zn + 4                         # one stream = N_in + N_out + one length word, in either direction
     return {"name": "one 16 MiB stream", "metric": "single-stream throughput (STARTC then STARTD of ONE stream, whole GPU each)",
             "value": round(n / ms_d / 1e3, 1), "unit": "MB/s", "ms_per_step": round(ms_d, 4), "higher_is_better": True,
             "config": {"workload": "one stream of %d bytes (families 1-4), CWINDOW=32, MATCH10: compressed by hdlz_compress_stream, "
@@ -456,6 +466,10 @@ def bench_single_stream(torch, eng, dev, a, n=1 << 24):
                        "stream_bytes": n, "compressed_bytes": zn},
             "inflate_MBps": round(n / ms_d / 1e3, 1), "inflate_ms": round(ms_d, 4),
             "compress_MBps": round(n / ms_c / 1e3, 1), "compress_ms": round(ms_c, 4),
+            # (VERDICT r4 #3b) the path is a CHAIN of kernels: algorithmic bytes over the duration of the whole call (HIP events around it);
+            # traffic = the counters summed over all kernels of one call (tools/prof_single.py -> profiles/r05_single_stream_pmc_summary.txt)
+            "roofline": roofline("k_par_* (STARTD: all kernels of hdlz_inflate_batch(nstreams = 1))", algo, kd, "k_par|stream=%d" % n),
+            "compress_roofline": roofline("k_stream_* (STARTC: all kernels of hdlz_compress_stream)", algo, kc, "k_stream|stream=%d" % n),
             "note": "one wave (every single stream before hdlz_inflate_par.hip): 9 MB/s; timed with HIP events around whole calls "
                     "(all kernels of the path)"}
 
@@ -576,7 +590,7 @@ def _zfixed_chunk(args):
     return b"".join(out), [len(z) for z in out]
 
 
-def bench_inflate(a, eng=None, cpu=True, streams=None, strategy=None):
+def bench_inflate(a, eng=None, cpu=True, streams=None, strategy=None, kernel=None, name=None):
     """BASELINE configs[3]: B stock-zlib Z_FIXED streams (wbits=15) over 2 KiB blocks of families 1/2/4
     (family 3 would make zlib emit stored blocks, which the DYNAMIC=False reference mis-decodes), made on
     the host cores with stock zlib outside the timed region; DYNAMIC=False semantics
@@ -590,11 +604,13 @@ def bench_inflate(a, eng=None, cpu=True, streams=None, strategy=None):
     dev = torch.device("cuda", 0)
     if eng is None:
         eng = hdl_deflate_amd.Engine(dev)
-    if streams is not None or strategy is not None:          # the dynamic-tree secondary entry: same flow, other streams
+    if streams is not None or strategy is not None or kernel is not None:     # a secondary entry: same flow, other streams / mapping
         import copy
         a = copy.copy(a)
         a.streams = streams or a.streams
         a.zlib_strategy = strategy or a.zlib_strategy
+        a.inflate_kernel = kernel or a.inflate_kernel
+        a.end_to_end = a.end_to_end and kernel is None
     B, n = a.streams, a.stream_block
     d_plain = make_blocks(B, n, dev, seed=4, families=(1, 2, 4))
     host = d_plain.cpu().numpy()
@@ -624,7 +640,7 @@ def bench_inflate(a, eng=None, cpu=True, streams=None, strategy=None):
     z_bytes, u_bytes = int(off[-1]), B * n
     algo = z_bytes + u_bytes + 4 * B
     fixed = a.zlib_strategy == "fixed"
-    res = {"name": "configs[3]" if fixed else "dynamic trees",
+    res = {"name": name or ("configs[3]" if fixed else "dynamic trees"),
            "metric": "inflate_output_throughput (zlib Z_FIXED streams, DYNAMIC=False)" if fixed
            else "inflate_output_throughput (stock zlib streams, dynamic trees, two passes)",
            "value": round(u_bytes / (dt / a.steps) / 1e6, 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps,
@@ -804,7 +820,7 @@ def main():
                          "(exercises the second pass k_inflate_tok<true> / k_inflate_dyn, SURVEY 8(f) rank 1)")
     ap.add_argument("--inflate-kernel", default="default", choices=["default", "token", "byte", "group"],
                     help="inflate: lane-per-stream kernel variant (token = k_inflate_tok, byte = k_inflate)")
-    ap.add_argument("--mode", default="compress", choices=["compress", "inflate", "roundtrip"],
+    ap.add_argument("--mode", default="compress", choices=["compress", "inflate", "roundtrip", "single"],
                     help="compress = BASELINE metric (default); inflate = only the configs[3] side metric (1 GPU)")
     ap.add_argument("--no-archive", dest="archive", action="store_false",
                     help="N=1: skip the archive figure (compress + scan + hdlz_compact_batch) of the headline job")
@@ -824,6 +840,11 @@ def main():
         d5 = make_blocks(a.cfg5_blocks, CFG5_BLOCK, torch.device("cuda", 0), seed=0)
         r5 = run_compress(torch, eng, d5, 32, 10, 1, 1, 0)
         print(json.dumps(bench_roundtrip(torch, eng, a, d5, r5)), flush=True)
+    elif a.mode == "single":                                  # only the one-stream entry (profiling)
+        import torch
+        import hdl_deflate_amd
+        torch.cuda.set_device(0)
+        print(json.dumps(bench_single_stream(torch, hdl_deflate_amd.Engine(torch.device("cuda", 0)), torch.device("cuda", 0), a)), flush=True)
     elif a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
     elif a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out="gpurun_out/prof_$tag"
 mkdir -p "$out"
-BENCH="python bench.py --no-secondary --steps 3 --warmup 1 --cpu-seconds 0 --verify 0 $*"
+BENCH="python bench.py --no-secondary --steps ${STEPS:-3} --warmup ${WARMUP:-1} --cpu-seconds 0 --verify 0 $*"      # (STEPS / WARMUP: the driver runs 20 / 5)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o t -- $BENCH > "$out/bench_trace.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY -d "$out/pmc_sq" -o t -- $BENCH > "$out/bench_pmc_sq.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE -d "$out/pmc_lds" -o t -- $BENCH > "$out/bench_pmc_lds.log" 2>&1

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef uint32_t __attribute__((aligned(1))) u32u;
@@ -71,8 +72,11 @@ void run(const char* name, uint8_t* buf, uint32_t pitch, uint32_t lanes, uint32_
     printf("%-44s %8.3f ms  %7.1f ns / wave-instr / CU  %7.2f G lane-requests/s\n", name, ms, per_cu_ns, winstr * 64 / ms / 1e6);
 }
 
-int main() {
-    const uint32_t pitch = 2048, lanes = 262144;        // 16 waves per CU x 256 CUs, 512 MiB: the working set of k_inflate_tok
+int main(int argc, char** argv) {
+    // (round 5: optional argument = the stride between the lanes' regions; 262144 lanes x 2048 B = 512 MiB is the working set of
+    //  k_inflate_tok, x 512 B = 128 MiB fits the 256 MiB Infinity Cache, x 128 B = 32 MiB the eight L2s together)
+    const uint32_t pitch = argc > 1 ? (uint32_t)atoi(argv[1]) : 2048, lanes = 262144;        // 16 waves per CU x 256 CUs
+    printf("== region stride %u bytes: %u MiB touched\n", pitch, (unsigned)(((uint64_t)lanes * pitch) >> 20));
     uint8_t* buf; uint32_t* sink;
     hipMalloc(&buf, (size_t)lanes * pitch + 4096);
     hipMalloc(&sink, 64);

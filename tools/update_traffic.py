@@ -1,26 +1,42 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the PMC summaries of tools/evidence_r4.sh: per bench entry the HBM bytes per launch (FETCH_SIZE x 2
+"""profiles/traffic.json from the PMC summaries of tools/evidence_r5.sh: per bench entry the HBM bytes per launch (FETCH_SIZE x 2
 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, KB -> bytes; per-dispatch means of separate --pmc passes) and the
 issue counters (SQ_INSTS_VALU / _SALU, GRBM_GUI_ACTIVE), together with WHAT was measured -- kernel symbol, launch grid, library
 version -- so that bench.py can refuse an entry that does not describe the kernel it just launched.
-usage: tools/update_traffic.py gpurun_out/ev_r4        (copies the summaries to profiles/r04_<name>_pmc_summary.txt)"""
+usage: tools/update_traffic.py gpurun_out/ev_r5        (copies the summaries to profiles/r05_<name>_pmc_summary.txt)
+Round 5: the issue side is priced per kernel -- the share of its VALU instructions that issue at the full rate comes
+from its ISA (tools/valu_mix.py), the clock of the cycle counter from the tile timing build of the same evidence run."""
 import json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from valu_mix import mix
 root = sys.argv[1]
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 hdr = open(os.path.join(REPO, "include", "hdlz.h")).read()
 VERSION = int(re.search(r"#define\s+HDLZ_VERSION\s+(0x[0-9a-fA-F]+)", hdr).group(1), 16)
-RND = "r04"
+RND = "r05"
 # summary file, traffic.json key, kernel symbol (prefix) the counters are taken from, committed copy
-SPEC = [("pmc_cfg1.txt", "k_compress<1>|blocks=1048576|block=2048|data=families", "k_compress<1, true, true>", "cfg1"),
-        ("pmc_cfg5.txt", "k_compress<1>|blocks=131072|block=65536|data=families", "k_compress<1, true, false>", "cfg5"),
-        ("pmc_cfg2.txt", "k_compress<2>|blocks=16384|block=65536|data=text", "k_compress<2, true, false>", "cfg2"),
-        ("pmc_cw256.txt", "k_compress<8>|blocks=16384|block=65536|data=text", "k_compress<8, true, false>", "cw256"),
-        ("pmc_inflate.txt", "k_inflate_tok|streams=1048576|block=2048|fixed", "k_inflate_tok<false, 288u>", "inflate_tok"),
-        ("pmc_inflate_dyn.txt", "k_inflate_tok|streams=262144|block=2048|default", "k_inflate_tok<false, 288u> + k_inflate_tok<true, 144u>", "inflate_tokdyn"),
-        ("pmc_roundtrip.txt", "k_inflate_tok|roundtrip|streams=131072|block=65536", "k_inflate_tok<false, 288u>", "roundtrip")]
+# summary file, traffic.json key, kernel symbol(s) the counters are taken from, committed copy, (source file, mangled substring) for the VALU mix
+SPEC = [("pmc_cfg1.txt", "k_compress<1>|blocks=1048576|block=2048|data=families", "k_compress<1, true, true>", "cfg1", ("hdlz_compress.hip", "k_compressILi1ELb1ELb1E")),
+        ("pmc_cfg5.txt", "k_compress<1>|blocks=131072|block=65536|data=families", "k_compress<1, true, false>", "cfg5", ("hdlz_compress.hip", "k_compressILi1ELb1ELb0E")),
+        ("pmc_cfg2.txt", "k_compress<2>|blocks=16384|block=65536|data=text", "k_compress<2, true, false>", "cfg2", ("hdlz_compress.hip", "k_compressILi2ELb1ELb0E")),
+        ("pmc_cw256.txt", "k_compress<8>|blocks=16384|block=65536|data=text", "k_compress<8, true, false>", "cw256", ("hdlz_compress.hip", "k_compressILi8ELb1ELb0E")),
+        ("pmc_inflate.txt", "k_inflate_tok|streams=1048576|block=2048|fixed", "k_inflate_tok<false, 288u>", "inflate_tok", ("hdlz_inflate_tok.hip", "k_inflate_tokILb0E")),
+        ("pmc_inflate_dyn.txt", "k_inflate_tok|streams=262144|block=2048|default", "k_inflate_tok<false, 288u> + k_inflate_tok<true, 144u>", "inflate_tokdyn", ("hdlz_inflate_tok.hip", "k_inflate_tokILb1ELj144E")),
+        ("pmc_roundtrip.txt", "k_inflate_tok|roundtrip|streams=131072|block=65536", "k_inflate_tok<false, 288u>", "roundtrip", ("hdlz_inflate_tok.hip", "k_inflate_tokILb0E")),
+        ("pmc_inflate_grp.txt", "k_inflate_grp|streams=262144|block=2048|fixed", "k_inflate_grp", "inflate_grp", ("hdlz_inflate_grp.hip", "k_inflate_grp"))]
+# the clock of s_memtime under the headline load (tools/exp_tile_timing.py prints it)
+CLK = 2.3
+tt = os.path.join(root, "tile_timing.txt")
+if os.path.exists(tt):
+    m_ = re.search(r"the counter runs at ([0-9.]+) GHz", open(tt).read())
+    if m_:
+        CLK = float(m_.group(1))
+    open(os.path.join(REPO, "profiles", "r05_tile_timing.txt"), "w").write(
+        "# tools/exp_tile_timing.py on the -DHDLZ_TILE_TIMING build, evidence run of the shipped kernels (tools/evidence_r5.sh)\n" +
+        "".join(l for l in open(tt) if "amdgpu.ids" not in l))
 tj = os.path.join(REPO, "profiles", "traffic.json")
 T = json.load(open(tj))
-for fn, key, kern, tag in SPEC:
+for fn, key, kern, tag, mixsrc in SPEC:
     p = os.path.join(root, fn)
     if not os.path.exists(p):
         continue
@@ -50,22 +66,48 @@ for fn, key, kern, tag in SPEC:
         continue
     dest = "profiles/%s_%s_pmc_summary.txt" % (RND, tag)
     open(os.path.join(REPO, dest), "w").write(
-        "# rocprofv3 evidence (tools/evidence_r4.sh -> tools/profile*.sh: kernel stats + SQ / LDS / FETCH / WRITE (+ TA / TCP / TCC) passes, "
+        "# rocprofv3 evidence (tools/evidence_r5.sh -> tools/profile*.sh: kernel stats + SQ / LDS / FETCH / WRITE (+ TA / TCP / TCC) passes, "
         "separate --pmc passes, per-dispatch means; libhdlz 0x%06x)\n" % VERSION + txt)
     e = {"traffic_bytes": int(f * 2 * 1024 + w * 1024), "source": dest, "fetch_size_kb": f, "write_size_kb": w,
          "kernel": kern, "grid": grid[0], "hdlz_version": VERSION,
          "valu_insts": val("SQ_INSTS_VALU"), "salu_insts": val("SQ_INSTS_SALU"), "gui_active": val("GRBM_GUI_ACTIVE"),
-         "cycles_per_valu_inst": 4.0,
-         "issue_note": "est_issue_cycles = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs: an UPPER price -- measured in shader cycles "
-                       "(profiles/r04_ubench/ubench_valu_cycles*.txt) a wave64 instruction costs 1.96 (add/sub/and/or/xor/lshr/ashr/mov/min_u16/bitop3) "
-                       "or 3.25 cycles (everything else) at >= 4 waves per SIMD, 2.4 / 4.4 at two waves, 4.9 at one; the compress tile mixes 59 % / 41 % "
-                       "of the two classes (tools/phase_count.py); kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs (GRBM_GUI_ACTIVE / wall time = 2.4 GHz; "
-                       "s_memtime / wall time = 1.8-2.1 GHz under these loads)",
-         "note": "round 4, %s: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE" % kern}
+         "valu_fast_frac": None, "shader_clock_ghz": CLK,
+         "issue_note": "est_valu_pipe_cycles = SQ_INSTS_VALU x (1.96 f + 3.25 (1 - f)) / 1024 SIMDs, f = the full-rate share of this kernel's VALU "
+                       "instructions in its ISA (tools/valu_mix.py; 1.96 / 3.25 shader cycles per wave64 instruction measured in s_memtime ticks, "
+                       "profiles/r04_ubench/ubench_valu_cycles*.txt): the time the VALU pipes are HELD, a lower bound of the time they are needed "
+                       "(at 2 waves per SIMD a wave cannot issue faster than 2.4 / 4.4, alone 4.9); kernel_cycles = launch duration x the clock of "
+                       "the same counter under the headline load (%.3f GHz, profiles/r05_tile_timing.txt)" % CLK,
+         "note": "round 5, %s: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE" % kern}
+    f_, s_ = mix(mixsrc[0], mixsrc[1])
+    e["valu_fast_frac"] = f_ / float(f_ + s_)
     rd, wr = val("TCC_EA0_RDREQ"), val("TCC_EA0_WRREQ")
     if rd is not None:
         e["tcc_ea0_rdreq"] = rd; e["tcc_ea0_wrreq"] = wr
         e["note"] += "; TCC_EA0_RDREQ / WRREQ = the 64-byte requests that left the L2 (the far history of the copies: one sector per token)"
     T[key] = e
     print(key, e["traffic_bytes"], "grid", e["grid"], "valu", e["valu_insts"])
+# the one-stream paths (tools/prof_single.sh: counters summed over the kernels of one call)
+p = os.path.join(root, "pmc_single.txt")
+if os.path.exists(p):
+    txt = "\n".join(l for l in open(p).read().splitlines() if "amdgpu.ids" not in l) + "\n"
+    dest = "profiles/%s_single_stream_pmc_summary.txt" % RND
+    open(os.path.join(REPO, dest), "w").write("# rocprofv3 evidence (tools/evidence_r5.sh -> tools/prof_single.sh): one 16 MiB stream through hdlz_compress_stream (k_stream_*) and "
+                                              "hdlz_inflate_batch(nstreams = 1) (k_par_* + the fall-back launch), every counter SUMMED over the kernels of one call; libhdlz 0x%06x\n" % VERSION + txt)
+    for fam, key, kname in (("k_stream", "k_stream|stream=16777216", "k_stream_* (STARTC: all kernels of hdlz_compress_stream)"),
+                            ("k_par", "k_par|stream=16777216", "k_par_* (STARTD: all kernels of hdlz_inflate_batch(nstreams = 1))")):
+        vals = {}
+        cur = None
+        for ln in txt.splitlines():
+            m = re.match(r"\s*family (\w+)\s*$", ln)
+            if m:
+                cur = m.group(1)
+            m = re.search(r"(\w+)\s+n=\d+ mean=([0-9.e+]+)", ln)
+            if m and cur == fam:
+                vals[m.group(1)] = float(m.group(2))
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            T[key] = {"traffic_bytes": int(vals["FETCH_SIZE"] * 2 * 1024 + vals["WRITE_SIZE"] * 1024), "source": dest,
+                      "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"], "kernel": kname, "grid": None,
+                      "hdlz_version": VERSION, "valu_insts": vals.get("SQ_INSTS_VALU"), "salu_insts": vals.get("SQ_INSTS_SALU"),
+                      "note": "round 5: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, summed over the kernels of one call"}
+            print(key, T[key]["traffic_bytes"])
 json.dump(T, open(tj, "w"), indent=1)
