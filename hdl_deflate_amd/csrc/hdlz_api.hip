@@ -177,6 +177,7 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
                                    HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_TOKEN_ROUNDS);
     // in between: 16 lanes per stream (k_inflate_grp, round 5) -- from HDLZ_INFLATE_GROUP_MIN streams on it beats a wave per stream,
     // up to HDLZ_INFLATE_GROUP_MAX a lane per stream; the streams it flags (dynamic-tree blocks) take the second pass below
+    if ((flags & HDLZ_INFLATE_GROUP_PER_STREAM) && nstreams > 0x7FFFFFFFull * 16) return fail_param("nstreams too large for the 16-lanes-per-stream mapping");
     const bool group = (flags & HDLZ_INFLATE_GROUP_PER_STREAM) ||
                        (hint == 0u && nstreams >= HDLZ_INFLATE_GROUP_MIN && nstreams <= HDLZ_INFLATE_GROUP_MAX);
     const bool wave_all = !group && ((flags & HDLZ_INFLATE_WAVE_PER_STREAM) ||

@@ -855,6 +855,52 @@ def test_inflate_second_token_group_per_round(engine, oracle):
     assert int((rs == 0).sum()) > 100 and len(set(rs.tolist())) >= 2
 
 
+def test_inflate_group_mapping_ring_far_history_and_flush(engine, oracle):
+    """k_inflate_grp (16 lanes per stream, hdlz_inflate_grp.hip): what is particular to it -- the 2 KiB history ring wrapping many times,
+    copies that reach beyond the ring into the stream's own flushed output (distances up to 32 KiB), distance-1 / -2 / -3 ... -15 runs
+    (the byte-l-mod-dist move), 258-byte matches (17 steps), the 1 KiB flushes and the tail, the 128-byte input halves on streams
+    whose length is just around a multiple of them, stored and multi-block streams, capacity exactly at / below the output, damaged
+    and cut streams: status, length and bytes against the oracle (COPY, /root/reference/deflate.py:1593-1659; D8)"""
+    import torch
+    r = random.Random(77)
+    plains = []
+    for n in (1, 5, 127, 128, 129, 255, 256, 1023, 1024, 1025, 2047, 2048, 2049, 4100, 40000, 70000):
+        plains.append(bytes(r.choice(b"abcdefghij  \n") for _ in range(n)))
+    base = bytes(r.randrange(256) for _ in range(3000))
+    plains.append(base * 30)                                                   # far copies: 3000 back, again and again
+    plains.append(bytes(r.randrange(256) for _ in range(33000)) * 2)           # distance ~ 32 KiB (wbits = 15)
+    for d in range(1, 17):
+        plains.append(bytes(r.randrange(256) for _ in range(d)) * (5000 // d))   # period d: overlapping copies of every small distance
+    plains.append(bytes(100000))                                               # 258-byte matches at distance 1
+    plains.append(DYN_TEXT * 5)
+    zs = []
+    for k, pl in enumerate(plains):
+        c = zlib.compressobj(r.choice([1, 6, 9]), zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+        z = c.compress(pl[:len(pl) // 2]) + (c.flush(zlib.Z_FULL_FLUSH) if k % 3 == 0 else b"") + c.compress(pl[len(pl) // 2:]) + c.flush()
+        zs.append(z)
+    zs.append(zlib.compress(bytes(r.randrange(256) for _ in range(5000)), 0))  # stored blocks
+    damaged = []
+    for z in zs[:20]:
+        zb = bytearray(z)
+        if len(zb) > 8:
+            zb[r.randrange(2, len(zb))] ^= 1 << r.randrange(8)
+        damaged.append(bytes(zb))
+        damaged.append(z[:max(1, len(z) - r.randrange(1, 9))])
+    for batch, cap in ((zs, 100096), (damaged, 100096), (zs, 2048), (zs, 4100)):
+        off = np.zeros(len(batch) + 1, np.int64)
+        np.cumsum([len(z) for z in batch], out=off[1:])
+        flat = np.frombuffer(b"".join(batch) + bytes(64), dtype=np.uint8).copy()
+        ref, rl, rs = oracle.inflate_batch(flat, off.astype(np.uint64), cap, flags=0, nthreads=4)
+        out, ol, st = engine.inflate_batch(torch.from_numpy(flat).cuda(), in_off=torch.from_numpy(off).cuda(), out_pitch=cap, flags=64)
+        torch.cuda.synchronize()
+        ho, hl, hs = out.cpu().numpy(), ol.cpu().numpy().astype(np.uint32), st.cpu().numpy().astype(np.uint32)
+        # (default-strategy text may hold dynamic blocks: the call's second pass decodes those -- same results)
+        assert np.array_equal(hs, rs), (cap, np.nonzero(hs != rs)[0][:5], hs[hs != rs][:5], rs[hs != rs][:5])
+        assert np.array_equal(hl, rl), cap
+        for k in range(len(batch)):
+            assert ho[k, :hl[k]].tobytes() == ref[k, :rl[k]].tobytes(), (cap, k)
+
+
 def test_inflate_error_statuses(engine, oracle):
     cases = [b"\x78\x9c" + bytes([0x07]) + bytes(8),                                  # BTYPE 3
              zlib.compress(DYN_TEXT, 9),               # dynamic block
