@@ -54,12 +54,10 @@ namespace hdlz {
 #define TT_TILE() do {} while (0)
 #endif
 
-// lsrc[0 .. words) (LDS, 16-byte aligned) -> dst (HBM, 4-byte aligned): 16-byte stores, then the one to three words that are left.
-// Returns the number of VMEM instructions the WAVE issued -- at least: the stage's counted wait may leave that many in flight.
-__device__ __forceinline__ uint32_t store_words(uint32_t* __restrict__ dst, const uint32_t* lsrc, uint32_t words, uint32_t lane) {
+// lsrc[0 .. words) (LDS, 16-byte aligned) -> dst (HBM, 4-byte aligned): 16-byte stores, then the one to three words that are left
+__device__ __forceinline__ void store_words(uint32_t* __restrict__ dst, const uint32_t* lsrc, uint32_t words, uint32_t lane) {
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));
     const uint32_t nq = words >> 2;
-    uint32_t cnt = 0;
     for (uint32_t q0 = 0; q0 < nq; q0 += 64u) {
         const uint32_t q = q0 + lane;
         if (q < nq) {
@@ -68,13 +66,8 @@ __device__ __forceinline__ uint32_t store_words(uint32_t* __restrict__ dst, cons
             //  than 8 bytes must not be written in the next two wait states, and the hazard recognizer does not look into inline asm)
             asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dst + 4u * q), "v"(v) : "memory");
         }
-        cnt += 1u;
     }
-    if (words & 3u) {
-        if (lane < (words & 3u)) dst[4u * nq + lane] = lsrc[4u * nq + lane];
-        cnt += 1u;
-    }
-    return cnt;
+    if (lane < (words & 3u)) dst[4u * nq + lane] = lsrc[4u * nq + lane];
 }
 
 // NCH = ceil(cwindow / 32): 1, 2 or 8 chunks of 32 candidate distances; FULLWIN: cwindow == 32 * NCH (the reference's
@@ -140,7 +133,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
         const uint8_t* src;
         uint32_t n;
         const uint32_t bst = block_params(blk, src, n);
-        if (bst != HDLZ_OK) {                        // (never a requested block: the request makes the same checks)
+        if (bst != HDLZ_OK) {
             if (lane == 0) { a.out_len[blk] = 0; a.status[blk] = bst; }
             continue;
         }

@@ -142,12 +142,7 @@ struct S5 {
     }
 };
 
-__device__ __forceinline__ void lds_dma_load16(const uint8_t* gptr, uint32_t lds_base) {
-    uint32_t save;      // LDS address = M0 + lane * 16 (see tools/ubench/lds_dma.hip); M0 is saved and restored
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(save) : "v"(gptr), "s"(lds_base) : "memory");
-}
-
+// (16 bytes per lane straight into LDS: lds_dma16, hdlz_device.h -- LDS address = M0 + lane * 16, see tools/ubench/lds_dma.hip)
 // byte address of stream position `pos` of lane `lane` inside a wave's ring
 __device__ __forceinline__ uint32_t ring_addr(uint32_t pos, uint32_t lane4) { return ((pos & (RINGB - 4u)) << 6) | lane4 | (pos & 3u); }
 
@@ -274,7 +269,7 @@ __global__ __launch_bounds__(DYN ? 64 : 256) void k_inflate_tok(InflateArgs a, c
     uint32_t myissue = 0;       // value of `issued` right after this lane's pending request
 
 #define TOK_REQUEST(asyncv) do {                                                                        \
-        if (sbase + 16u <= zn) lds_dma_load16(z + sbase, inq_base);                                       \
+        if (sbase + 16u <= zn) lds_dma16(z + sbase, inq_base);                                       \
         else for (uint32_t k_ = 0; k_ < SLOT_DW; k_++) inq[lane * SLOT_DW + k_] = load32(z, sbase + 4u * k_, zn); \
         myissue = (asyncv);                                                                               \
     } while (0)
