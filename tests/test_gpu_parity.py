@@ -288,6 +288,9 @@ def test_calls_are_hip_graph_capturable(engine, oracle):
     work = torch.empty((engine.lib.hdlz_stream_work_bytes(nbig) + 7) // 8, dtype=torch.int64, device="cuda")
     back = torch.empty((B, n), dtype=torch.uint8, device="cuda")
     back2 = torch.empty((B, n), dtype=torch.uint8, device="cuda")
+    back3 = torch.empty((B, n), dtype=torch.uint8, device="cuda")
+    arch = torch.empty(B * out.shape[1] + 64, dtype=torch.uint8, device="cuda")
+    aoff = torch.empty(B + 1, dtype=torch.int64, device="cuda")
     engine.compress_batch(d, out=out, out_pitch=out.shape[1])          # eager once: device properties get cached
     engine.compress_stream(big, nbig, out=sout, work=work)
     torch.cuda.synchronize()
@@ -300,10 +303,14 @@ def test_calls_are_hip_graph_capturable(engine, oracle):
             _, bl, bs = engine.inflate_batch(out, in_len=None, out_pitch=n, out=back)
             # the lane mapping: pass 1, then the device-side list of streams with dynamic blocks in stream-ordered scratch memory
             _, bl2, bs2 = engine.inflate_batch(out, in_len=None, out_pitch=n, out=back2, flags=2)
+            # round 5: scan + gather in one launch (a ticket and descriptors in stream-ordered scratch), then the 16-lanes-per-stream
+            # mapping on the ragged archive it made
+            engine.archive(out, ol, archive=arch, offsets=aoff)
+            _, bl3, bs3 = engine.inflate_batch(arch, in_off=aoff, out_pitch=n, out=back3, flags=64)
     for seed in (11, 12):
         d.copy_(make_blocks(B, n, "cuda", seed=seed))
         big.copy_(make_blocks(40, n, "cuda", seed=seed + 100).reshape(-1))
-        out.zero_(); sout.zero_(); back.zero_(); back2.zero_()
+        out.zero_(); sout.zero_(); back.zero_(); back2.zero_(); back3.zero_(); aoff.zero_()
         g.replay()
         torch.cuda.synchronize()
         assert int((st != 0).sum()) == 0 and int(ss.item()) == 0
@@ -314,6 +321,8 @@ def test_calls_are_hip_graph_capturable(engine, oracle):
         # inflate took the full pitch as in_len: trailing zero bytes after the Adler-32 are ignored (D6)
         assert int((bs != 0).sum()) == 0 and torch.equal(back, d) and int((bl != n).sum()) == 0
         assert int((bs2 != 0).sum()) == 0 and torch.equal(back2, d) and int((bl2 != n).sum()) == 0
+        assert int(aoff[-1].item()) == int(ol.to(torch.int64).sum().item())
+        assert int((bs3 != 0).sum()) == 0 and torch.equal(back3, d) and int((bl3 != n).sum()) == 0
 
 
 def test_api_edge_cases(engine, oracle):
