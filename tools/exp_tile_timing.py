@@ -23,7 +23,7 @@ ncu = torch.cuda.get_device_properties(0).multi_processor_count
 G = min(B, ncu * 256)
 v = zl.cpu().numpy().astype(np.uint32)[: 15 * G].reshape(15, G).astype(np.float64)      # [part][wave]
 names = ["block prologue", "stage (HBM wait, LDS fill)", "search", "adler", "extend", "parse", "chain", "codes", "scan", "scatter",
-         "scatter drain (barrier)", "flush"]
+         "first prologue of the wave", "flush"]
 tiles = v[12]
 tot = v[:12].sum(axis=0)
 print("%d blocks of %d bytes, CWINDOW %d: %d waves, %.0f tiles per wave, launch %.3f ms (timing build)" % (B, n, cw, G, tiles.mean(), ms))
@@ -31,6 +31,8 @@ for k in range(12):
     print("  %-28s %9.0f cycles per tile  %5.1f %%" % (names[k], (v[k] / tiles).mean(), 100 * v[k].sum() / tot.sum()))
 print("  total %.0f wave cycles per tile; per wave %.3f M cycles (slowest %.3f M, fastest %.3f M)" % (
     (tot / tiles).mean(), tot.mean() / 1e6, tot.max() / 1e6, tot.min() / 1e6))
+print("  wave lifetime %.3f M ticks (mean); sum of lifetimes / (SIMDs x launch ticks) = %.2f waves resident on average" % (
+    v[13].mean() / 1e6, v[13].sum() / (4 * ncu * ms * 1e6 * (v[13] / v[14]).mean() * 0.1)))
 print("  s_memtime ticks per wave lifetime / s_memrealtime ticks (100 MHz): the counter runs at %.3f GHz; launch %.3f ms = %.0f ticks per SIMD" % (
     (v[13] / v[14]).mean() * 0.1, ms, ms * 1e6 * (v[13] / v[14]).mean() * 0.1))
 from hdl_deflate_amd.data import make_blocks as _mb
