@@ -1,6 +1,8 @@
 """CPU, world_size 2 over gloo: the N>1 path of SURVEY 8(e) -- contiguous block shards, all-gather of
 per-block output lengths, exclusive scan for archive offsets.  No payload collective exists."""
+import datetime
 import os
+import queue
 import socket
 
 import numpy as np
@@ -21,10 +23,59 @@ def test_shard_range_covers_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _worker(rank, world, port, nblocks, q):
+def _rendezvous(rank, world, port, q):
+    """init_process_group; a failure HERE (gloo's full-mesh connect on a busy host) is reported as infrastructure, not as a result"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, "rendezvous", repr(e)))
+        raise
+
+
+def _spawn_world(worker, world, extra, timeout):
+    """Run `worker(rank, world, port, *extra, q)` on `world` spawned processes and return their queue entries.  A rendezvous that fails or
+    never completes is retried on a fresh port (twice); a worker that fails AFTER it -- an assertion of the test -- is not."""
+    ctx = mp.get_context("spawn")
+    for attempt in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        q = ctx.Queue()
+        ps = [ctx.Process(target=worker, args=(r, world, port) + tuple(extra) + (q,)) for r in range(world)]
+        for p in ps:
+            p.start()
+        res, infra = [], None
+        try:
+            for _ in ps:
+                item = q.get(timeout=timeout)
+                if len(item) == 3 and item[1] == "rendezvous":
+                    infra = item
+                    break
+                res.append(item)
+        except queue.Empty:
+            infra = ("?", "rendezvous", "no answer within %d s" % timeout) if not res else None
+            if infra is None:
+                for p in ps:
+                    p.terminate()
+                raise
+        if infra is None:
+            for p in ps:
+                p.join(60)
+                assert p.exitcode == 0
+            return res
+        for p in ps:                # the exact processes this call started
+            p.terminate()
+        for p in ps:
+            p.join(30)
+        if attempt == 2:
+            raise RuntimeError("gloo rendezvous failed three times: %r" % (infra,))
+
+
+def _worker(rank, world, port, nblocks, q):
+    _rendezvous(rank, world, port, q)
     try:
         from oracle import oracle as O
         from hdl_deflate_amd.data import family_bytes
@@ -49,20 +100,7 @@ def test_length_allgather_world2():
 
 
 def _run_world2(nblocks):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, nblocks, q)) for r in range(world)]
-    for p in ps:
-        p.start()
-    res = [q.get(timeout=120) for _ in ps]
-    for p in ps:
-        p.join(60)
-        assert p.exitcode == 0
+    res = _spawn_world(_worker, 2, (nblocks,), 120)
     from oracle import oracle as O
     from hdl_deflate_amd.data import family_bytes
     want = [len(O.compress(family_bytes(1 + b % 4, 300 + (b % 5), seed=b, counter0=16 * b))[1]) for b in range(nblocks)]
@@ -89,9 +127,7 @@ def _lens_of(nblocks):
 
 
 def _worker8(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _rendezvous(rank, world, port, q)
     try:
         res = {}
         for nblocks in (131072, 131075):
@@ -124,20 +160,7 @@ def _worker8(rank, world, port, q):
 
 
 def test_length_allgather_world8_job_shapes_and_subgroup():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    world = 8
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    ps = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
-    for p in ps:
-        p.start()
-    res = [q.get(timeout=300) for _ in ps]
-    for p in ps:
-        p.join(60)
-        assert p.exitcode == 0
+    res = _spawn_world(_worker8, 8, (), 150)
     for nblocks in (131072, 131075):
         want = _lens_of(nblocks).to(torch.int64)
         for rank, r in res:
