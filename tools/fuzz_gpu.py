@@ -68,6 +68,25 @@ def main():
             print("COMPRESS MISMATCH it=%d seed=%d block=%d n=%d cw=%d mm=%d kind=%d mis=%d status gpu/ref %d/%d len %d/%d"
                   % (it, a.seed, bad, lens[bad], cw, mm, kind, mis, hs[bad], rs[bad], hl[bad], rl[bad]))
             return 1
+        # the rows gathered into one archive (scan + gather in one launch): the streams back to back, offsets = the exclusive scan
+        if it % 2 == 0:
+            arc, aoff = eng.archive(out, ol)
+            torch.cuda.synchronize()
+            ha, hoff = arc.cpu().numpy(), aoff.cpu().numpy()
+            want_off = np.concatenate([[0], np.cumsum(hl.astype(np.int64))])
+            if not (hoff == want_off).all() or ha[: want_off[-1]].tobytes() != b"".join(ho[b, :hl[b]].tobytes() for b in range(B)):
+                print("ARCHIVE MISMATCH it=%d seed=%d B=%d cw=%d mm=%d kind=%d" % (it, a.seed, B, cw, mm, kind))
+                return 1
+            if (hs == 0).all() and B >= 1:          # ... and inflated straight from it (ragged input = the archive's offsets)
+                capa = (int(lens.max()) + 15) // 16 * 16 + 16
+                ab, abl, abs_ = eng.inflate_batch(arc, in_off=aoff, out_pitch=capa, flags=int(rng.choice([0, 2, 4, 34, 64])))
+                torch.cuda.synchronize()
+                hb, hbl, hbs = ab.cpu().numpy(), abl.cpu().numpy(), abs_.cpu().numpy()
+                for b in range(min(B, 2000)):
+                    if hbs[b] != 0 or hbl[b] != lens[b] or hb[b, :lens[b]].tobytes() != flat[off[b]:off[b + 1]].tobytes():
+                        print("ARCHIVE-INFLATE MISMATCH it=%d seed=%d block=%d n=%d cw=%d mm=%d status %d len %d" %
+                              (it, a.seed, b, lens[b], cw, mm, hbs[b], hbl[b]))
+                        return 1
         # inflate the compressed rows back on the GPU (padded rows, fixed pitch) for blocks that compressed
         okb = hs == 0
         if okb.any():
