@@ -241,7 +241,7 @@ int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t
 int hdlz_archive_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, uint64_t nblocks,
                        uint8_t* d_archive, uint64_t archive_cap, uint64_t* d_off, void* stream) {
     if (!d_off || (nblocks && (!d_rows || !d_len || !d_archive))) return fail_param("null device pointer");
-    if (nblocks > 0xFFFFFFFFull * 256ull) return fail_param("nblocks too large for one launch");
+    if (nblocks > 0x7FFFFFFFull) return fail_param("nblocks too large for one launch (2^31 - 1 rows)");   // (32-bit tile and word counts)
     int rc = check_device();
     if (rc != HDLZ_OK) return rc;
     hipError_t e = hdlz::launch_archive(d_rows, row_pitch, d_len, nblocks, d_archive, archive_cap, d_off, static_cast<hipStream_t>(stream));

@@ -161,7 +161,7 @@ int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t
  * the archive's length -- and row b is copied to d_archive + d_off[b], all in one launch (a ticketed decoupled look-back over tiles
  * of 256 rows; stream-ordered scratch: 8 bytes per tile).  d_off is at once the ragged-input index hdlz_inflate_batch / hdlz_compress_batch
  * take (d_in_off).  archive_cap: bytes writable at d_archive; rows that would end beyond it are not copied -- compare d_off[nblocks]
- * with archive_cap after the call (sum of row bounds = always enough).  d_archive must be device memory.
+ * with archive_cap after the call (sum of row bounds = always enough).  d_archive must be device memory.  nblocks < 2^31.
  */
 int hdlz_archive_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, uint64_t nblocks,
                        uint8_t* d_archive, uint64_t archive_cap, uint64_t* d_off, void* stream);

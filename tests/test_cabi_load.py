@@ -44,6 +44,11 @@ def test_no_cpu_fallback_without_gpu():
     assert rc == E_HIP and b"no CPU path" in L.hdlz_last_error() or rc == E_HIP
     assert L.hdlz_compress_batch(buf, None, 64, 64, 1, 999, 10, buf, 64, buf, buf, None) == E_BAD_PARAM
     assert L.hdlz_inflate_batch(buf, None, 64, 64, 1, 0, 0, buf, 64, buf, buf, None) == E_HIP
+    # hdlz_archive_batch: parameter checks come before the device is looked at; with good parameters: no device, no CPU path
+    off = (ctypes.c_uint64 * 4)()
+    assert L.hdlz_archive_batch(buf, 64, buf, 1 << 31, buf, 64, off, None) == E_BAD_PARAM and b"2^31" in L.hdlz_last_error()
+    assert L.hdlz_archive_batch(buf, 64, buf, 1, buf, 64, None, None) == E_BAD_PARAM
+    assert L.hdlz_archive_batch(buf, 64, buf, 1, buf, 64, off, None) == E_HIP
     try:
         hdl_deflate_amd.Engine()
     except RuntimeError as e:
