@@ -18,13 +18,13 @@
 //      k_par_emit    one wave per piece writes the bytes, 64 tokens at a time -- except that the history before the piece's own output
 //                    is not there yet.  A byte copied from there becomes a MARKER: src[p] = the absolute position it comes from
 //                    (markers are copied like bytes);
-//   4. k_par_jump    pointer jumping over the markers: src[p] <- eight steps along its chain, until the source is a byte (double-
-//                    buffered, one launch per pass, log8(pieces) + 1 passes at most; a pass with nothing left returns at once).
+//   4. k_par_jump    pointer jumping over the markers IN PLACE: src[p] <- up to HOPS steps along its chain, until the source is a byte
+//                    (one launch per pass, log_HOPS(pieces) + 1 passes at most; a pass with nothing left returns at once).
 // Anything else -- another block type, more than one block, a failed check (NO EOF, bad symbol, bad distance, capacity) -- sets
 // a fallback flag on the device and k_inflate_dyn redoes the stream from its first byte (it is launched behind the chain and
 // returns at once otherwise): status words and bytes are those of the serial decoder by construction, the parallel path
 // only ever reports HDLZ_OK.  Scratch (stream-ordered, from the library's own pool): ~1.6 KB per piece (the maps of the 32 offsets, of the sub-boundaries and of the
-// listed chains, the token lists) and 8 bytes per possible output byte (markers).
+// listed chains, the token lists) and 4 bytes per possible output byte (markers; 8 up to round 4: two buffers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdlz_device.h"
@@ -54,7 +54,7 @@ struct ParArgs {
     uint32_t flags, obsize;
     uint8_t* out;
     uint32_t cap;               // output capacity (bytes)
-    uint32_t srcn;              // entries of srcA / srcB
+    uint32_t srcn;              // entries of srcA
     uint32_t* out_len;
     uint32_t* status;
     uint32_t nchunks;
@@ -71,8 +71,7 @@ struct ParArgs {
     uint32_t* gopos;            // [ngroups]
     uint32_t* tokens;           // [nchunks][tmax_of(chbits)]  the tokens of every piece
     uint32_t* ntok;             // [nchunks]
-    uint32_t* srcA;             // [srcn]  marker of every output byte (NONE = the byte is there), double-buffered for the jumps
-    uint32_t* srcB;
+    uint32_t* srcA;             // [srcn]  marker of every output byte: the absolute position it comes from; NONE / ROOT | r: the byte is there
     uint32_t sub;               // k_par_spec: sub-pieces per piece (SUB), whose boundaries get maps of their own
     uint8_t* mexit8;            // [nchunks][SUB-1][32]  offset behind sub-boundary s for entry offset e (X_EOB: the chain ended in front of it)
     uint32_t* mnb32;            // [nchunks][SUB-1][32]  bytes of the tokens that start in front of that boundary
@@ -583,7 +582,6 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
     const uint32_t cstart = a.opos[c];
     uint8_t* out = a.out;
     uint32_t* src = a.srcA;
-    uint32_t* src2 = a.srcB;
     uint32_t Pb = cstart, nmark = 0, mlast = 0;
     for (uint32_t sbi = 0; sbi < nsub; sbi++) {
         const uint32_t f = c * nsub + sbi;
@@ -668,7 +666,7 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
                 }
                 if (in) { hb[slot] = (uint8_t)v; hm[slot] = m; }
                 if (in) {
-                    out[pabs] = (uint8_t)v; src[pabs] = m; src2[pabs] = NONE;      // (the second buffer of the marker passes: see k_par_jump)
+                    out[pabs] = (uint8_t)v; src[pabs] = m;
                     nmark += m != NONE ? 1u : 0u;
                     mlast = m != NONE ? pabs + 1u : mlast;
                 }
@@ -684,11 +682,16 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
     if (nmark) atomicAdd(&a.ctl[C_MARK], nmark);
 }
 
-// ---- 4. one pass of pointer jumping over the markers.  One workgroup per piece, over the bytes up to the piece's last marker only:
-// a stream with short distances (what STARTC writes: CWINDOW bytes) has its markers in the first CWINDOW bytes of every piece, and a
-// sweep over ALL output positions per pass read and wrote 4 bytes per output byte (64 + 64 MB at 16 MiB: 64 us).  Positions outside
-// the extents are no markers in EITHER buffer (the emit writes NONE to both), so a chain that leads there ends there.
+// ---- 4. one pass of pointer jumping over the markers, IN PLACE (round 5: one marker word per output byte instead of two buffers -- half
+// the scratch).  One workgroup per piece, over the bytes up to the piece's last marker only: a stream with short distances (what
+// STARTC writes: CWINDOW bytes) has its markers in the first CWINDOW bytes of every piece.
+// Why in place is exact.  src[p] is written by ONE thread (the one that owns p) and only ever replaced by a position further along
+// p's own chain or by its ROOT, so whatever a reader from another piece sees -- the old word (the XCDs' L2s are not coherent inside
+// a launch) or the new one -- is a valid ancestor.  The one thing a reader must not do is take the BYTE of a position that was resolved
+// in the launch it runs in (that store may not be visible yet): a resolved position keeps ROOT | r, r = the byte of the emit its chain
+// ends in -- final since the emit -- and a chain that arrives there takes out[r], not out[p].
 constexpr uint32_t HOPS = 256;                // (8 in round 2: a pass that finds nothing left still costs a launch, 4.5 us -- three passes cover 65536 pieces)
+constexpr uint32_t ROOT = 0x80000000u;        // src word: ROOT | r = resolved, the byte is out[r] (NONE: a byte of the emit, its own root); positions are < 2^30
 __global__ __launch_bounds__(64) void k_par_jump(ParArgs a, uint32_t pass) {
     if (a.ctl[C_FALLBACK] != 0u) return;
     if (a.ctl[pass == 0u ? (uint32_t)C_MARK : C_PASS0 + pass - 1u] == 0u) return;            // nothing left
@@ -697,24 +700,26 @@ __global__ __launch_bounds__(64) void k_par_jump(ParArgs a, uint32_t pass) {
     const uint32_t ext = a.mext[c];
     if (ext == 0u) return;
     const uint32_t p0 = a.opos[c];
-    const uint32_t* sin = (pass & 1u) ? a.srcB : a.srcA;
-    uint32_t* sout = (pass & 1u) ? a.srcA : a.srcB;
+    uint32_t* s = a.srcA;
     uint32_t left = 0;
     for (uint32_t p = p0 + threadIdx.x; p < p0 + ext; p += 64u) {
-        uint32_t m = sin[p];
-        uint32_t r = NONE;
-        if (m != NONE) {
-            // up to HOPS steps along the chain as it was before this launch: a chain of length L is L / HOPS long afterwards
-            r = m;
+        uint32_t m = s[p];
+        if (m & ROOT) continue;               // a byte: the emit's, or resolved by an earlier pass
+        uint32_t r = m;
+        bool open = true;
 #pragma unroll 1
-            for (uint32_t h = 0; h < HOPS; h++) {
-                const uint32_t m2 = sin[m];
-                if (m2 == NONE) { a.out[p] = a.out[m]; r = NONE; break; }     // (final since an earlier launch: nobody writes it now)
-                m = m2; r = m2;
+        for (uint32_t h = 0; h < HOPS; h++) {
+            const uint32_t m2 = s[m];
+            if (m2 & ROOT) {
+                const uint32_t root = m2 == NONE ? m : (m2 & ~ROOT);
+                a.out[p] = a.out[root];       // (a byte of the emit: nobody writes it now)
+                r = ROOT | root; open = false;
+                break;
             }
-            left += r != NONE ? 1u : 0u;
+            m = m2; r = m2;
         }
-        sout[p] = r;
+        left += open ? 1u : 0u;
+        s[p] = r;
     }
 #pragma unroll
     for (int ofs = 32; ofs > 0; ofs >>= 1) left += (uint32_t)__shfl_xor((int)left, ofs, 64);
@@ -740,7 +745,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     const uint64_t cap64 = a.out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00ull : a.out_pitch;
     uint64_t srcn = (uint64_t)zn * 172u + 258u;            // a token of 13 bits makes at most 258 bytes
     if (srcn > cap64) srcn = cap64;
-    if (srcn > (1ull << 30)) return hipSuccess;            // (8 GiB of scratch: leave it to the serial decoder)
+    if (srcn > (1ull << 30)) return hipSuccess;            // (4 GiB of scratch: leave it to the serial decoder)
     // (with the de-duplicated speculation: 1024-bit pieces 1.10 ms at 16 MiB -- markers, scans --, 4096 bits with 8 sub-pieces 0.67, these 0.64)
     // measured with the final kernels, 1 / 4 / 16 MiB of output: 1024-bit pieces 0.191 / 0.328 / 1.00 ms, 2048 bits 0.241 / 0.286 / 0.65, 4096 bits 0.317 / 0.361 / 0.571
     const uint32_t chbits = zn < (5u << 18) ? CH_BITS_MAX / 8u : zn < (3u << 20) ? CH_BITS_MAX / 4u : zn < (24u << 20) ? CH_BITS_MAX / 2u : CH_BITS_MAX;
@@ -756,7 +761,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                  o_mx = take((size_t)nchunks * (sub - 1u) * 32u), o_mn = take((size_t)nchunks * (sub - 1u) * 128u),
                  o_fe = take((size_t)nchunks * sub), o_fo = take((size_t)nchunks * sub * 4u),
                  o_tk = take((size_t)nchunks * sub * tmax_of(chbits / sub) * 4u), o_nt = take((size_t)nchunks * sub * 4u), o_sa = take((size_t)srcn * 4u),
-                 o_sb = take((size_t)srcn * 4u), o_me = take((size_t)nchunks * 4u),
+                 o_me = take((size_t)nchunks * 4u),
                  o_rp = take((size_t)nchunks * 128u), o_cp = take((size_t)nchunks * 128u), o_cx = take((size_t)nchunks * 32u),
                  o_cn = take((size_t)nchunks * 128u), o_cmx = take((size_t)nchunks * 32u * (sub - 1u)), o_cmn = take((size_t)nchunks * 128u * (sub - 1u));
     uint8_t* ws = nullptr;
@@ -768,7 +773,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                   reinterpret_cast<uint32_t*>(ws + o_ctl), ws + o_ex, reinterpret_cast<uint32_t*>(ws + o_nb), ws + o_en,
                   reinterpret_cast<uint32_t*>(ws + o_op), ws + o_gx, ws + o_gs, reinterpret_cast<uint32_t*>(ws + o_gn), ws + o_ge,
                   reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_tk), reinterpret_cast<uint32_t*>(ws + o_nt),
-                  reinterpret_cast<uint32_t*>(ws + o_sa), reinterpret_cast<uint32_t*>(ws + o_sb), sub, ws + o_mx,
+                  reinterpret_cast<uint32_t*>(ws + o_sa), sub, ws + o_mx,
                   reinterpret_cast<uint32_t*>(ws + o_mn), (uint32_t)C_NUSED, reinterpret_cast<uint32_t*>(ws + o_me)};
         // the same arguments at sub-piece granularity: what the real decode and the emit work on
         ParArgs pf = p;

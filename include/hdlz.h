@@ -79,7 +79,7 @@ enum {
 #define HDLZ_INFLATE_BIN_MIN 64u
 /* a batch of ONE stream of at least this many bytes (fixed-pitch form, no mapping hint) is cut into 1 KiB pieces and decoded by
  * the whole GPU when it is a single fixed-Huffman block -- the streams STARTC writes --, else by one wave as before (decided on
- * the device, same results); scratch: stream-ordered, 8 bytes per possible output byte (min(out_pitch, 172 * in_len)).
+ * the device, same results); scratch: stream-ordered, 4 bytes per possible output byte (min(out_pitch, 172 * in_len); 8 up to round 4).
  * A batch of a FEW such streams (fixed pitch, nstreams * 2 KiB <= in_len) goes through the same path stream by stream. */
 #define HDLZ_INFLATE_PAR_MIN 16384u
 /* 16 lanes per stream (hdlz_inflate_grp.hip; round 5): the stream's history in a 2 KiB LDS ring, input and output in full lines, four
@@ -133,7 +133,7 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
  * mapping that pass runs in two stages, the second one for the few streams whose block codes more than 144
  * literal/length symbols, and keeps the list of its streams in stream-ordered scratch memory, hipMallocAsync /
  * hipFreeAsync on `stream`, 4 bytes per stream (if that allocation fails the wave mapping finishes the job); the
- * parallel path for ONE large stream or a few of them -- HDLZ_INFLATE_PAR_MIN below -- allocates 8 bytes per possible
+ * parallel path for ONE large stream or a few of them -- HDLZ_INFLATE_PAR_MIN below -- allocates 4 bytes per possible
  * output byte the same way, whatever the flags; no other case allocates, and every case stays capturable into a HIP
  * graph) blocks, 4 trailer bytes required
  * but Adler-32 not verified -- exactly the reference's acceptance (deflate.py:635-651 IDLE/STARTD,
