@@ -152,8 +152,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_eu<NCH
 
         for (uint32_t t0 = 0; t0 < n; t0 += TILE) {       // (ONE_TILE: one iteration; left as a loop -- hipcc spills when it is peeled)
             // -------------------------------------------------------------- 1. stage the tile
-            if (blk == blockIdx.x) TT(10); else TT(0);            // block prologue / loop overhead (slot 10: the wave's first -- in the
-                                                                  // timing build it holds the s_memrealtime round trip, ~45 us)
+            if (blk == blockIdx.x) TT(10); else TT(0);            // block prologue / loop overhead (slot 10: the wave's first -- ~45 us in the
+                                                                  // timing build of <1,true,true>, whose prologue spills SGPRs to scratch (the
+                                                                  // shipped kernel has none); 140 cycles in the wide-window instantiations)
             HDLZ_MARK("stage");
             const uint32_t nfull = min((n - t0) >> 4, NCHUNK);    // whole chunks of the block in this tile
             wave_lds_order();                                     // (the previous tile's reads of lds.in are done)

@@ -33,7 +33,9 @@ if os.path.exists(tt):
         CLK = float(m_.group(1))
     open(os.path.join(REPO, "profiles", "r05_tile_timing.txt"), "w").write(
         "# tools/exp_tile_timing.py on the -DHDLZ_TILE_TIMING build, evidence run of the shipped kernels (tools/evidence_r5.sh)\n" +
-        "".join(l for l in open(tt) if "amdgpu.ids" not in l))
+        "".join(l for l in open(tt) if "amdgpu.ids" not in l) +
+        "# \"first prologue of the wave\": ~45 us in front of a wave's first tile in THIS instrumented build of <1,true,true> (its prologue spills SGPRs to scratch; the shipped kernel has\n"
+        "# no scratch, and the wide-window instantiations of the same build show 140 cycles there): an artifact of the stamps, reported apart so that \"block prologue\" is the per-tile cost.\n")
 tj = os.path.join(REPO, "profiles", "traffic.json")
 T = json.load(open(tj))
 for fn, key, kern, tag, mixsrc in SPEC:
