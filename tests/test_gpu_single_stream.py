@@ -158,3 +158,30 @@ def test_single_stream_inside_a_hip_graph(engine, oracle):
     torch.cuda.synchronize()
     assert int(bs.item()) == 0 and int(bl.item()) == 400000
     assert back[0, :400000].cpu().numpy().tobytes() == zlib.decompress(z)
+
+
+def test_runs_and_short_periods_at_64_mib(engine):
+    """64 MiB of zeros / of a period-3 pattern through STARTC and back through STARTD: EVERY output byte of every piece is a marker
+    of the bytes in front of the piece, the chains are as deep as the stream has pieces (~20 000: several in-place jump passes), and the
+    jump's per-piece memo is what keeps that from costing 256 hops per BYTE.  Round trip (the compress side of these inputs is
+    oracle-checked in tools/adversarial_stream.py and, at 3 MiB, above); the parallel path must have taken them: the serial decoder
+    needs seconds."""
+    import torch
+    n = 64 << 20
+    for name in ("zeros", "period3"):
+        d = torch.zeros(n + 16, dtype=torch.uint8, device="cuda") if name == "zeros" else (torch.arange(n + 16, device="cuda") % 3 + 65).to(torch.uint8)
+        d[n:] = 0
+        out, ol, st = engine.compress_stream(d, n)
+        zn = int(ol.item())
+        assert int(st.item()) == 0 and zn < n // 5
+        zin = out[:zn].reshape(1, zn).contiguous()
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            back, bl, bs = engine.inflate_batch(zin, out_pitch=n + 64)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+        assert int(bs[0].item()) == 0 and int(bl[0].item()) == n and torch.equal(back[0, :n], d[:n]), name
+        assert dt < 0.25, (name, dt)            # (1.6 ms measured; one wave: ~6 s)
+        del d, out, back, zin
+        torch.cuda.empty_cache()
