@@ -149,6 +149,9 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
     return HDLZ_OK;
 }
 
+#ifndef HDLZ_PAR_FEW_BYTES
+#define HDLZ_PAR_FEW_BYTES 2048
+#endif
 int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
                        uint64_t nstreams, uint32_t flags, uint32_t obsize, uint8_t* d_out, uint64_t out_pitch,
                        uint32_t* d_out_len, uint32_t* d_status, void* stream) {
@@ -191,9 +194,10 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
         if (e != hipSuccess) return fail_hip(e, "launch the parallel single-stream inflate");
         if (used) return HDLZ_OK;
     }
-    // a FEW large streams (fixed pitch): one after the other through the same path -- a wave per stream decodes 9 MB/s, the whole
-    // GPU needs ~0.35 ms + the stream's share of 15-25 GB/s: worth it while nstreams * 2 KiB <= in_len
-    if (nstreams > 1 && !d_in_off && in_len >= HDLZ_INFLATE_PAR_MIN && nstreams * 2048ull <= (uint64_t)in_len &&
+    // a FEW large streams (fixed pitch): one after the other through the same path -- a wave per stream decodes ~11 MB/s (64 KiB: 5.9 ms,
+    // 1 MiB: 94 ms, however many streams), one k_par chain costs 0.125 ms (64 KiB) .. 0.17 ms (1 MiB): worth it while nstreams *
+    // HDLZ_PAR_FEW_BYTES <= in_len (measured break-even 1.6 .. 2.1 KiB per stream, profiles/r05_inflate_mapping.txt; 512 and 128 lose)
+    if (nstreams > 1 && !d_in_off && in_len >= HDLZ_INFLATE_PAR_MIN && nstreams * (uint64_t)HDLZ_PAR_FEW_BYTES <= (uint64_t)in_len &&
         !(flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_BYTE_LOCKSTEP))) {
         bool all_used = true;
         uint64_t s = 0;

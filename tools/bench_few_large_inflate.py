@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""hdlz_inflate_batch on a FEW LARGE streams (fixed pitch): when is one k_par_* chain per stream, one after the other, faster than the
+batch kernels (every stream a serial chain)?  A/B of the threshold with HDLZ_LIB=... variants built with -DHDLZ_PAR_FEW_BYTES=n."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hdl_deflate_amd import Engine
+from hdl_deflate_amd.data import make_blocks
+e = Engine()
+for nb, kib in ((16, 64), (32, 64), (64, 64), (128, 64), (256, 64), (64, 256), (256, 256), (512, 256), (1024, 256), (256, 1024), (1024, 1024)):
+    n = kib << 10
+    d = make_blocks(nb * (n // 2048), 2048, "cuda", seed=2).reshape(nb, n)
+    zo, zl, st = e.compress_batch(d)
+    assert int(st.max().item()) == 0
+    res = []
+    for label, fl in (("auto", 0), ("wave", 4), ("group", 64)):
+        f = lambda: e.inflate_batch(zo, out_pitch=n, flags=fl)
+        back, bl, bs = f(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            back, bl, bs = f()
+        b.record(); torch.cuda.synchronize()
+        ok = int(bs.max().item()) == 0 and torch.equal(back[:, :n], d)
+        res.append("%s %8.3f ms%s" % (label, a.elapsed_time(b) / 3, "" if ok else " MISMATCH"))
+    print("%5d x %5d KiB (pitch %d):  %s" % (nb, kib, zo.shape[1], "  ".join(res)), flush=True)
+    del d, zo, back
+    torch.cuda.empty_cache()
