@@ -149,8 +149,8 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
     return HDLZ_OK;
 }
 
-#ifndef HDLZ_PAR_FEW_BYTES
-#define HDLZ_PAR_FEW_BYTES 2048
+#ifndef HDLZ_PAR_BATCH_MAX
+#define HDLZ_PAR_BATCH_MAX HDLZ_INFLATE_PAR_BATCH_MAX      // (A/B builds override it: tools/bench_few_large_inflate.py)
 #endif
 int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
                        uint64_t nstreams, uint32_t flags, uint32_t obsize, uint8_t* d_out, uint64_t out_pitch,
@@ -194,24 +194,17 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
         if (e != hipSuccess) return fail_hip(e, "launch the parallel single-stream inflate");
         if (used) return HDLZ_OK;
     }
-    // a FEW large streams (fixed pitch): one after the other through the same path -- a wave per stream decodes ~11 MB/s (64 KiB: 5.9 ms,
-    // 1 MiB: 94 ms, however many streams), one k_par chain costs 0.125 ms (64 KiB) .. 0.17 ms (1 MiB): worth it while nstreams *
-    // HDLZ_PAR_FEW_BYTES <= in_len (measured break-even 1.6 .. 2.1 KiB per stream, profiles/r05_inflate_mapping.txt; 512 and 128 lose)
-    if (nstreams > 1 && !d_in_off && in_len >= HDLZ_INFLATE_PAR_MIN && nstreams * (uint64_t)HDLZ_PAR_FEW_BYTES <= (uint64_t)in_len &&
-        !(flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_BYTE_LOCKSTEP))) {
-        bool all_used = true;
-        uint64_t s = 0;
-        for (; s < nstreams && all_used; s++) {
-            hdlz::InflateArgs a1 = a;
-            a1.in = d_in + s * in_pitch; a1.out = d_out + s * out_pitch; a1.out_len = d_out_len + s; a1.status = d_status + s;
-            a1.nstreams = 1;
-            bool used = false;
-            hipError_t e = hdlz::launch_inflate_par(a1, st, &used);
-            if (e != hipSuccess) return fail_hip(e, "launch the parallel single-stream inflate");
-            all_used = used;
-        }
-        if (all_used) return HDLZ_OK;
-        // (no scratch for stream s - 1: the batch kernels below redo everything, which is harmless)
+    // a FEW large streams (fixed pitch): the same path with every kernel launched once for all of them (blockIdx.y = the stream; round 5 --
+    // up to round 4 one chain of launches per stream, 0.125 ms each).  The batch kernels decode a stream as ONE serial chain (64 KiB:
+    // 5.9 ms, 1 MiB: 94 ms, however few there are); this path costs the launch chain once plus the streams' bytes at the rate of the
+    // single-stream path (profiles/r05_inflate_mapping.txt).
+    if (nstreams > 1 && nstreams <= HDLZ_PAR_BATCH_MAX && !d_in_off && in_len >= HDLZ_INFLATE_PAR_MIN &&
+        !(flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_GROUP_PER_STREAM))) {
+        bool used = false;
+        hipError_t e = hdlz::launch_inflate_par(a, st, &used);
+        if (e != hipSuccess) return fail_hip(e, "launch the parallel inflate of a few large streams");
+        if (used) return HDLZ_OK;
+        // (no scratch: the batch kernels below)
     }
     if (wave_all) {
         hipError_t e = hdlz::launch_inflate_dyn(a, st, true);

@@ -73,6 +73,7 @@ hipError_t launch_inflate_grp(const InflateArgs& a, hipStream_t stream);
 hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool all);
 hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used);
 hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream, bool all, const uint32_t* few_n = nullptr, uint32_t lane_min = 0);
+hipError_t launch_inflate_dyn_flagged(const InflateArgs& a, hipStream_t stream);
 size_t stream_work_bytes(uint32_t n, uint32_t nblocks);
 hipError_t launch_compress_streams(const uint8_t* in, uint64_t in_pitch, uint32_t n, uint32_t nblocks, int cwindow, int maxmatch,
                                    uint8_t* out, uint64_t out_pitch, uint32_t* out_len, uint32_t* status, void* work,

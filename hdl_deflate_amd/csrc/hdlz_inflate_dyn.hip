@@ -672,6 +672,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 
 // second pass after k_inflate (streams it flagged with HDLZ_E_DYNAMIC_UNSUPPORTED), or -- `all` -- the only pass
+// the streams whose status is HDLZ_E_DYNAMIC_UNSUPPORTED, whatever the flags (the several-streams form of hdlz_inflate_par.hip flags what
+// it gives up on -- under HDLZ_INFLATE_ASSUME_FIXED too, where the batch kernels' second pass has nothing to do)
+hipError_t launch_inflate_dyn_flagged(const InflateArgs& a, hipStream_t stream) {
+    if (a.nstreams == 0) return hipSuccess;
+    const uint64_t g = a.nstreams < 65536u ? a.nstreams : 65536u;
+    hipLaunchKernelGGL(k_inflate_dyn<false>, dim3((unsigned)g), dim3(64), 0, stream, a, (hdlz_istate*)nullptr, 0u, (const uint32_t*)nullptr, 0u);
+    return hipGetLastError();
+}
+
 hipError_t launch_inflate_dyn(const InflateArgs& a0, hipStream_t stream, bool all, const uint32_t* few_n, uint32_t lane_min) {
     if (a0.nstreams == 0 || (!all && (a0.flags & HDLZ_INFLATE_ASSUME_FIXED))) return hipSuccess;
     InflateArgs a = a0;

@@ -1,5 +1,5 @@
-// hdlz_inflate_par.hip -- STARTD for ONE large stream on the whole GPU (the port adapter's case: the reference inflates one stream
-// at a time, /root/reference/deflate.py:635-732 HEADER, :1402-1445 NEXT, :1519-1591 INFLATE, :1593-1659 COPY).
+// hdlz_inflate_par.hip -- STARTD for ONE large stream -- or a batch of up to HDLZ_INFLATE_PAR_BATCH_MAX of them, blockIdx.y = the stream -- on
+// the whole GPU (the port adapter's case: the reference inflates one stream at a time, /root/reference/deflate.py:635-732 HEADER, :1402-1445 NEXT, :1519-1591 INFLATE, :1593-1659 COPY).
 //
 // One wave decoding one stream is a serial chain: ~9 MB/s (k_inflate_dyn), a fifth of what the FPGA does at 100 MHz.  A stream of ONE
 // fixed-Huffman block -- what STARTC writes (deflate.py:429-466: 78 9C, BFINAL = 1, BTYPE = 1) and all the reference's DYNAMIC=False
@@ -77,7 +77,29 @@ struct ParArgs {
     uint32_t* mnb32;            // [nchunks][SUB-1][32]  bytes of the tokens that start in front of that boundary
     uint32_t cnu;               // the control word that holds the number of pieces in use at THIS granularity (C_NUSED / C_FNUSED)
     uint32_t* mext;             // [nchunks]  bytes from a piece's first output byte to behind its LAST marker (0: it has none)
+    // SEVERAL streams in the same launches (round 5): blockIdx.y is the stream; stream s reads z + s * in_pitch, writes out + s * out_pitch,
+    // out_len[s], status[s], and owns the scratch ws_stride bytes behind stream s - 1's (every array above, same layout)
+    uint64_t in_pitch, out_pitch;
+    size_t ws_stride;
+    uint32_t batch;             // != 0: a stream the path gives up on is FLAGGED for the serial pass (status HDLZ_E_DYNAMIC_UNSUPPORTED)
 };
+template <typename T> __device__ __forceinline__ void shift_ptr(T*& p, size_t bytes) {
+    p = reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + bytes);
+}
+// the arguments of stream blockIdx.y: every kernel below works on ONE stream and never looks at another one's arrays
+__device__ __forceinline__ ParArgs of_stream(ParArgs a) {
+    const uint32_t s = blockIdx.y;
+    if (s == 0u) return a;
+    a.z += (uint64_t)s * a.in_pitch;
+    a.out += (uint64_t)s * a.out_pitch;
+    a.out_len += s;
+    a.status += s;
+    const size_t d = (size_t)s * a.ws_stride;
+    shift_ptr(a.ctl, d); shift_ptr(a.exit8, d); shift_ptr(a.nb32, d); shift_ptr(a.entry8, d); shift_ptr(a.opos, d);
+    shift_ptr(a.gexit8, d); shift_ptr(a.gstop8, d); shift_ptr(a.gnb32, d); shift_ptr(a.gentry8, d); shift_ptr(a.gopos, d);
+    shift_ptr(a.tokens, d); shift_ptr(a.ntok, d); shift_ptr(a.srcA, d); shift_ptr(a.mexit8, d); shift_ptr(a.mnb32, d); shift_ptr(a.mext, d);
+    return a;
+}
 
 __device__ __forceinline__ void fill_tables(uint32_t* lit, uint32_t* dst, uint32_t tid, uint32_t nthreads) {
     for (uint32_t c = tid; c < 512u; c += nthreads) lit[c] = tok::lit_entry(c, true);      // (symbols 286 / 287 send the stream to the serial decoder whatever their leaf says)
@@ -99,7 +121,8 @@ __device__ __forceinline__ uint64_t bits_at(const uint32_t* win, uint32_t b_c, u
 
 // ---- 1. speculative decode: lane (piece, offset)
 template <bool SUBMAPS>
-__global__ __launch_bounds__(64) void k_par_spec(ParArgs a) {
+__global__ __launch_bounds__(64) void k_par_spec(ParArgs a_) {
+    const ParArgs a = of_stream(a_);
     __shared__ uint32_t lit[512], dst[32], win[2][WIN_DW];
     const uint32_t lane = threadIdx.x, half = lane >> 5, e = lane & 31u;
     fill_tables(lit, dst, lane, 64u);
@@ -184,6 +207,11 @@ struct Chains {
     uint32_t* cmn;
 };
 enum { C_NCHAIN = 6 };
+__device__ __forceinline__ Chains of_stream(Chains ch, size_t ws_stride) {
+    const size_t d = (size_t)blockIdx.y * ws_stride;
+    shift_ptr(ch.rep, d); shift_ptr(ch.cpos, d); shift_ptr(ch.cexit, d); shift_ptr(ch.cnb, d); shift_ptr(ch.cmx, d); shift_ptr(ch.cmn, d);
+    return ch;
+}
 
 // one token of a chain, lengths and byte counts only, branch-free (see k_par_spec); x = the next 32 stream bits
 __device__ __forceinline__ void spec_token(uint32_t x, const uint32_t* lit, const uint32_t* dst, uint32_t& pos, uint32_t& nbytes,
@@ -211,7 +239,9 @@ __device__ __forceinline__ void spec_token(uint32_t x, const uint32_t* lit, cons
 
 constexpr uint32_t HEAD_WAVES = 8;            // waves per workgroup of k_par_head: ONE atomic on the chain counter per workgroup (one per
                                               // wave -- 9.4 k same-address atomics at 16 MiB -- serialised in L2: 121 us for 25 us of work)
-__global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a, Chains ch) {
+__global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a_, Chains ch_) {
+    const ParArgs a = of_stream(a_);
+    const Chains ch = of_stream(ch_, a_.ws_stride);
     __shared__ uint32_t lit[512], dst[32], win[HEAD_WAVES][2][HEAD_BITS / 32 + 8], first[HEAD_WAVES][2][32], slotof[HEAD_WAVES][2][32];
     __shared__ uint32_t wcount[HEAD_WAVES], wbase[HEAD_WAVES];
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u, half = lane >> 5, e = lane & 31u;
@@ -267,7 +297,9 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a, Chains 
 // (The lane's bits copied into an LDS row of its own first -- no global load, hence no `s_waitcnt vmcnt` in the loop -- changed nothing
 // here: 138 -> 143 us at 16 MiB.  The ~800 cycles per token of a wave that is alone on its SIMD are the DEPENDENT issue of ~35
 // instructions and two LDS round trips, not memory; k_par_tokens, which also stores, gained 10 % from the same rows and keeps them.)
-__global__ __launch_bounds__(64) void k_par_tail(ParArgs a, Chains ch) {
+__global__ __launch_bounds__(64) void k_par_tail(ParArgs a_, Chains ch_) {
+    const ParArgs a = of_stream(a_);
+    const Chains ch = of_stream(ch_, a_.ws_stride);
     __shared__ uint32_t lit[512], dst[32];
     const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
     const uint32_t nchain = a.ctl[C_NCHAIN];
@@ -303,7 +335,9 @@ __global__ __launch_bounds__(64) void k_par_tail(ParArgs a, Chains ch) {
     if (have) { ch.cexit[i] = run ? (uint8_t)(pos - end) : (uint8_t)exitc; ch.cnb[i] = nbytes; }
 }
 
-__global__ __launch_bounds__(256) void k_par_resolve(ParArgs a, Chains ch) {
+__global__ __launch_bounds__(256) void k_par_resolve(ParArgs a_, Chains ch_) {
+    const ParArgs a = of_stream(a_);
+    const Chains ch = of_stream(ch_, a_.ws_stride);
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= a.nchunks * 32u) return;
     const uint32_t r = ch.rep[t];
@@ -335,7 +369,8 @@ __device__ __forceinline__ uint32_t stage_group(GroupLds& L, const ParArgs& a, u
     __syncthreads();
     return cnt;
 }
-__global__ __launch_bounds__(64) void k_par_scan_groups(ParArgs a) {
+__global__ __launch_bounds__(64) void k_par_scan_groups(ParArgs a_) {
+    const ParArgs a = of_stream(a_);
     __shared__ GroupLds L;
     const uint32_t lane = threadIdx.x, g = blockIdx.x;
     const uint32_t cnt = stage_group(L, a, g, lane);
@@ -352,7 +387,8 @@ __global__ __launch_bounds__(64) void k_par_scan_groups(ParArgs a) {
         a.gnb32[g * 32u + lane] = acc;                     // (a group makes < 64 * 175 KB)
     }
 }
-__global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a) {
+__global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a_) {
+    const ParArgs a = of_stream(a_);
     __shared__ GroupLds L;                                 // (the maps of 64 GROUPS at a time, staged like a group's pieces)
     __shared__ __attribute__((aligned(16))) uint8_t stp[GROUP * 32];
     __shared__ uint8_t ent[GROUP];
@@ -441,7 +477,10 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a) {
         if (!good) a.ctl[C_FALLBACK] = 1u;
     }
 }
-__global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a, uint8_t* fentry8, uint32_t* fopos) {
+__global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a_, uint8_t* fentry8, uint32_t* fopos) {
+    const ParArgs a = of_stream(a_);
+    shift_ptr(fentry8, (size_t)blockIdx.y * a_.ws_stride);
+    shift_ptr(fopos, (size_t)blockIdx.y * a_.ws_stride);
     __shared__ GroupLds L;
     __shared__ uint8_t ent[GROUP];
     __shared__ uint32_t op[GROUP];
@@ -484,7 +523,8 @@ __global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a, uint8_t* fent
 constexpr uint32_t TOK_LIT = 0x80000000u;     // a token: TOK_LIT | byte, or length | distance << 9
 __host__ __device__ inline uint32_t tmax_of(uint32_t chbits) { return chbits / 8u + 2u; }      // the shortest token is 8 bits long
 template <bool ROWS>
-__global__ __launch_bounds__(64) void k_par_tokens(ParArgs a) {
+__global__ __launch_bounds__(64) void k_par_tokens(ParArgs a_) {
+    const ParArgs a = of_stream(a_);
     __shared__ uint32_t lit[512], dst[32];
     extern __shared__ uint32_t rows_[];              // ROWS: the stream bits a lane will read, copied into an LDS row of its own first (dword j of lane l
                                                      // at j * 64 + l: every lane in its own bank) -- no global load and no `s_waitcnt vmcnt` in the loop
@@ -568,7 +608,8 @@ constexpr uint32_t HRING = 1024;              // (2048 with a pointer array besi
 constexpr uint32_t SPAN = 768;                // a batch ends with the token that takes its output beyond this many bytes
 constexpr uint32_t HREACH = HRING - 128u;     // distances served from the ring (it is written a 64-byte slice at a time)
 constexpr uint32_t P_RES = 0xFFu;             // in-slice pointer: the byte / marker is there
-__global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
+__global__ __launch_bounds__(64) void k_par_emit(ParArgs a_) {
+    const ParArgs a = of_stream(a_);
     __shared__ uint8_t hb[HRING];             // ring over the piece's output positions: byte ...
     __shared__ uint32_t hm[HRING];            // ... marker (NONE = the byte is there) ...
     __shared__ uint32_t tI[64];               // the batch's token words
@@ -692,7 +733,8 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a) {
 // ends in -- final since the emit -- and a chain that arrives there takes out[r], not out[p].
 constexpr uint32_t HOPS = 256;                // (8 in round 2: a pass that finds nothing left still costs a launch, 4.5 us -- three passes cover 65536 pieces)
 constexpr uint32_t ROOT = 0x80000000u;        // src word: ROOT | r = resolved, the byte is out[r] (NONE: a byte of the emit, its own root); positions are < 2^30
-__global__ __launch_bounds__(64) void k_par_jump(ParArgs a, uint32_t pass) {
+__global__ __launch_bounds__(64) void k_par_jump(ParArgs a_, uint32_t pass) {
+    const ParArgs a = of_stream(a_);
     if (a.ctl[C_FALLBACK] != 0u) return;
     if (a.ctl[pass == 0u ? (uint32_t)C_MARK : C_PASS0 + pass - 1u] == 0u) return;            // nothing left
     const uint32_t c = blockIdx.x;
@@ -736,31 +778,46 @@ __global__ __launch_bounds__(64) void k_par_jump(ParArgs a, uint32_t pass) {
 }
 
 // ---- 5. the verdict: HDLZ_OK and the length, or the serial decoder's turn
-__global__ __launch_bounds__(64) void k_par_finish(ParArgs a, uint32_t passes) {
+__global__ __launch_bounds__(64) void k_par_finish(ParArgs a_, uint32_t passes) {
+    const ParArgs a = of_stream(a_);
     if (threadIdx.x != 0) return;
     const uint32_t left = a.ctl[C_MARK] == 0u ? 0u : a.ctl[C_PASS0 + passes - 1u];
     const bool ok = a.ctl[C_FALLBACK] == 0u && left == 0u;
     if (ok) { a.out_len[0] = a.ctl[C_TOTAL]; a.status[0] = HDLZ_OK; }
+    else if (a.batch) { a.out_len[0] = 0u; a.status[0] = HDLZ_E_DYNAMIC_UNSUPPORTED; }      // several streams: the serial pass redoes the flagged ones
     a.ctl[C_OK] = ok ? 1u : 0u;
 }
 
+// the control words of every stream of the launch
+__global__ __launch_bounds__(64) void k_par_zero(ParArgs a_) {
+    const ParArgs a = of_stream(a_);
+    if (threadIdx.x < C_WORDS) a.ctl[threadIdx.x] = 0u;
+}
+static_assert(C_WORDS <= 64, "k_par_zero: one wave");
+
 }  // namespace par
 
-// one stream of at least HDLZ_INFLATE_PAR_MIN bytes (fixed pitch form): the parallel chain, then -- only if it gave up -- one wave
+// a.nstreams streams of at least HDLZ_INFLATE_PAR_MIN bytes each (fixed pitch form): the parallel chain -- every kernel once, blockIdx.y =
+// the stream --, then the serial decoder for what it gave up on: ONE stream: one wave, only if needed; several: the streams the chain
+// flagged (status HDLZ_E_DYNAMIC_UNSUPPORTED, as pass 1 of the batch kernels flags them)
 hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used) {
     using namespace par;
     *used = false;
     const uint32_t zn = a.in_len;
+    const uint32_t nstr = (uint32_t)a.nstreams;
+    if (a.nstreams == 0 || a.nstreams > 65535u) return hipSuccess;
     const uint64_t cap64 = a.out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00ull : a.out_pitch;
     uint64_t srcn = (uint64_t)zn * 172u + 258u;            // a token of 13 bits makes at most 258 bytes
     if (srcn > cap64) srcn = cap64;
     if (srcn > (1ull << 30)) return hipSuccess;            // (4 GiB of scratch: leave it to the serial decoder)
     // (with the de-duplicated speculation: 1024-bit pieces 1.10 ms at 16 MiB -- markers, scans --, 4096 bits with 8 sub-pieces 0.67, these 0.64)
     // measured with the final kernels, 1 / 4 / 16 MiB of output: 1024-bit pieces 0.191 / 0.328 / 1.00 ms, 2048 bits 0.241 / 0.286 / 0.65, 4096 bits 0.317 / 0.361 / 0.571
-    const uint32_t chbits = zn < (5u << 18) ? CH_BITS_MAX / 8u : zn < (3u << 20) ? CH_BITS_MAX / 4u : zn < (24u << 20) ? CH_BITS_MAX / 2u : CH_BITS_MAX;
+    // (the piece size follows the bytes of the whole LAUNCH: 256 streams of 1 MiB are cut like one stream of 256 MiB, not like 256 small ones)
+    const uint64_t ztot = (uint64_t)zn * nstr;
+    const uint32_t chbits = ztot < (5u << 18) ? CH_BITS_MAX / 8u : ztot < (3u << 20) ? CH_BITS_MAX / 4u : ztot < (24u << 20) ? CH_BITS_MAX / 2u : CH_BITS_MAX;
     const uint32_t nchunks = (8u * zn - FIRST_BIT + chbits - 1u) / chbits;
     // streams that do not fill the GPU with one lane per piece (the port's: LMAX = 24 bits = 16 MiB) decode sub-pieces
-    const uint32_t sub = zn < (24u << 20) ? SUB : 1u;
+    const uint32_t sub = ztot < (24u << 20) ? SUB : 1u;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
     const uint32_t ngroups = (nchunks + GROUP - 1u) / GROUP;
@@ -774,16 +831,19 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                  o_rp = take((size_t)nchunks * 128u), o_cp = take((size_t)nchunks * 128u), o_cx = take((size_t)nchunks * 32u),
                  o_cn = take((size_t)nchunks * 128u), o_cmx = take((size_t)nchunks * 32u * (sub - 1u)), o_cmn = take((size_t)nchunks * 128u * (sub - 1u));
     uint8_t* ws = nullptr;
-    hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), off, stream);
+    const size_t stride = off;                                  // (a multiple of 256: every stream's arrays are aligned like the first one's)
+    if (nstr > 1u && stride * (size_t)nstr > ((size_t)16 << 30)) return hipSuccess;      // (more than 16 GiB of scratch: the batch kernels)
+    hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), stride * nstr, stream);
     if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // no scratch: the caller goes on with the serial decoder
-    e = zero_words(reinterpret_cast<uint32_t*>(ws + o_ctl), C_WORDS, stream);
-    if (e == hipSuccess) {
+    {
         ParArgs p{a.in, zn, a.flags, a.obsize, a.out, (uint32_t)cap64, (uint32_t)srcn, a.out_len, a.status, nchunks, chbits,
                   reinterpret_cast<uint32_t*>(ws + o_ctl), ws + o_ex, reinterpret_cast<uint32_t*>(ws + o_nb), ws + o_en,
                   reinterpret_cast<uint32_t*>(ws + o_op), ws + o_gx, ws + o_gs, reinterpret_cast<uint32_t*>(ws + o_gn), ws + o_ge,
                   reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_tk), reinterpret_cast<uint32_t*>(ws + o_nt),
                   reinterpret_cast<uint32_t*>(ws + o_sa), sub, ws + o_mx,
-                  reinterpret_cast<uint32_t*>(ws + o_mn), (uint32_t)C_NUSED, reinterpret_cast<uint32_t*>(ws + o_me)};
+                  reinterpret_cast<uint32_t*>(ws + o_mn), (uint32_t)C_NUSED, reinterpret_cast<uint32_t*>(ws + o_me),
+                  a.in_pitch, a.out_pitch, stride, nstr > 1u ? 1u : 0u};
+        hipLaunchKernelGGL(k_par_zero, dim3(1, nstr), dim3(64), 0, stream, p);
         // the same arguments at sub-piece granularity: what the real decode and the emit work on
         ParArgs pf = p;
         pf.nchunks = nchunks * sub; pf.chbits = chbits / sub; pf.cnu = C_FNUSED;
@@ -792,29 +852,29 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         for (uint64_t reach = 1; reach < (uint64_t)nchunks + 1u; reach *= HOPS) passes++;
         if (passes > C_WORDS - C_PASS0) passes = C_WORDS - C_PASS0;
 #ifdef HDLZ_PAR_SPEC32
-        if (sub > 1u) hipLaunchKernelGGL(k_par_spec<true>, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p);
-        else hipLaunchKernelGGL(k_par_spec<false>, dim3((nchunks + 1u) / 2u), dim3(64), 0, stream, p);
+        if (sub > 1u) hipLaunchKernelGGL(k_par_spec<true>, dim3((nchunks + 1u) / 2u, nstr), dim3(64), 0, stream, p);
+        else hipLaunchKernelGGL(k_par_spec<false>, dim3((nchunks + 1u) / 2u, nstr), dim3(64), 0, stream, p);
 #else
         Chains ch{reinterpret_cast<uint32_t*>(ws + o_rp), reinterpret_cast<uint32_t*>(ws + o_cp), ws + o_cx, reinterpret_cast<uint32_t*>(ws + o_cn),
                   ws + o_cmx, reinterpret_cast<uint32_t*>(ws + o_cmn)};
-        hipLaunchKernelGGL(k_par_head, dim3((nchunks + 2u * HEAD_WAVES - 1u) / (2u * HEAD_WAVES)), dim3(64 * HEAD_WAVES), 0, stream, p, ch);
-        hipLaunchKernelGGL(k_par_tail, dim3((nchunks * 32u + 63u) / 64u), dim3(64), 0, stream, p, ch);
-        hipLaunchKernelGGL(k_par_resolve, dim3((nchunks * 32u + 255u) / 256u), dim3(256), 0, stream, p, ch);
+        hipLaunchKernelGGL(k_par_head, dim3((nchunks + 2u * HEAD_WAVES - 1u) / (2u * HEAD_WAVES), nstr), dim3(64 * HEAD_WAVES), 0, stream, p, ch);
+        hipLaunchKernelGGL(k_par_tail, dim3((nchunks * 32u + 63u) / 64u, nstr), dim3(64), 0, stream, p, ch);
+        hipLaunchKernelGGL(k_par_resolve, dim3((nchunks * 32u + 255u) / 256u, nstr), dim3(256), 0, stream, p, ch);
 #endif
-        hipLaunchKernelGGL(k_par_scan_groups, dim3(ngroups), dim3(64), 0, stream, p);
-        hipLaunchKernelGGL(k_par_scan_top, dim3(1), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(k_par_scan_pieces, dim3(ngroups), dim3(64), 0, stream, p, pf.entry8, pf.opos);
+        hipLaunchKernelGGL(k_par_scan_groups, dim3(ngroups, nstr), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(k_par_scan_top, dim3(1, nstr), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(k_par_scan_pieces, dim3(ngroups, nstr), dim3(64), 0, stream, p, pf.entry8, pf.opos);
         if (pf.chbits <= CH_BITS_MAX / 2u)
-            hipLaunchKernelGGL(k_par_tokens<true>, dim3((pf.nchunks + 63u) / 64u), dim3(64), 256u * (pf.chbits / 32u + 6u), stream, pf);
-        else hipLaunchKernelGGL(k_par_tokens<false>, dim3((pf.nchunks + 63u) / 64u), dim3(64), 0, stream, pf);
+            hipLaunchKernelGGL(k_par_tokens<true>, dim3((pf.nchunks + 63u) / 64u, nstr), dim3(64), 256u * (pf.chbits / 32u + 6u), stream, pf);
+        else hipLaunchKernelGGL(k_par_tokens<false>, dim3((pf.nchunks + 63u) / 64u, nstr), dim3(64), 0, stream, pf);
         ParArgs pe = p;                                                 // the emit: pieces, reading the sub-pieces' token lists
         pe.tokens = pf.tokens; pe.ntok = pf.ntok;
-        hipLaunchKernelGGL(k_par_emit, dim3(nchunks), dim3(64), 0, stream, pe);
-        for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(nchunks), dim3(64), 0, stream, p, j);
-        hipLaunchKernelGGL(k_par_finish, dim3(1), dim3(64), 0, stream, p, passes);
+        hipLaunchKernelGGL(k_par_emit, dim3(nchunks, nstr), dim3(64), 0, stream, pe);
+        for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(nchunks, nstr), dim3(64), 0, stream, p, j);
+        hipLaunchKernelGGL(k_par_finish, dim3(1, nstr), dim3(64), 0, stream, p, passes);
         e = hipGetLastError();
-        // the serial decoder returns at once when ctl[C_OK] >= 1
-        if (e == hipSuccess) e = launch_inflate_dyn(a, stream, true, p.ctl + C_OK, 1u);
+        // ONE stream: the serial decoder returns at once when ctl[C_OK] >= 1; several: it redoes the streams k_par_finish flagged
+        if (e == hipSuccess) e = nstr == 1u ? launch_inflate_dyn(a, stream, true, p.ctl + C_OK, 1u) : launch_inflate_dyn_flagged(a, stream);
         *used = true;
     }
     const hipError_t e2 = hipFreeAsync(ws, stream);

@@ -80,8 +80,12 @@ enum {
 /* a batch of ONE stream of at least this many bytes (fixed-pitch form, no mapping hint) is cut into 1 KiB pieces and decoded by
  * the whole GPU when it is a single fixed-Huffman block -- the streams STARTC writes --, else by one wave as before (decided on
  * the device, same results); scratch: stream-ordered, 4 bytes per possible output byte (min(out_pitch, 172 * in_len); 8 up to round 4).
- * A batch of a FEW such streams (fixed pitch, nstreams * 2 KiB <= in_len) goes through the same path stream by stream. */
+ * A batch of up to HDLZ_INFLATE_PAR_BATCH_MAX such streams (fixed pitch, no mapping hint) goes through the same path, every kernel
+ * launched ONCE for all of them (round 5; one chain of launches per stream before): the batch kernels decode a stream as one serial
+ * chain -- 5.9 ms for a 64 KiB stream however few there are -- so 256 streams of 64 KiB take 0.58 ms instead of 5.9, 256 of 1 MiB 6.4 ms
+ * instead of 42; from ~8192 streams on the batch kernels win (profiles/r05_inflate_mapping.txt).  Scratch as above, per stream. */
 #define HDLZ_INFLATE_PAR_MIN 16384u
+#define HDLZ_INFLATE_PAR_BATCH_MAX 4096u
 /* 16 lanes per stream (hdlz_inflate_grp.hip; round 5): the stream's history in a 2 KiB LDS ring, input and output in full lines, four
  * streams per wave -- the mapping for batches too small to fill the GPU one lane per stream and too large to give every stream a
  * wave: the default for HDLZ_INFLATE_GROUP_MIN <= nstreams <= HDLZ_INFLATE_GROUP_MAX (measured crossovers, tools/bench_inflate_mapping.py),
@@ -133,7 +137,7 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
  * mapping that pass runs in two stages, the second one for the few streams whose block codes more than 144
  * literal/length symbols, and keeps the list of its streams in stream-ordered scratch memory, hipMallocAsync /
  * hipFreeAsync on `stream`, 4 bytes per stream (if that allocation fails the wave mapping finishes the job); the
- * parallel path for ONE large stream or a few of them -- HDLZ_INFLATE_PAR_MIN below -- allocates 4 bytes per possible
+ * parallel path for ONE large stream or up to HDLZ_INFLATE_PAR_BATCH_MAX of them -- HDLZ_INFLATE_PAR_MIN below -- allocates 4 bytes per possible
  * output byte the same way, whatever the flags; no other case allocates, and every case stays capturable into a HIP
  * graph) blocks, 4 trailer bytes required
  * but Adler-32 not verified -- exactly the reference's acceptance (deflate.py:635-651 IDLE/STARTD,

@@ -185,3 +185,59 @@ def test_runs_and_short_periods_at_64_mib(engine):
         assert dt < 0.25, (name, dt)            # (1.6 ms measured; one wave: ~6 s)
         del d, out, back, zin
         torch.cuda.empty_cache()
+
+
+def test_many_large_streams_one_launch_chain_mixed_outcomes(engine, oracle):
+    """Round 5: several large fixed-pitch streams go through k_par_* TOGETHER (blockIdx.y = the stream), and the streams that path gives
+    up on are flagged for the serial decoder.  A batch that mixes everything: our own streams of different lengths in rows of one pitch,
+    stock-zlib single fixed blocks with far history, a dynamic-tree stream, a multi-block stream, a cut stream, a damaged one, all zeros
+    (markers everywhere) -- status, length and bytes of EVERY stream against the oracle, under the default flags and the reference's
+    build variants (DYNAMIC=False / ONEBLOCK / an OBSIZE), and the batch must not take longer than a few serial streams would."""
+    import torch
+    rng = np.random.default_rng(11)
+    zs = []
+    for k, n in enumerate((200000, 90000, 150000, 40000, 260000)):
+        data = _text(n, 20 + k) if k % 2 else bytes(rng.integers(0, 8, n, dtype=np.uint8) + 65)
+        d = torch.frombuffer(bytearray(data + bytes(64)), dtype=torch.uint8).cuda()
+        out, ol, st = engine.compress_stream(d, len(data), cwindow=256 if k == 2 else 32)
+        assert int(st.item()) == 0
+        zs.append(out[:int(ol.item())].cpu().numpy().tobytes())
+    d = torch.zeros(300000 + 64, dtype=torch.uint8, device="cuda")
+    out, ol, st = engine.compress_stream(d, 300000)
+    zs.append(out[:int(ol.item())].cpu().numpy().tobytes())                                    # every byte a marker
+    zs.append(_zfixed(_text(140000, 31), level=9))                                             # one fixed block, distances up to 32 KiB
+    zs.append(zlib.compress(_text(120000, 32), 6))                                             # dynamic trees: serial
+    zs.append(_zfixed(_text(400000, 33)))                                                      # several fixed blocks: serial
+    zs.append(zs[0][: len(zs[0]) // 2])                                                        # cut: NO EOF from the serial decoder
+    bad = bytearray(zs[1]); bad[len(bad) // 3] ^= 0x10; zs.append(bytes(bad))                  # damaged
+    zs.append(zlib.compress(bytes(rng.integers(0, 256, 50000, dtype=np.uint8)), 0))            # stored blocks
+    pitch = (max(len(z) for z in zs) + 64 + 15) // 16 * 16
+    assert min(len(z) for z in zs) >= 16384
+    host = np.zeros((len(zs), pitch), np.uint8)
+    for k, z in enumerate(zs):
+        host[k, : len(z)] = np.frombuffer(z, np.uint8)
+    zin = torch.from_numpy(host).cuda()
+    cap = 420000
+    for flags, obsize in ((0, 0), (1, 0), (8, 0), (0, 4096), (9, 32768)):
+        # (fixed pitch: a stream's length is the pitch -- the zero padding behind its end is part of what the decoder is given)
+        back, bl, bs = engine.inflate_batch(zin, out_pitch=cap, flags=flags, obsize=obsize)
+        torch.cuda.synchronize()
+        hb, hl, hs = back.cpu().numpy(), bl.cpu().numpy(), bs.cpu().numpy()
+        for k, z in enumerate(zs):
+            rc, ref = oracle.inflate(host[k].tobytes(), out_cap=cap, flags=flags, obsize=obsize)
+            assert hs[k] == rc, (k, flags, obsize, hs[k], rc)
+            assert hb[k, : hl[k]].tobytes() == ref, (k, flags, obsize)
+    # the path was taken: the good streams alone, eight times over, cost far less than eight serial decodes of the longest
+    good = torch.from_numpy(np.tile(host[:7], (8, 1))).cuda()
+    t_par, t_wave = _timed_batch(engine, good, cap, 0), _timed_batch(engine, good, cap, 4)
+    assert t_par * 3 < t_wave, (t_par, t_wave)
+
+
+def _timed_batch(engine, zin, cap, flags):
+    import torch
+    engine.inflate_batch(zin, out_pitch=cap, flags=flags)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    engine.inflate_batch(zin, out_pitch=cap, flags=flags)
+    torch.cuda.synchronize()
+    return time.time() - t0

@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
-"""hdlz_inflate_batch on a FEW LARGE streams (fixed pitch): when is one k_par_* chain per stream, one after the other, faster than the
-batch kernels (every stream a serial chain)?  A/B of the threshold with HDLZ_LIB=... variants built with -DHDLZ_PAR_FEW_BYTES=n."""
+"""hdlz_inflate_batch on a FEW LARGE streams (fixed pitch): the whole-GPU path over all of them (k_par_*, blockIdx.y = the stream) against the
+batch kernels (every stream a serial chain).  SHAPES=512x16,2048x64 (streams x KiB) overrides the list; the limit of the path:
+HDLZ_LIB=... variants built with -DHDLZ_PAR_BATCH_MAX=n."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from hdl_deflate_amd import Engine
 from hdl_deflate_amd.data import make_blocks
 e = Engine()
-for nb, kib in ((16, 64), (32, 64), (64, 64), (128, 64), (256, 64), (64, 256), (256, 256), (512, 256), (1024, 256), (256, 1024), (1024, 1024)):
+SHAPES = [tuple(int(v) for v in x.split('x')) for x in os.environ['SHAPES'].split(',')] if os.environ.get('SHAPES') else None
+for nb, kib in SHAPES or ((16, 64), (32, 64), (64, 64), (128, 64), (256, 64), (64, 256), (256, 256), (512, 256), (1024, 256), (256, 1024), (1024, 1024)):
     n = kib << 10
     d = make_blocks(nb * (n // 2048), 2048, "cuda", seed=2).reshape(nb, n)
     zo, zl, st = e.compress_batch(d)
     assert int(st.max().item()) == 0
     res = []
-    for label, fl in (("auto", 0), ("wave", 4), ("group", 64)):
+    for label, fl in (("auto", 0), ("lane", 2), ("wave", 4), ("group", 64)):
         f = lambda: e.inflate_batch(zo, out_pitch=n, flags=fl)
         back, bl, bs = f(); torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
