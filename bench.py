@@ -400,6 +400,7 @@ def main_single(a):
         # -- the reference's own use: ONE stream at a time.  STARTC then STARTD on one 16 MiB stream (the most a port with LMAX = 24
         #    holds), each on the whole GPU (k_stream_*, k_par_*)
         sec.append(bench_single_stream(torch, eng, dev, a))
+        sec.append(bench_few_large(torch, eng, dev, a))
         res["secondary"] = sec
     print(json.dumps(res), flush=True)
 
@@ -472,6 +473,42 @@ def bench_single_stream(torch, eng, dev, a, n=1 << 24):
             "compress_roofline": roofline("k_stream_* (STARTC: all kernels of hdlz_compress_stream)", algo, kc, "k_stream|stream=%d" % n),
             "note": "one wave (every single stream before hdlz_inflate_par.hip): 9 MB/s; timed with HIP events around whole calls "
                     "(all kernels of the path)"}
+
+
+def bench_few_large(torch, eng, dev, a, nstreams=256, n=1 << 20, with_wave=True):
+    """a FEW LARGE streams in one hdlz_inflate_batch call (fixed pitch): the whole-GPU path over all of them (k_par_*, blockIdx.y = the
+    stream) -- the batch kernels decode a stream as one serial chain, so such a batch ran at one stream's latency (flag 4: the wave mapping)"""
+    from hdl_deflate_amd.data import make_blocks
+    d = make_blocks(nstreams * (n // 2048), 2048, dev, seed=6).reshape(nstreams, n)
+    zo, zl, st = eng.compress_batch(d, cwindow=32, maxmatch=10)
+    assert int(st.max().item()) == 0
+    zsum = int(zl.sum().item())
+    back = torch.empty((nstreams, n), dtype=torch.uint8, device=dev)
+
+    def step():
+        return eng.inflate_batch(zo, out_pitch=n, out=back)
+
+    def step_wave():
+        return eng.inflate_batch(zo, out_pitch=n, out=back, flags=4)
+
+    _, bl, bs = step()
+    torch.cuda.synchronize()
+    assert int(bs.max().item()) == 0 and int(bl.min().item()) == n and torch.equal(back, d), "few-large-streams round trip failed"
+    kd = kernel_ms(torch, step, max(3, a.steps))
+    kw = kernel_ms(torch, step_wave, 2) if with_wave else [0.0]      # (profiling runs leave it out: its kernel is part of the path's family)
+    ms_d = sum(kd) / len(kd)
+    total = nstreams * n
+    algo = total + zsum + 4 * nstreams
+    return {"name": "%d streams of 1 MiB" % nstreams, "metric": "inflate_output_throughput (a few large streams, one call)",
+            "value": round(total / ms_d / 1e3, 1), "unit": "MB/s", "ms_per_step": round(ms_d, 4), "higher_is_better": True,
+            "config": {"workload": "%d own streams of %d bytes (families 1-4, CWINDOW=32, MATCH10) in rows of one pitch: hdlz_inflate_batch, "
+                                   "no mapping hint, round trip checked" % (nstreams, n), "streams": nstreams, "stream_bytes": n,
+                       "compressed_bytes": zsum},
+            "wave_per_stream_ms": round(sum(kw) / len(kw), 3),
+            "roofline": roofline("k_par_* (STARTD: all kernels of hdlz_inflate_batch, %d streams)" % nstreams, algo, kd,
+                                 "k_par|streams=%d|stream=%d" % (nstreams, n)),
+            "note": "every kernel of the single-stream path launched once for all streams (blockIdx.y = the stream); timed with HIP events "
+                    "around whole calls; wave_per_stream_ms: the same batch through k_inflate_dyn (flag 4), what it cost before round 5"}
 
 
 # ------------------------------------------------------------------------------------------------ N > 1
@@ -820,7 +857,7 @@ def main():
                          "(exercises the second pass k_inflate_tok<true> / k_inflate_dyn, SURVEY 8(f) rank 1)")
     ap.add_argument("--inflate-kernel", default="default", choices=["default", "token", "byte", "group"],
                     help="inflate: lane-per-stream kernel variant (token = k_inflate_tok, byte = k_inflate)")
-    ap.add_argument("--mode", default="compress", choices=["compress", "inflate", "roundtrip", "single"],
+    ap.add_argument("--mode", default="compress", choices=["compress", "inflate", "roundtrip", "single", "few"],
                     help="compress = BASELINE metric (default); inflate = only the configs[3] side metric (1 GPU)")
     ap.add_argument("--no-archive", dest="archive", action="store_false",
                     help="N=1: skip the archive figure (compress + scan + hdlz_compact_batch) of the headline job")
@@ -845,6 +882,11 @@ def main():
         import hdl_deflate_amd
         torch.cuda.set_device(0)
         print(json.dumps(bench_single_stream(torch, hdl_deflate_amd.Engine(torch.device("cuda", 0)), torch.device("cuda", 0), a)), flush=True)
+    elif a.mode == "few":                                     # only the few-large-streams entry (profiling)
+        import torch
+        import hdl_deflate_amd
+        torch.cuda.set_device(0)
+        print(json.dumps(bench_few_large(torch, hdl_deflate_amd.Engine(torch.device("cuda", 0)), torch.device("cuda", 0), a, with_wave=False)), flush=True)
     elif a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
     elif a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:

@@ -83,8 +83,10 @@ struct ParArgs {
     size_t ws_stride;
     uint32_t batch;             // != 0: a stream the path gives up on is FLAGGED for the serial pass (status HDLZ_E_DYNAMIC_UNSUPPORTED)
 };
+// (pointer arithmetic, NOT a round trip through an integer: that makes the pointer generic and every access through it a flat_load /
+//  flat_store, which waits on the LDS counter as well -- k_par_emit ran 7.7 ms instead of 0.15 that way)
 template <typename T> __device__ __forceinline__ void shift_ptr(T*& p, size_t bytes) {
-    p = reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + bytes);
+    p = reinterpret_cast<T*>(reinterpret_cast<uint8_t*>(p) + bytes);
 }
 // the arguments of stream blockIdx.y: every kernel below works on ONE stream and never looks at another one's arrays
 __device__ __forceinline__ ParArgs of_stream(ParArgs a) {
@@ -832,7 +834,30 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                  o_cn = take((size_t)nchunks * 128u), o_cmx = take((size_t)nchunks * 32u * (sub - 1u)), o_cmn = take((size_t)nchunks * 128u * (sub - 1u));
     uint8_t* ws = nullptr;
     const size_t stride = off;                                  // (a multiple of 256: every stream's arrays are aligned like the first one's)
-    if (nstr > 1u && stride * (size_t)nstr > ((size_t)16 << 30)) return hipSuccess;      // (more than 16 GiB of scratch: the batch kernels)
+    // more than 4 GiB of scratch: the batch goes through in groups of streams, one chain of launches each (a group of that size fills the
+    // GPU as well; its scratch is the one the group in front of it gave back, stream-ordered)
+    constexpr size_t BUDGET = (size_t)4 << 30;
+    if (nstr > 1u && stride * (size_t)nstr > BUDGET) {
+        const uint32_t gs = (uint32_t)(BUDGET / stride);
+        if (gs == 0u) return hipSuccess;                        // (cannot happen: one stream's scratch is below 4 GiB + its pieces)
+        if (gs < nstr) {
+            for (uint32_t s0 = 0; s0 < nstr; s0 += gs) {
+                InflateArgs g = a;
+                g.in = a.in + (uint64_t)s0 * a.in_pitch;
+                g.out = a.out + (uint64_t)s0 * a.out_pitch;
+                g.out_len = a.out_len + s0;
+                g.status = a.status + s0;
+                g.nstreams = nstr - s0 < gs ? nstr - s0 : gs;
+                bool u = false;
+                const hipError_t eg = launch_inflate_par(g, stream, &u);
+                if (eg != hipSuccess) return eg;
+                // (a group without scratch: the caller's batch kernels redo the whole batch, which is harmless)
+                if (!u) return hipSuccess;
+            }
+            *used = true;
+            return hipSuccess;
+        }
+    }
     hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), stride * nstr, stream);
     if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // no scratch: the caller goes on with the serial decoder
     {

@@ -82,8 +82,8 @@ enum {
  * the device, same results); scratch: stream-ordered, 4 bytes per possible output byte (min(out_pitch, 172 * in_len); 8 up to round 4).
  * A batch of up to HDLZ_INFLATE_PAR_BATCH_MAX such streams (fixed pitch, no mapping hint) goes through the same path, every kernel
  * launched ONCE for all of them (round 5; one chain of launches per stream before): the batch kernels decode a stream as one serial
- * chain -- 5.9 ms for a 64 KiB stream however few there are -- so 256 streams of 64 KiB take 0.58 ms instead of 5.9, 256 of 1 MiB 6.4 ms
- * instead of 42; from ~8192 streams on the batch kernels win (profiles/r05_inflate_mapping.txt).  Scratch as above, per stream. */
+ * chain -- 5.9 ms for a 64 KiB stream however few there are -- so 256 streams of 64 KiB take 0.48 ms instead of 5.9, 256 of 1 MiB 4.4 ms
+ * instead of 42; from ~8192 streams on the batch kernels win (profiles/r05_inflate_mapping.txt).  Scratch as above, per stream (more than 4 GiB: the batch goes through in groups of streams). */
 #define HDLZ_INFLATE_PAR_MIN 16384u
 #define HDLZ_INFLATE_PAR_BATCH_MAX 4096u
 /* 16 lanes per stream (hdlz_inflate_grp.hip; round 5): the stream's history in a 2 KiB LDS ring, input and output in full lines, four

@@ -25,6 +25,7 @@ bash tools/profile_inflate.sh ev_rt --mode roundtrip > "$out/pmc_roundtrip.txt" 
 bash tools/profile_inflate.sh ev_grp --inflate-kernel group --streams 262144 > "$out/pmc_inflate_grp.txt" 2>&1
 bash tools/profile_mem.sh ev_grp_mem --inflate-kernel group --streams 262144 >> "$out/pmc_inflate_grp.txt" 2>&1
 bash tools/prof_single.sh ev_single > "$out/pmc_single.txt" 2>&1
+PROF_MODE=few bash tools/prof_single.sh ev_few > "$out/pmc_few.txt" 2>&1
 # 2b. the tile timing build of the headline kernel (built here if it did not travel: hipcc is on the GPU box too)
 [ -f hdl_deflate_amd/lib/libhdlz_tiletime.so ] || HDLZ_VARIANT=tiletime HDLZ_DEFS="-DHDLZ_TILE_TIMING" HDLZ_ONLY="hdlz_compress" bash hdl_deflate_amd/csrc/build.sh > /dev/null 2>&1
 # (wave time per phase + the clock of the cycle counter under this load)

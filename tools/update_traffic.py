@@ -88,6 +88,29 @@ for fn, key, kern, tag, mixsrc in SPEC:
         e["note"] += "; TCC_EA0_RDREQ / WRREQ = the 64-byte requests that left the L2 (the far history of the copies: one sector per token)"
     T[key] = e
     print(key, e["traffic_bytes"], "grid", e["grid"], "valu", e["valu_insts"])
+# a few large streams in one call (PROF_MODE=few tools/prof_single.sh: the k_par_* family summed over the kernels of one call)
+p = os.path.join(root, "pmc_few.txt")
+if os.path.exists(p):
+    txt = "\n".join(l for l in open(p).read().splitlines() if "amdgpu.ids" not in l) + "\n"
+    dest = "profiles/%s_few_large_pmc_summary.txt" % RND
+    open(os.path.join(REPO, dest), "w").write("# rocprofv3 evidence (PROF_MODE=few tools/prof_single.sh): 256 own streams of 1 MiB through ONE hdlz_inflate_batch call (k_par_*, blockIdx.y = the stream, "
+                                              "+ the launch that redoes flagged streams), every counter SUMMED over the kernels of one call; the k_stream family here is the setup's compress_batch; libhdlz 0x%06x\n" % VERSION + txt)
+    vals, cur = {}, None
+    for ln in txt.splitlines():
+        m = re.match(r"\s*family (\w+)\s*$", ln)
+        if m:
+            cur = m.group(1)
+        m = re.search(r"(\w+)\s+n=\d+ mean=([0-9.e+]+)", ln)
+        if m and cur == "k_par":
+            vals[m.group(1)] = float(m.group(2))
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        key = "k_par|streams=256|stream=1048576"
+        T[key] = {"traffic_bytes": int(vals["FETCH_SIZE"] * 2 * 1024 + vals["WRITE_SIZE"] * 1024), "source": dest,
+                  "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+                  "kernel": "k_par_* (STARTD: all kernels of hdlz_inflate_batch, 256 streams)", "grid": None,
+                  "hdlz_version": VERSION, "valu_insts": vals.get("SQ_INSTS_VALU"), "salu_insts": vals.get("SQ_INSTS_SALU"),
+                  "note": "round 5: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, summed over the kernels of one call"}
+        print(key, T[key]["traffic_bytes"])
 # the one-stream paths (tools/prof_single.sh: counters summed over the kernels of one call)
 p = os.path.join(root, "pmc_single.txt")
 if os.path.exists(p):
