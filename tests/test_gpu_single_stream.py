@@ -158,6 +158,27 @@ def test_single_stream_inside_a_hip_graph(engine, oracle):
     torch.cuda.synchronize()
     assert int(bs.item()) == 0 and int(bl.item()) == 400000
     assert back[0, :400000].cpu().numpy().tobytes() == zlib.decompress(z)
+    # ... and three such streams in one captured call (the same kernels, blockIdx.y = the stream; one of them a dynamic stream: flagged
+    # and redone by the serial pass inside the graph)
+    z3 = [z, zlib.compress(_text(300000, 13), 6), _zfixed(_text(350000, 14))]
+    pitch = (max(len(x) for x in z3) + 64 + 15) // 16 * 16
+    host = np.zeros((3, pitch), np.uint8)
+    for k, x in enumerate(z3):
+        host[k, : len(x)] = np.frombuffer(x, np.uint8)
+    zin3 = torch.from_numpy(host).cuda()
+    back3 = torch.empty((3, 400064), dtype=torch.uint8, device="cuda")
+    engine.inflate_batch(zin3, out_pitch=400064, out=back3)
+    torch.cuda.synchronize()
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g3, stream=s):
+            _, bl3, bs3 = engine.inflate_batch(zin3, out_pitch=400064, out=back3)
+    back3.zero_()
+    g3.replay()
+    torch.cuda.synchronize()
+    for k, x in enumerate(z3):
+        want = zlib.decompress(x)
+        assert int(bs3[k].item()) == 0 and int(bl3[k].item()) == len(want) and back3[k, : len(want)].cpu().numpy().tobytes() == want, k
 
 
 def test_runs_and_short_periods_at_64_mib(engine):
