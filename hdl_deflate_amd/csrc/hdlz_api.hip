@@ -149,6 +149,9 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
     return HDLZ_OK;
 }
 
+#ifndef HDLZ_PAR_BATCH_SHORT_MAX
+#define HDLZ_PAR_BATCH_SHORT_MAX HDLZ_INFLATE_PAR_BATCH_SHORT_MAX
+#endif
 #ifndef HDLZ_PAR_BATCH_MAX
 #define HDLZ_PAR_BATCH_MAX HDLZ_INFLATE_PAR_BATCH_MAX      // (A/B builds override it: tools/bench_few_large_inflate.py)
 #endif
@@ -197,8 +200,9 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     // a FEW large streams (fixed pitch): the same path with every kernel launched once for all of them (blockIdx.y = the stream; round 5 --
     // up to round 4 one chain of launches per stream, 0.125 ms each).  The batch kernels decode a stream as ONE serial chain (64 KiB:
     // 5.9 ms, 1 MiB: 94 ms, however few there are); this path costs the launch chain once plus the streams' bytes at the rate of the
-    // single-stream path (profiles/r05_inflate_mapping.txt).
-    if (nstreams > 1 && nstreams <= HDLZ_PAR_BATCH_MAX && !d_in_off && in_len >= HDLZ_INFLATE_PAR_MIN &&
+    // single-stream path (profiles/r05_inflate_mapping.txt).  Streams below HDLZ_INFLATE_PAR_LONG bytes: up to HDLZ_INFLATE_PAR_BATCH_SHORT_MAX of them
+    // (1024 x 2 KiB: 0.21 ms against 0.33; from 2048 on the wave mapping is as fast).  A batch of dynamic-tree streams pays ~0.05 ms for asking.
+    if (nstreams > 1 && nstreams <= (in_len >= HDLZ_INFLATE_PAR_LONG ? HDLZ_PAR_BATCH_MAX : HDLZ_PAR_BATCH_SHORT_MAX) && !d_in_off && in_len >= HDLZ_INFLATE_PAR_MIN &&
         !(flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_GROUP_PER_STREAM))) {
         bool used = false;
         hipError_t e = hdlz::launch_inflate_par(a, st, &used);

@@ -121,6 +121,16 @@ __device__ __forceinline__ uint64_t bits_at(const uint32_t* win, uint32_t b_c, u
     return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
 }
 
+// the stream must be one fixed block (or be read as one: the DYNAMIC=False / ONEBLOCK builds).  k_par_scan_top gives the verdict (the
+// fallback flag); the kernels in front of it only SKIP such a stream -- a batch of small dynamic-tree streams must not pay a speculative
+// fixed-Huffman decode of every stream before the serial pass takes them
+__device__ __forceinline__ bool one_fixed_block(const ParArgs& a) {
+    const uint32_t hdr = a.zn >= 5u ? (uint32_t)a.z[2] : 0u;
+    const bool fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) || ((hdr >> 1) & 3u) == 1u;
+    const bool last = (a.flags & HDLZ_INFLATE_ONEBLOCK) || (hdr & 1u);
+    return a.zn >= 5u && fixed && last;
+}
+
 // ---- 1. speculative decode: lane (piece, offset)
 template <bool SUBMAPS>
 __global__ __launch_bounds__(64) void k_par_spec(ParArgs a_) {
@@ -244,6 +254,7 @@ constexpr uint32_t HEAD_WAVES = 8;            // waves per workgroup of k_par_he
 __global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a_, Chains ch_) {
     const ParArgs a = of_stream(a_);
     const Chains ch = of_stream(ch_, a_.ws_stride);
+    if (!one_fixed_block(a)) return;
     __shared__ uint32_t lit[512], dst[32], win[HEAD_WAVES][2][HEAD_BITS / 32 + 8], first[HEAD_WAVES][2][32], slotof[HEAD_WAVES][2][32];
     __shared__ uint32_t wcount[HEAD_WAVES], wbase[HEAD_WAVES];
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u, half = lane >> 5, e = lane & 31u;
@@ -302,6 +313,7 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a_, Chains
 __global__ __launch_bounds__(64) void k_par_tail(ParArgs a_, Chains ch_) {
     const ParArgs a = of_stream(a_);
     const Chains ch = of_stream(ch_, a_.ws_stride);
+    if (!one_fixed_block(a)) return;
     __shared__ uint32_t lit[512], dst[32];
     const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
     const uint32_t nchain = a.ctl[C_NCHAIN];
@@ -340,6 +352,7 @@ __global__ __launch_bounds__(64) void k_par_tail(ParArgs a_, Chains ch_) {
 __global__ __launch_bounds__(256) void k_par_resolve(ParArgs a_, Chains ch_) {
     const ParArgs a = of_stream(a_);
     const Chains ch = of_stream(ch_, a_.ws_stride);
+    if (!one_fixed_block(a)) return;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= a.nchunks * 32u) return;
     const uint32_t r = ch.rep[t];
@@ -373,6 +386,7 @@ __device__ __forceinline__ uint32_t stage_group(GroupLds& L, const ParArgs& a, u
 }
 __global__ __launch_bounds__(64) void k_par_scan_groups(ParArgs a_) {
     const ParArgs a = of_stream(a_);
+    if (!one_fixed_block(a)) return;
     __shared__ GroupLds L;
     const uint32_t lane = threadIdx.x, g = blockIdx.x;
     const uint32_t cnt = stage_group(L, a, g, lane);
@@ -400,10 +414,7 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a_) {
     __shared__ uint8_t pathb[8][32][8], segmap[8][32], segstop[8][32], segent[8];
     const uint32_t lane = threadIdx.x;                     // (256 threads: staging, and 8 segments x 32 entry offsets for the walk)
     // the stream must be one fixed block (or be read as one: the DYNAMIC=False / ONEBLOCK builds)
-    const uint32_t hdr = a.zn >= 5u ? (uint32_t)a.z[2] : 0u;
-    const bool fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) || ((hdr >> 1) & 3u) == 1u;
-    const bool last = (a.flags & HDLZ_INFLATE_ONEBLOCK) || (hdr & 1u);
-    if (a.zn < 5u || !fixed || !last) { if (lane == 0u) a.ctl[C_FALLBACK] = 1u; return; }
+    if (!one_fixed_block(a)) { if (lane == 0u) a.ctl[C_FALLBACK] = 1u; return; }
     const uint32_t ngroups = (a.nchunks + GROUP - 1u) / GROUP;
     if (lane == 0u) { sh_stop = 0; sh_e = 0; sh_bad = 0; sh_nused = 0; sh_acc = 0; }
     __syncthreads();

@@ -83,9 +83,16 @@ enum {
  * A batch of up to HDLZ_INFLATE_PAR_BATCH_MAX such streams (fixed pitch, no mapping hint) goes through the same path, every kernel
  * launched ONCE for all of them (round 5; one chain of launches per stream before): the batch kernels decode a stream as one serial
  * chain -- 5.9 ms for a 64 KiB stream however few there are -- so 256 streams of 64 KiB take 0.48 ms instead of 5.9, 256 of 1 MiB 4.4 ms
- * instead of 42; from ~8192 streams on the batch kernels win (profiles/r05_inflate_mapping.txt).  Scratch as above, per stream (more than 4 GiB: the batch goes through in groups of streams). */
-#define HDLZ_INFLATE_PAR_MIN 16384u
+ * instead of 42; from ~8192 streams on the batch kernels win (profiles/r05_inflate_mapping.txt).  Scratch as above, per stream (more than 4 GiB: the batch goes through in groups of streams).
+ * Streams shorter than HDLZ_INFLATE_PAR_LONG take the path in batches of up to HDLZ_INFLATE_PAR_BATCH_SHORT_MAX (the chain of launches costs
+ * ~0.12 ms: one 8 KiB stream 0.12 instead of 0.75 ms, 1024 streams of 2 KiB 0.21 instead of 0.33 ms; 4096 of them: the wave mapping wins).
+ * (The threshold was 16384 up to the first builds of 0x000500: the path cost 0.35 ms then.) */
+#ifndef HDLZ_INFLATE_PAR_MIN          /* (A/B builds override it) */
+#define HDLZ_INFLATE_PAR_MIN 2048u
+#endif
+#define HDLZ_INFLATE_PAR_LONG 16384u
 #define HDLZ_INFLATE_PAR_BATCH_MAX 4096u
+#define HDLZ_INFLATE_PAR_BATCH_SHORT_MAX 1024u
 /* 16 lanes per stream (hdlz_inflate_grp.hip; round 5): the stream's history in a 2 KiB LDS ring, input and output in full lines, four
  * streams per wave -- the mapping for batches too small to fill the GPU one lane per stream and too large to give every stream a
  * wave: the default for HDLZ_INFLATE_GROUP_MIN <= nstreams <= HDLZ_INFLATE_GROUP_MAX (measured crossovers, tools/bench_inflate_mapping.py),
