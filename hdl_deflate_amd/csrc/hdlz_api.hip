@@ -164,7 +164,7 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
                   HDLZ_INFLATE_TOKEN_ROUNDS | HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_GROUP_PER_STREAM))
         return fail_param("unknown flag");
     // the kernels keep stream lengths and bit positions in 32 bits (8 * length must not wrap)
-    if (!d_in_off && in_len >= 0x10000000u) return fail_param("in_len too large (streams are limited to 256 MiB - 1)");
+    if (in_len >= 0x10000000u) return fail_param("in_len too large (streams are limited to 256 MiB - 1)");
     if (!d_in_off && nstreams > 1 && in_pitch < in_len) return fail_param("in_pitch < in_len");
     {
         const uint32_t mf = flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_GROUP_PER_STREAM);
@@ -190,7 +190,8 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
                                      (!(flags & HDLZ_INFLATE_LANE_PER_STREAM) && nstreams <= HDLZ_INFLATE_WAVE_THRESHOLD));
     // ONE large stream: cut into 1 KiB pieces and decoded by the whole GPU (hdlz_inflate_par.hip) when it is a single fixed block --
     // what STARTC writes --, by one wave otherwise (decided on the device); the explicit mapping hints keep the batch kernels
-    if (nstreams == 1 && !d_in_off && in_len >= HDLZ_INFLATE_PAR_MIN &&
+    // (ragged input: in_len is the caller's upper bound on the stream lengths, 0 = not stated -- then the batch kernels)
+    if (nstreams == 1 && in_len >= HDLZ_INFLATE_PAR_MIN &&
         !(flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_BYTE_LOCKSTEP))) {
         bool used = false;
         hipError_t e = hdlz::launch_inflate_par(a, st, &used);
@@ -202,7 +203,7 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     // 5.9 ms, 1 MiB: 94 ms, however few there are); this path costs the launch chain once plus the streams' bytes at the rate of the
     // single-stream path (profiles/r05_inflate_mapping.txt).  Streams below HDLZ_INFLATE_PAR_LONG bytes: up to HDLZ_INFLATE_PAR_BATCH_SHORT_MAX of them
     // (1024 x 2 KiB: 0.21 ms against 0.33; from 2048 on the wave mapping is as fast).  A batch of dynamic-tree streams pays ~0.05 ms for asking.
-    if (nstreams > 1 && nstreams <= (in_len >= HDLZ_INFLATE_PAR_LONG ? HDLZ_PAR_BATCH_MAX : HDLZ_PAR_BATCH_SHORT_MAX) && !d_in_off && in_len >= HDLZ_INFLATE_PAR_MIN &&
+    if (nstreams > 1 && nstreams <= (in_len >= HDLZ_INFLATE_PAR_LONG ? HDLZ_PAR_BATCH_MAX : HDLZ_PAR_BATCH_SHORT_MAX) && in_len >= HDLZ_INFLATE_PAR_MIN &&
         !(flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_GROUP_PER_STREAM))) {
         bool used = false;
         hipError_t e = hdlz::launch_inflate_par(a, st, &used);

@@ -80,6 +80,8 @@ struct ParArgs {
     // SEVERAL streams in the same launches (round 5): blockIdx.y is the stream; stream s reads z + s * in_pitch, writes out + s * out_pitch,
     // out_len[s], status[s], and owns the scratch ws_stride bytes behind stream s - 1's (every array above, same layout)
     uint64_t in_pitch, out_pitch;
+    const uint64_t* in_off;     // nullable.  Ragged input: stream s is z[in_off[s] .. in_off[s + 1]); zn is then the caller's BOUND on the lengths (the
+                                // pieces are laid out for it; bytes behind a stream's own end read as zero, like the padding of a pitched row)
     size_t ws_stride;
     uint32_t batch;             // != 0: a stream the path gives up on is FLAGGED for the serial pass (status HDLZ_E_DYNAMIC_UNSUPPORTED)
 };
@@ -91,8 +93,12 @@ template <typename T> __device__ __forceinline__ void shift_ptr(T*& p, size_t by
 // the arguments of stream blockIdx.y: every kernel below works on ONE stream and never looks at another one's arrays
 __device__ __forceinline__ ParArgs of_stream(ParArgs a) {
     const uint32_t s = blockIdx.y;
+    if (a.in_off) {
+        const uint64_t o0 = a.in_off[s], n64 = a.in_off[s + 1u] - o0;
+        a.z += o0;
+        a.zn = n64 > (uint64_t)a.zn ? 0xFFFFFFFFu : (uint32_t)n64;      // longer than the stated bound: one_fixed_block() sends it to the serial pass
+    } else a.z += (uint64_t)s * a.in_pitch;
     if (s == 0u) return a;
-    a.z += (uint64_t)s * a.in_pitch;
     a.out += (uint64_t)s * a.out_pitch;
     a.out_len += s;
     a.status += s;
@@ -125,10 +131,10 @@ __device__ __forceinline__ uint64_t bits_at(const uint32_t* win, uint32_t b_c, u
 // fallback flag); the kernels in front of it only SKIP such a stream -- a batch of small dynamic-tree streams must not pay a speculative
 // fixed-Huffman decode of every stream before the serial pass takes them
 __device__ __forceinline__ bool one_fixed_block(const ParArgs& a) {
-    const uint32_t hdr = a.zn >= 5u ? (uint32_t)a.z[2] : 0u;
+    const uint32_t hdr = (a.zn >= 5u && a.zn != 0xFFFFFFFFu) ? (uint32_t)a.z[2] : 0u;
     const bool fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) || ((hdr >> 1) & 3u) == 1u;
     const bool last = (a.flags & HDLZ_INFLATE_ONEBLOCK) || (hdr & 1u);
-    return a.zn >= 5u && fixed && last;
+    return a.zn >= 5u && a.zn != 0xFFFFFFFFu && fixed && last;
 }
 
 // ---- 1. speculative decode: lane (piece, offset)
@@ -854,7 +860,8 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         if (gs < nstr) {
             for (uint32_t s0 = 0; s0 < nstr; s0 += gs) {
                 InflateArgs g = a;
-                g.in = a.in + (uint64_t)s0 * a.in_pitch;
+                if (a.in_off) g.in_off = a.in_off + s0;
+                else g.in = a.in + (uint64_t)s0 * a.in_pitch;
                 g.out = a.out + (uint64_t)s0 * a.out_pitch;
                 g.out_len = a.out_len + s0;
                 g.status = a.status + s0;
@@ -878,7 +885,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                   reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_tk), reinterpret_cast<uint32_t*>(ws + o_nt),
                   reinterpret_cast<uint32_t*>(ws + o_sa), sub, ws + o_mx,
                   reinterpret_cast<uint32_t*>(ws + o_mn), (uint32_t)C_NUSED, reinterpret_cast<uint32_t*>(ws + o_me),
-                  a.in_pitch, a.out_pitch, stride, nstr > 1u ? 1u : 0u};
+                  a.in_pitch, a.out_pitch, a.in_off, stride, nstr > 1u ? 1u : 0u};
         hipLaunchKernelGGL(k_par_zero, dim3(1, nstr), dim3(64), 0, stream, p);
         // the same arguments at sub-piece granularity: what the real decode and the emit work on
         ParArgs pf = p;

@@ -47,7 +47,7 @@ class Engine(object):
         if in_off is not None:
             assert in_off.is_cuda and in_off.dtype == torch.int64 and in_off.is_contiguous()
             nb = in_off.numel() - 1
-            return in_off.data_ptr(), 0, 0, nb
+            return in_off.data_ptr(), 0, (0 if in_len is None else in_len), nb
         assert d_in.dim() == 2 or nblocks is not None
         if d_in.dim() == 2:
             nb, pitch = d_in.shape
@@ -118,6 +118,10 @@ class Engine(object):
     @_on_device
     def inflate_batch(self, d_in, in_off=None, in_len=None, nblocks=None, out_pitch=None, flags=0, obsize=0,
                       out=None):
+        """STARTD for a batch: d_in uint8 [B, pitch] (a stream per row, `in_len` bytes of it: default the pitch) or flat uint8 with in_off
+        int64[B + 1] -- then `in_len`, if given, is an UPPER BOUND on the stream lengths: with it a batch of up to 4096 streams (1024
+        below 16 KiB) can take the whole-GPU path (a stream longer than the bound is still decoded, by the serial pass).
+        -> (out uint8[B, out_pitch], out_len int32[B], status int32[B]); per-stream failures are statuses."""
         off_ptr, pitch, ilen, nb = self._prep(d_in, in_off, in_len, nblocks)
         assert out_pitch is not None and out_pitch % 4 == 0
         if out is None:

@@ -248,6 +248,19 @@ def test_many_large_streams_one_launch_chain_mixed_outcomes(engine, oracle):
             rc, ref = oracle.inflate(host[k].tobytes(), out_cap=cap, flags=flags, obsize=obsize)
             assert hs[k] == rc, (k, flags, obsize, hs[k], rc)
             assert hb[k, : hl[k]].tobytes() == ref, (k, flags, obsize)
+    # the same streams RAGGED (exact lengths, back to back -- an archive): with the caller's bound on the lengths in in_len the batch takes
+    # the same path; a bound that is too small for some streams sends those to the serial pass; no bound: the batch kernels.  Same answers.
+    flat = torch.from_numpy(np.frombuffer(b"".join(zs) + bytes(64), np.uint8).copy()).cuda()
+    offs = torch.from_numpy(np.concatenate([[0], np.cumsum([len(z) for z in zs])]).astype(np.int64)).cuda()
+    for bound in (max(len(z) for z in zs), 100000, None):
+        for flags, obsize in ((0, 0), (9, 32768)):
+            back, bl, bs = engine.inflate_batch(flat, in_off=offs, in_len=bound, out_pitch=cap, flags=flags, obsize=obsize)
+            torch.cuda.synchronize()
+            hb, hl, hs = back.cpu().numpy(), bl.cpu().numpy(), bs.cpu().numpy()
+            for k, z in enumerate(zs):
+                rc, ref = oracle.inflate(z, out_cap=cap, flags=flags, obsize=obsize)
+                assert hs[k] == rc, (k, bound, flags, hs[k], rc)
+                assert hb[k, : hl[k]].tobytes() == ref, (k, bound, flags)
     # the path was taken: the good streams alone, eight times over, cost far less than eight serial decodes of the longest
     good = torch.from_numpy(np.tile(host[:7], (8, 1))).cuda()
     t_par, t_wave = _timed_batch(engine, good, cap, 0), _timed_batch(engine, good, cap, 4)

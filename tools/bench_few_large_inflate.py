@@ -24,8 +24,12 @@ for nb, kib in SHAPES or ((16, 64), (32, 64), (64, 64), (128, 64), (256, 64), (6
         zo, zl, st = e.compress_batch(d)
         assert int(st.max().item()) == 0
     res = []
+    ragged = os.environ.get("RAGGED") and not os.environ.get("ZLIB")      # the streams back to back (an archive) + the caller's bound on their lengths
+    if ragged:
+        arc, aoff = e.archive(zo, zl)
+        bound = zo.shape[1]
     for label, fl in (("auto", 0), ("lane", 2), ("wave", 4), ("group", 64)):
-        f = lambda: e.inflate_batch(zo, out_pitch=n, flags=fl)
+        f = (lambda: e.inflate_batch(arc, in_off=aoff, in_len=bound, out_pitch=n, flags=fl)) if ragged else (lambda: e.inflate_batch(zo, out_pitch=n, flags=fl))
         back, bl, bs = f(); torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()

@@ -79,7 +79,8 @@ def main():
                 return 1
             if (hs == 0).all() and B >= 1:          # ... and inflated straight from it (ragged input = the archive's offsets)
                 capa = (int(lens.max()) + 15) // 16 * 16 + 16
-                ab, abl, abs_ = eng.inflate_batch(arc, in_off=aoff, out_pitch=capa, flags=int(rng.choice([0, 2, 4, 34, 64])))
+                ab, abl, abs_ = eng.inflate_batch(arc, in_off=aoff, out_pitch=capa, flags=int(rng.choice([0, 0, 2, 4, 34, 64])),
+                                                  in_len=[None, int(hl.max()), max(1, int(hl.max()) // 2)][int(rng.integers(0, 3))])   # (the caller's bound on the lengths: none / right / too small)
                 torch.cuda.synchronize()
                 hb, hbl, hbs = ab.cpu().numpy(), abl.cpu().numpy(), abs_.cpu().numpy()
                 for b in range(min(B, 2000)):
@@ -120,7 +121,7 @@ def main():
             ob_ = int(rng.choice([0, 0, 512, 4096, 32768]))
             capd = (int(lens[selb].max()) + 300 + 15) // 16 * 16
             zb, zl, zst = eng.inflate_batch(torch.from_numpy(zflat).cuda(), in_off=torch.from_numpy(zoff).cuda(), out_pitch=capd, flags=fl_,
-                                            obsize=ob_)
+                                            obsize=ob_, in_len=[None, max(len(z) for z in zd), 64][int(rng.integers(0, 3))])
             torch.cuda.synchronize()
             hb, hbl, hbs = zb.cpu().numpy(), zl.cpu().numpy(), zst.cpu().numpy()
             for k, z in enumerate(zd):
