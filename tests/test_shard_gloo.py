@@ -89,6 +89,7 @@ def _worker(rank, world, port, nblocks, q):
         # payload gather of the per-rank archives (8(f) rank 2): concatenation = the global archive
         mine = torch.frombuffer(bytearray(b"".join(O.compress(x)[1] for x in blocks)), dtype=torch.uint8)
         whole = gather_archive(mine, mine.numel())
+        dist.barrier()                   # nobody tears the process group (rank 0: the store) down while another rank is still at work
         q.put((rank, all_len.tolist(), offs.tolist(), total, bytes(whole.numpy().tobytes())))
     finally:
         dist.destroy_process_group()
@@ -154,6 +155,9 @@ def _worker8(rank, world, port, q):
             blob = torch.arange(b0, b1, dtype=torch.int64).to(torch.uint8)
             whole = gather_archive(blob, blob.numel(), group=odd)
             assert torch.equal(whole, torch.arange(nblocks, dtype=torch.int64).to(torch.uint8))
+        # the even ranks are done here while the odd ones still talk inside their group: nobody tears the default group (rank 0: the store)
+        # down before everybody is through (a rare hang of this test otherwise: 2 of ~35 runs)
+        dist.barrier()
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
