@@ -613,6 +613,7 @@ def main_sharded(a):
         else:
             res["note"] = "T(1) of this job is the ms_per_step of the 'configs[4]-shape, 1 GPU' entry of `bench.py --gpus 1`"
         print(json.dumps(res), flush=True)
+    dist.barrier()                 # (rank 0 measured T1 meanwhile: nobody leaves the group before everybody is through)
     dist.destroy_process_group()
 
 
