@@ -654,8 +654,14 @@ def bench_inflate(a, eng=None, cpu=True, streams=None, strategy=None, kernel=Non
     host = d_plain.cpu().numpy()
     nproc = min(os.cpu_count() or 1, 64)
     per = (B + nproc * 4 - 1) // (nproc * 4)
-    with mp.get_context("fork").Pool(nproc) as pool:
+    # (close + join, not the context manager: its terminate() sends SIGTERM, which a profiler's signal handler in the forked workers can
+    #  swallow -- a traced run of this file hung there for good)
+    pool = mp.get_context("fork").Pool(nproc)
+    try:
         parts = pool.map(_zfixed_chunk, [(host[k:k + per].tobytes(), n, a.zlib_strategy) for k in range(0, B, per)])
+    finally:
+        pool.close()
+        pool.join()
     del host
     lens = np.fromiter((l for _, ls in parts for l in ls), dtype=np.int64, count=B)
     off = np.zeros(B + 1, np.int64)
