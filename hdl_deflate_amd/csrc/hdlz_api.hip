@@ -164,7 +164,8 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
                   HDLZ_INFLATE_TOKEN_ROUNDS | HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_GROUP_PER_STREAM))
         return fail_param("unknown flag");
     // the kernels keep stream lengths and bit positions in 32 bits (8 * length must not wrap)
-    if (in_len >= 0x10000000u) return fail_param("in_len too large (streams are limited to 256 MiB - 1)");
+    if (!d_in_off && in_len >= 0x10000000u) return fail_param("in_len too large (streams are limited to 256 MiB - 1)");
+    if (d_in_off && in_len >= 0x10000000u) in_len = 0;      // ragged: a bound nobody can use is no bound (the field was ignored before round 5)
     if (!d_in_off && nstreams > 1 && in_pitch < in_len) return fail_param("in_pitch < in_len");
     {
         const uint32_t mf = flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_GROUP_PER_STREAM);
