@@ -192,7 +192,15 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     // ONE large stream: cut into 1 KiB pieces and decoded by the whole GPU (hdlz_inflate_par.hip) when it is a single fixed block --
     // what STARTC writes --, by one wave otherwise (decided on the device); the explicit mapping hints keep the batch kernels
     // (ragged input: in_len is the caller's upper bound on the stream lengths, 0 = not stated -- then the batch kernels)
-    if (nstreams == 1 && in_len >= HDLZ_INFLATE_PAR_MIN &&
+    // While the stream is being CAPTURED into a HIP graph the path keeps to what it took before round 5 -- one fixed-pitch stream of
+    // HDLZ_INFLATE_PAR_LONG bytes or more: a graph that held the several-streams form next to other calls with stream-ordered scratch
+    // aborted inside hipGraphLaunch once in three runs of tests/test_gpu_parity.py::test_calls_are_hip_graph_capturable (ROCm 7.2; the same
+    // calls outside a graph: 10^8 fuzzed blocks clean).  The results are the same either way.
+    hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap_st) != hipSuccess || cap_st != hipStreamCaptureStatusNone;
+    if (capturing) (void)hipGetLastError();
+    const bool par_one = capturing ? (!d_in_off && in_len >= HDLZ_INFLATE_PAR_LONG) : in_len >= HDLZ_INFLATE_PAR_MIN;
+    if (nstreams == 1 && par_one &&
         !(flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_BYTE_LOCKSTEP))) {
         bool used = false;
         hipError_t e = hdlz::launch_inflate_par(a, st, &used);
@@ -204,7 +212,7 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     // 5.9 ms, 1 MiB: 94 ms, however few there are); this path costs the launch chain once plus the streams' bytes at the rate of the
     // single-stream path (profiles/r05_inflate_mapping.txt).  Streams below HDLZ_INFLATE_PAR_LONG bytes: up to HDLZ_INFLATE_PAR_BATCH_SHORT_MAX of them
     // (1024 x 2 KiB: 0.21 ms against 0.33; from 2048 on the wave mapping is as fast).  A batch of dynamic-tree streams pays ~0.05 ms for asking.
-    if (nstreams > 1 && nstreams <= (in_len >= HDLZ_INFLATE_PAR_LONG ? HDLZ_PAR_BATCH_MAX : HDLZ_PAR_BATCH_SHORT_MAX) && in_len >= HDLZ_INFLATE_PAR_MIN &&
+    if (!capturing && nstreams > 1 && nstreams <= (in_len >= HDLZ_INFLATE_PAR_LONG ? HDLZ_PAR_BATCH_MAX : HDLZ_PAR_BATCH_SHORT_MAX) && in_len >= HDLZ_INFLATE_PAR_MIN &&
         !(flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_GROUP_PER_STREAM))) {
         bool used = false;
         hipError_t e = hdlz::launch_inflate_par(a, st, &used);

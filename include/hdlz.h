@@ -88,7 +88,9 @@ enum {
  * ~0.12 ms: one 8 KiB stream 0.12 instead of 0.75 ms, 1024 streams of 2 KiB 0.21 instead of 0.33 ms; 4096 of them: the wave mapping wins).
  * (The threshold was 16384 up to the first builds of 0x000500: the path cost 0.35 ms then.)
  * Ragged input (d_in_off given): in_len, if not 0, is the caller's UPPER BOUND on the stream lengths and the thresholds above apply to it (0 =
- * not stated: the batch kernels, as before); a stream longer than the bound is decoded by the serial pass -- right, only slower. */
+ * not stated: the batch kernels, as before); a stream longer than the bound is decoded by the serial pass -- right, only slower.
+ * While `stream` is being captured into a HIP graph only ONE fixed-pitch stream of >= HDLZ_INFLATE_PAR_LONG bytes takes the path (what it
+ * took before round 5; a batch goes to the batch kernels): same results, see hdlz_api.hip. */
 #ifndef HDLZ_INFLATE_PAR_MIN          /* (A/B builds override it) */
 #define HDLZ_INFLATE_PAR_MIN 2048u
 #endif
