@@ -255,6 +255,115 @@ def compress_entry(name, workload, r, cwindow, maxmatch, steps, warmup, traffic_
             "roofline": roofline(kname_for(cwindow, r["n"]), algo, r["k_ms"], traffic_key, None, compress_grid(r["B"]), r["in_bytes"])}
 
 
+# ------------------------------------------------------------------------------------------------ the ONE line
+LINE_MAX = 12288            # the driver keeps only the tail of stdout: a line beyond ~16 KB was not parsed (BENCH_r05.parsed == None)
+DETAIL_DEFAULT = os.path.join("profiles", "r06_bench_detail.json")
+ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch",
+             "kernel_ms_avg", "kernel_ms_median", "kernel_ms_min", "launches_timed", "device_copy_GBps", "frac_of_device_copy")
+ISSUE_KEEP = ("frac", "valu_insts_per_launch", "valu_insts_per_byte", "source")
+TOP_KEEP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "per_gpu_MBps", "compression_ratio_out_over_in", "roofline", "cpu_baseline", "archive", "end_to_end",
+            "input_MBps", "length_allgather_ms_avg", "lengths_digest", "T1_ms", "T1_kernel_ms_median", "speedup_vs_T1",
+            "T1_lengths_digest", "scaling_curve", "error", "visible_devices", "secondary", "detail")
+SEC_KEEP = ("name", "metric", "value", "unit", "ms_per_step", "compression_ratio_out_over_in", "input_MBps", "roofline",
+            "compress_roofline", "inflate_MBps", "compress_MBps", "wave_per_stream_ms", "status")
+
+
+def _numbers_only(d, depth=2):
+    """a sub-object of the line without its prose: numbers, booleans, None and strings of at most 48 characters"""
+    out = {}
+    for k, v in d.items():
+        if k == "note" or k.endswith("_note") or k == "ms_all":
+            continue
+        if isinstance(v, dict):
+            if depth > 0:
+                out[k] = _numbers_only(v, depth - 1)
+        elif not isinstance(v, str) or len(v) <= 48:
+            out[k] = v
+    return out
+
+
+def _slim_roofline(r):
+    s = {k: r[k] for k in ROOF_KEEP if k in r}
+    if isinstance(r.get("issue"), dict):
+        s["issue"] = {k: r["issue"][k] for k in ISSUE_KEEP if k in r["issue"]}
+    return s
+
+
+def _short(s, n):
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def slim_line(res, detail_path=None, line_max=LINE_MAX):
+    """the line the driver parses: the contract's keys, `roofline`, `cpu_baseline` and the numbers of every secondary entry; all
+    prose (`note`s, long workload texts, per-entry configs) stays in the detail file named in `detail` (VERDICT r5 #1)"""
+    top = {k: res[k] for k in TOP_KEEP if k in res and k not in ("secondary", "roofline", "cpu_baseline", "archive", "end_to_end", "config")}
+    if "config" in res:
+        top["config"] = {k: (_short(v, 200) if isinstance(v, str) else v) for k, v in res["config"].items()}
+    if "roofline" in res:
+        top["roofline"] = _slim_roofline(res["roofline"])
+    if "cpu_baseline" in res:
+        cb = res["cpu_baseline"]
+        top["cpu_baseline"] = {k: (_short(v, 160) if isinstance(v, str) else v) for k, v in cb.items() if k != "note"}
+    for k in ("archive", "end_to_end"):
+        if isinstance(res.get(k), dict):
+            top[k] = _numbers_only(res[k])
+    if detail_path:
+        top["detail"] = detail_path
+    sec = []
+    for e in res.get("secondary", []):
+        se = {k: e[k] for k in SEC_KEEP if k in e and k not in ("roofline", "compress_roofline")}
+        if "metric" in se:
+            se["metric"] = _short(se["metric"], 80)
+        for k in ("roofline", "compress_roofline"):
+            if isinstance(e.get(k), dict):
+                se[k] = _slim_roofline(e[k])
+                se[k]["kernel"] = _short(str(se[k].get("kernel")), 48)
+                for drop in ("peak", "unit", "bound", "kernel_ms_median", "kernel_ms_min", "launches_timed"):
+                    se[k].pop(drop, None)
+        sec.append(se)
+    if sec:
+        top["secondary"] = sec
+    enc = lambda o: json.dumps(o, separators=(",", ":"))
+    line = enc(top)
+    # never lose the headline to the size of the rest: shed secondary detail in steps until the line fits
+    for shed in ("traffic_source", "metric", "compress_roofline", "issue", "roofline"):
+        if len(line) < line_max:
+            break
+        for se in top.get("secondary", []):
+            se.pop(shed, None)
+            for k in ("roofline", "compress_roofline"):
+                if isinstance(se.get(k), dict):
+                    se[k].pop(shed, None)
+        line = enc(top)
+    while len(line) >= line_max and top.get("secondary"):
+        top["secondary"].pop()
+        top["secondary_truncated"] = True
+        line = enc(top)
+    assert len(line) < line_max, "bench line of %d bytes" % len(line)
+    return line
+
+
+def emit(res, a=None):
+    """write the full result (every note, config and sub-measurement) to the detail file, print the slim line"""
+    path = getattr(a, "detail", None) if a is not None else None
+    named = None
+    if path:
+        for p in (path, os.path.join("gpurun_out", os.path.basename(path)) if os.path.isdir(os.path.join(REPO, "gpurun_out")) else None):
+            if not p:
+                continue
+            try:
+                full = p if os.path.isabs(p) else os.path.join(REPO, p)
+                os.makedirs(os.path.dirname(full), exist_ok=True)
+                with open(full, "w") as f:
+                    json.dump(res, f, indent=1)
+                    f.write("\n")
+                named = named or p
+            except OSError:
+                pass
+    print(slim_line(res, named), flush=True)
+
+
 # ------------------------------------------------------------------------------------------------ N = 1
 def main_single(a):
     import torch
@@ -402,7 +511,7 @@ def main_single(a):
         sec.append(bench_single_stream(torch, eng, dev, a))
         sec.append(bench_few_large(torch, eng, dev, a))
         res["secondary"] = sec
-    print(json.dumps(res), flush=True)
+    emit(res, a)
 
 
 def bench_roundtrip(torch, eng, a, d_plain, r):
@@ -612,7 +721,7 @@ def main_sharded(a):
                            "job's); speedup_vs_T1 / n_gpus is the strong-scaling efficiency" % total)
         else:
             res["note"] = "T(1) of this job is the ms_per_step of the 'configs[4]-shape, 1 GPU' entry of `bench.py --gpus 1`"
-        print(json.dumps(res), flush=True)
+        emit(res, a)
     dist.barrier()                 # (rank 0 measured T1 meanwhile: nobody leaves the group before everybody is through)
     dist.destroy_process_group()
 
@@ -872,9 +981,11 @@ def main():
                     help="N=1: skip the PCIe-inclusive measurement of the headline job (SURVEY 8(d) Timing)")
     ap.add_argument("--no-t1", dest="t1", action="store_false",
                     help="N>1: do not run the whole job on rank 0 first (T1_ms / speedup_vs_T1 are then absent)")
+    ap.add_argument("--detail", default=DETAIL_DEFAULT,
+                    help="file that receives the FULL result (notes, configs, every sub-measurement); the printed line names it ('' = none)")
     a = ap.parse_args()
     if a.mode == "inflate":
-        print(json.dumps(bench_inflate(a)), flush=True)
+        emit(bench_inflate(a), a)
     elif a.mode == "roundtrip":                               # only the configs[4] round-trip entry (profiling)
         import torch
         import hdl_deflate_amd
@@ -883,17 +994,17 @@ def main():
         eng = hdl_deflate_amd.Engine(torch.device("cuda", 0))
         d5 = make_blocks(a.cfg5_blocks, CFG5_BLOCK, torch.device("cuda", 0), seed=0)
         r5 = run_compress(torch, eng, d5, 32, 10, 1, 1, 0)
-        print(json.dumps(bench_roundtrip(torch, eng, a, d5, r5)), flush=True)
+        emit(bench_roundtrip(torch, eng, a, d5, r5), a)
     elif a.mode == "single":                                  # only the one-stream entry (profiling)
         import torch
         import hdl_deflate_amd
         torch.cuda.set_device(0)
-        print(json.dumps(bench_single_stream(torch, hdl_deflate_amd.Engine(torch.device("cuda", 0)), torch.device("cuda", 0), a)), flush=True)
+        emit(bench_single_stream(torch, hdl_deflate_amd.Engine(torch.device("cuda", 0)), torch.device("cuda", 0), a), a)
     elif a.mode == "few":                                     # only the few-large-streams entry (profiling)
         import torch
         import hdl_deflate_amd
         torch.cuda.set_device(0)
-        print(json.dumps(bench_few_large(torch, hdl_deflate_amd.Engine(torch.device("cuda", 0)), torch.device("cuda", 0), a, with_wave=False)), flush=True)
+        emit(bench_few_large(torch, hdl_deflate_amd.Engine(torch.device("cuda", 0)), torch.device("cuda", 0), a, with_wave=False), a)
     elif a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
     elif a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:

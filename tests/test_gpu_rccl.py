@@ -98,6 +98,7 @@ def _run_bench(world, env_extra, args):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines[0]) < 12288, len(lines[0])                  # (the driver did not parse a 20 KB line)
     return json.loads(lines[0])
 
 
@@ -167,3 +168,25 @@ def test_bench_gpus_8_even_and_uneven_jobs():
         assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["value"] > 0 and r["config"]["blocks_total"] == blocks
         assert r["config"]["blocks_per_gpu"] == blocks // 8 + (1 if blocks % 8 else 0)          # rank 0's shard
         assert r["lengths_digest"] == r["T1_lengths_digest"] and r["T1_ms"] > 0
+
+
+def test_bench_single_gpu_line_is_short_and_complete(tmp_path):
+    """the `--gpus 1` line (every secondary entry, reduced sizes) is ONE line below 12 KB that carries the contract's
+    keys, `roofline` and `cpu_baseline`; the prose went to the detail file it names"""
+    detail = str(tmp_path / "bench_detail.json")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--blocks", "65536", "--cfg5-blocks", "2048", "--text-blocks", "256",
+           "--streams", "65536", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1", "--detail", detail]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 12288, [len(ln) for ln in lines]
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "secondary", "detail"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["roofline"]["frac"] > 0 and r["roofline"]["bound"] == "hbm"
+    assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["cores"] >= 1
+    assert len(r["secondary"]) >= 9 and all(e["value"] > 0 and e["roofline"]["frac"] > 0 for e in r["secondary"])
+    full = json.load(open(detail))
+    assert full["value"] == r["value"] and "note" in full["roofline"] and len(full["secondary"]) == len(r["secondary"])
