@@ -781,7 +781,7 @@ def bench_inflate(a, eng=None, cpu=True, streams=None, strategy=None, kernel=Non
     d_off = torch.from_numpy(off).to(dev)
     d_out = torch.empty((B, n), dtype=torch.uint8, device=dev)
     flags = hdl_deflate_amd.INFLATE_ASSUME_FIXED if a.zlib_strategy == "fixed" else 0
-    flags |= {"default": 0, "token": 16, "byte": 32, "group": 64}[a.inflate_kernel]       # kernel / mapping variant (include/hdlz.h); group = 16 lanes per stream
+    flags |= {"default": 0, "lane": 2, "wave": 4, "group": 64}[a.inflate_kernel]       # mapping hint (include/hdlz.h); group = 16 lanes per stream
 
     def step():
         return eng.inflate_batch(d_in, in_off=d_off, out_pitch=n, flags=flags, out=d_out)
@@ -805,9 +805,9 @@ def bench_inflate(a, eng=None, cpu=True, streams=None, strategy=None, kernel=Non
                       "streams": B, "block_bytes": n},
            "input_MBps": round(z_bytes / (dt / a.steps) / 1e6, 1),
            "compression_ratio_out_over_in": round(z_bytes / u_bytes, 4),
-           "roofline": roofline(("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_grp" if a.inflate_kernel == "group" else "k_inflate_tok<false>") +
-                                ("" if fixed else " + k_inflate_dyn" if a.inflate_kernel == "byte" else " + k_inflate_tok<true>"), algo, k_ms,
-                                "%s|streams=%d|block=%d|%s" % ("k_inflate" if a.inflate_kernel == "byte" else "k_inflate_grp" if a.inflate_kernel == "group" else "k_inflate_tok", B, n, a.zlib_strategy),
+           "roofline": roofline(("k_inflate_dyn" if a.inflate_kernel == "wave" else "k_inflate_grp" if a.inflate_kernel == "group" else "k_inflate_tok<false>") +
+                                ("" if fixed or a.inflate_kernel == "wave" else " + k_inflate_tok<true>"), algo, k_ms,
+                                "%s|streams=%d|block=%d|%s" % ("k_inflate_dyn" if a.inflate_kernel == "wave" else "k_inflate_grp" if a.inflate_kernel == "group" else "k_inflate_tok", B, n, a.zlib_strategy),
                                 None, None, u_bytes)}
     if fixed and a.end_to_end:
         # SURVEY 8(d) "Timing" for STARTD: the job from pinned HOST buffers (streams in, rows out), the three steps one after the other;
@@ -971,8 +971,8 @@ def main():
     ap.add_argument("--zlib-strategy", default="fixed", choices=["fixed", "default"],
                     help="inflate: fixed = Z_FIXED streams (configs[3]); default = stock zlib streams with dynamic trees "
                          "(exercises the second pass k_inflate_tok<true> / k_inflate_dyn, SURVEY 8(f) rank 1)")
-    ap.add_argument("--inflate-kernel", default="default", choices=["default", "token", "byte", "group"],
-                    help="inflate: lane-per-stream kernel variant (token = k_inflate_tok, byte = k_inflate)")
+    ap.add_argument("--inflate-kernel", default="default", choices=["default", "lane", "wave", "group"],
+                    help="inflate: mapping hint (lane = k_inflate_tok, wave = k_inflate_dyn, group = k_inflate_grp)")
     ap.add_argument("--mode", default="compress", choices=["compress", "inflate", "roundtrip", "single", "few"],
                     help="compress = BASELINE metric (default); inflate = only the configs[3] side metric (1 GPU)")
     ap.add_argument("--no-archive", dest="archive", action="store_false",

@@ -8,7 +8,8 @@ LIB_PATH = os.environ.get("HDLZ_LIB") or os.path.join(_HERE, "lib", "libhdlz.so"
 EXPORTS = ("hdlz_version", "hdlz_status_string", "hdlz_last_error", "hdlz_device_count", "hdlz_out_bound",
            "hdlz_compress_batch", "hdlz_inflate_batch", "hdlz_compact_batch", "hdlz_archive_batch",
            "hdlz_stream_work_bytes", "hdlz_compress_stream", "hdlz_streams_work_bytes", "hdlz_compress_streams",
-           "hdlz_compress_chunk", "hdlz_inflate_chunk", "hdlz_release_scratch")
+           "hdlz_compress_chunk", "hdlz_inflate_chunk", "hdlz_release_scratch",
+           "hdlz_inflate_work_bytes", "hdlz_inflate_batch_ws", "hdlz_archive_work_bytes", "hdlz_archive_batch_ws")
 _lib = None
 
 
@@ -53,5 +54,13 @@ def load():
     L.hdlz_inflate_chunk.restype = ci
     L.hdlz_inflate_chunk.argtypes = [vp, u32, ci, u32, u32, vp, u64, u32, vp, vp]
     L.hdlz_release_scratch.restype = ci
+    L.hdlz_inflate_work_bytes.restype = ctypes.c_size_t
+    L.hdlz_inflate_work_bytes.argtypes = [u64, u32, u64, u32, ci]
+    L.hdlz_inflate_batch_ws.restype = ci
+    L.hdlz_inflate_batch_ws.argtypes = [vp, vp, u64, u32, u64, u32, u32, vp, u64, vp, vp, vp, ctypes.c_size_t, vp]
+    L.hdlz_archive_work_bytes.restype = ctypes.c_size_t
+    L.hdlz_archive_work_bytes.argtypes = [u64]
+    L.hdlz_archive_batch_ws.restype = ci
+    L.hdlz_archive_batch_ws.argtypes = [vp, u64, vp, u64, vp, u64, vp, vp, ctypes.c_size_t, vp]
     _lib = L
     return L

@@ -18,7 +18,7 @@ lib="$out/libhdlz${var:+_$var}.so"
 mkdir -p "$out" "$objdir"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${HDLZ_DEFS:-}"
-srcs="hdlz_compress hdlz_compress_small hdlz_compress_stream hdlz_compress_chunk hdlz_inflate hdlz_inflate_tok hdlz_inflate_grp hdlz_inflate_par hdlz_inflate_dyn hdlz_compact hdlz_api"
+srcs="hdlz_compress hdlz_compress_small hdlz_compress_stream hdlz_compress_chunk hdlz_inflate_tok hdlz_inflate_grp hdlz_inflate_par hdlz_inflate_dyn hdlz_compact hdlz_api"
 only="${HDLZ_ONLY:-$srcs}"
 pids=()
 for f in $only; do

@@ -19,6 +19,24 @@ int fail_param(const char* what) {
     snprintf(g_err, sizeof(g_err), "bad parameter: %s", what);
     return HDLZ_E_BAD_PARAM;
 }
+// The entry points that draw scratch from the library's pool (hipMallocFromPoolAsync / hipFreeAsync on the caller's stream) refuse a
+// stream that is being captured: the calls would become graph memory nodes, and on ROCm 7.2 the memory such a node hands out does not
+// keep what the graph's own kernel nodes write to it (tools/repro/graph_scratch.hip: a kernel node reads ZEROS where the node in front
+// of it wrote, 2-3 million words in 60 replays, no libhdlz involved; with libhdlz: wrong bytes, a hang, and -- round 5 -- an abort in
+// hipGraphLaunch when k_par_* followed garbage lists out of bounds; profiles/r06_graph_abort_cause.txt).  The _ws entry points
+// allocate nothing and are capturable.
+int refuse_capture(void* stream, const char* use) {
+#ifdef HDLZ_ALLOW_POOL_IN_CAPTURE                         // (lib/libhdlz_poolcap.so: tools/repro/graph_abort.py shows what then happens)
+    return HDLZ_OK;
+#endif
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const hipError_t e = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs);
+    if (e != hipSuccess) { (void)hipGetLastError(); return HDLZ_OK; }
+    if (cs == hipStreamCaptureStatusNone) return HDLZ_OK;
+    snprintf(g_err, sizeof(g_err), "bad parameter: the stream is being captured into a graph and this entry point allocates "
+                                   "stream-ordered scratch: use %s (caller-owned scratch)", use);
+    return HDLZ_E_BAD_PARAM;
+}
 int fail_hip(hipError_t e, const char* where) {
     snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
     return HDLZ_E_HIP;
@@ -86,6 +104,15 @@ hipError_t scratch_release() {
     if (dev >= 0 && dev < 64 && g_pools[dev]) return hipMemPoolTrimTo(g_pools[dev], 0);
     return hipSuccess;
 }
+hipError_t Work::get(size_t need, hipStream_t stream, uint8_t** p) const {
+    if (caller) {                                         // the caller's buffer or nothing: this call allocates no memory
+        if (!base || need > bytes) return hipErrorOutOfMemory;
+        *p = base;
+        return hipSuccess;
+    }
+    return scratch_alloc(reinterpret_cast<void**>(p), need, stream);
+}
+hipError_t Work::put(uint8_t* p, hipStream_t stream) const { return caller ? hipSuccess : hipFreeAsync(p, stream); }
 }  // namespace hdlz
 
 extern "C" {
@@ -155,88 +182,105 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
 #ifndef HDLZ_PAR_BATCH_MAX
 #define HDLZ_PAR_BATCH_MAX HDLZ_INFLATE_PAR_BATCH_MAX      // (A/B builds override it: tools/bench_few_large_inflate.py)
 #endif
-int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
+}  // extern "C"
+
+namespace {
+// does a batch of this shape take the whole-GPU path (hdlz_inflate_par.hip)?  ONE large stream: cut into pieces and decoded by the whole
+// GPU.  A FEW large streams: the same chain with every kernel launched once for all of them (blockIdx.y = the stream): the batch kernels
+// decode a stream as ONE serial chain (64 KiB: 5.9 ms, 1 MiB: 94 ms, however few there are); this path costs the launch chain once plus
+// the streams' bytes at the rate of the single-stream path (profiles/r05_inflate_mapping.txt).  Streams below HDLZ_INFLATE_PAR_LONG bytes:
+// up to HDLZ_INFLATE_PAR_BATCH_SHORT_MAX of them.  Ragged input: in_len is the caller's upper bound on the stream lengths (0 = not stated).
+// The explicit mapping hints keep the batch kernels.
+bool par_applies(uint64_t nstreams, uint32_t in_len, uint32_t flags) {
+    if (in_len < HDLZ_INFLATE_PAR_MIN) return false;
+    if (flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM)) return false;
+    if (nstreams == 1) return true;
+    if (flags & HDLZ_INFLATE_GROUP_PER_STREAM) return false;
+    return nstreams <= (in_len >= HDLZ_INFLATE_PAR_LONG ? HDLZ_PAR_BATCH_MAX : HDLZ_PAR_BATCH_SHORT_MAX);
+}
+
+int inflate_batch_impl(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
                        uint64_t nstreams, uint32_t flags, uint32_t obsize, uint8_t* d_out, uint64_t out_pitch,
-                       uint32_t* d_out_len, uint32_t* d_status, void* stream) {
+                       uint32_t* d_out_len, uint32_t* d_status, const hdlz::Work& w, void* stream) {
     if (nstreams > 0x7FFFFFFFull * 32) return fail_param("nstreams too large for one launch");
     if (nstreams && (!d_in || !d_out || !d_out_len || !d_status)) return fail_param("null device pointer");
     if (flags & ~(HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_ONEBLOCK |
-                  HDLZ_INFLATE_TOKEN_ROUNDS | HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_GROUP_PER_STREAM))
+                  HDLZ_INFLATE_GROUP_PER_STREAM))
         return fail_param("unknown flag");
     // the kernels keep stream lengths and bit positions in 32 bits (8 * length must not wrap)
     if (!d_in_off && in_len >= 0x10000000u) return fail_param("in_len too large (streams are limited to 256 MiB - 1)");
-    if (d_in_off && in_len >= 0x10000000u) in_len = 0;      // ragged: a bound nobody can use is no bound (the field was ignored before round 5)
+    if (d_in_off && in_len >= 0x10000000u) in_len = 0;      // ragged: a bound nobody can use is no bound
     if (!d_in_off && nstreams > 1 && in_pitch < in_len) return fail_param("in_pitch < in_len");
     {
         const uint32_t mf = flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_GROUP_PER_STREAM);
         if (mf & (mf - 1u)) return fail_param("contradictory mapping flags");
     }
     if ((out_pitch & 3u) || (reinterpret_cast<uintptr_t>(d_out) & 3u)) return fail_param("d_out / out_pitch must be 4-byte aligned");
+    if (w.caller && w.base && (reinterpret_cast<uintptr_t>(w.base) & 255u)) return fail_param("d_work must be 256-byte aligned");
     int rc = check_device();
     if (rc != HDLZ_OK) return rc;
     if (nstreams == 0) return HDLZ_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hdlz::InflateArgs a{d_in, d_in_off, in_pitch, in_len, nstreams, flags, obsize, d_out, out_pitch, d_out_len, d_status};
-    // mapping: one LANE per stream (k_inflate, 64 streams in lockstep per wave) needs ~10^5 streams to fill the GPU;
-    // below HDLZ_INFLATE_WAVE_THRESHOLD streams one WAVE per stream (k_inflate_dyn, window decode) is faster, for
-    // any block type
-    const uint32_t hint = flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_GROUP_PER_STREAM |
-                                   HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_TOKEN_ROUNDS);
-    // in between: 16 lanes per stream (k_inflate_grp, round 5) -- from HDLZ_INFLATE_GROUP_MIN streams on it beats a wave per stream,
+    // mapping: one LANE per stream (k_inflate_tok, 64 streams in lockstep per wave) needs ~10^5 streams to fill the GPU;
+    // below HDLZ_INFLATE_WAVE_THRESHOLD streams one WAVE per stream (k_inflate_dyn, window decode) is faster, for any block type;
+    // in between: 16 lanes per stream (k_inflate_grp) -- from HDLZ_INFLATE_GROUP_MIN streams on it beats a wave per stream,
     // up to HDLZ_INFLATE_GROUP_MAX a lane per stream; the streams it flags (dynamic-tree blocks) take the second pass below
+    const uint32_t hint = flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_GROUP_PER_STREAM);
     if ((flags & HDLZ_INFLATE_GROUP_PER_STREAM) && nstreams > 0x7FFFFFFFull * 16) return fail_param("nstreams too large for the 16-lanes-per-stream mapping");
     const bool group = (flags & HDLZ_INFLATE_GROUP_PER_STREAM) ||
                        (hint == 0u && nstreams >= HDLZ_INFLATE_GROUP_MIN && nstreams <= HDLZ_INFLATE_GROUP_MAX);
     const bool wave_all = !group && ((flags & HDLZ_INFLATE_WAVE_PER_STREAM) ||
                                      (!(flags & HDLZ_INFLATE_LANE_PER_STREAM) && nstreams <= HDLZ_INFLATE_WAVE_THRESHOLD));
-    // ONE large stream: cut into 1 KiB pieces and decoded by the whole GPU (hdlz_inflate_par.hip) when it is a single fixed block --
-    // what STARTC writes --, by one wave otherwise (decided on the device); the explicit mapping hints keep the batch kernels
-    // (ragged input: in_len is the caller's upper bound on the stream lengths, 0 = not stated -- then the batch kernels)
-    // While the stream is being CAPTURED into a HIP graph the path keeps to what it took before round 5 -- one fixed-pitch stream of
-    // HDLZ_INFLATE_PAR_LONG bytes or more: a graph that held the several-streams form next to other calls with stream-ordered scratch
-    // aborted inside hipGraphLaunch once in three runs of tests/test_gpu_parity.py::test_calls_are_hip_graph_capturable (ROCm 7.2; the same
-    // calls outside a graph: 10^8 fuzzed blocks clean).  The results are the same either way.
-    hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(st, &cap_st) != hipSuccess || cap_st != hipStreamCaptureStatusNone;
-    if (capturing) (void)hipGetLastError();
-    const bool par_one = capturing ? (!d_in_off && in_len >= HDLZ_INFLATE_PAR_LONG) : in_len >= HDLZ_INFLATE_PAR_MIN;
-    if (nstreams == 1 && par_one &&
-        !(flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_BYTE_LOCKSTEP))) {
+    if (par_applies(nstreams, in_len, flags)) {
         bool used = false;
-        hipError_t e = hdlz::launch_inflate_par(a, st, &used);
-        if (e != hipSuccess) return fail_hip(e, "launch the parallel single-stream inflate");
+        hipError_t e = hdlz::launch_inflate_par(a, st, &used, w);
+        if (e != hipSuccess) return fail_hip(e, "launch the whole-GPU inflate (k_par_*)");
         if (used) return HDLZ_OK;
-    }
-    // a FEW large streams (fixed pitch): the same path with every kernel launched once for all of them (blockIdx.y = the stream; round 5 --
-    // up to round 4 one chain of launches per stream, 0.125 ms each).  The batch kernels decode a stream as ONE serial chain (64 KiB:
-    // 5.9 ms, 1 MiB: 94 ms, however few there are); this path costs the launch chain once plus the streams' bytes at the rate of the
-    // single-stream path (profiles/r05_inflate_mapping.txt).  Streams below HDLZ_INFLATE_PAR_LONG bytes: up to HDLZ_INFLATE_PAR_BATCH_SHORT_MAX of them
-    // (1024 x 2 KiB: 0.21 ms against 0.33; from 2048 on the wave mapping is as fast).  A batch of dynamic-tree streams pays ~0.05 ms for asking.
-    if (!capturing && nstreams > 1 && nstreams <= (in_len >= HDLZ_INFLATE_PAR_LONG ? HDLZ_PAR_BATCH_MAX : HDLZ_PAR_BATCH_SHORT_MAX) && in_len >= HDLZ_INFLATE_PAR_MIN &&
-        !(flags & (HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_BYTE_LOCKSTEP | HDLZ_INFLATE_GROUP_PER_STREAM))) {
-        bool used = false;
-        hipError_t e = hdlz::launch_inflate_par(a, st, &used);
-        if (e != hipSuccess) return fail_hip(e, "launch the parallel inflate of a few large streams");
-        if (used) return HDLZ_OK;
-        // (no scratch: the batch kernels below)
+        // (no scratch, or a shape the path leaves alone: the batch kernels below)
     }
     if (wave_all) {
         hipError_t e = hdlz::launch_inflate_dyn(a, st, true);
         if (e != hipSuccess) return fail_hip(e, "launch k_inflate_dyn");
         return HDLZ_OK;
     }
-    // lane per stream: one TOKEN per round (k_inflate_tok, round 2: 362 GB/s on BASELINE configs[3]) unless the caller asks for
-    // round 1's one-byte-per-iteration kernel (k_inflate, 278 GB/s)
-    hipError_t e = group ? hdlz::launch_inflate_grp(a, st)
-                 : (flags & HDLZ_INFLATE_BYTE_LOCKSTEP) ? hdlz::launch_inflate(a, st) : hdlz::launch_inflate_tok(a, st);
+    // lane per stream, one TOKEN group per round (k_inflate_tok), or 16 lanes per stream
+    hipError_t e = group ? hdlz::launch_inflate_grp(a, st) : hdlz::launch_inflate_tok(a, st, w);
     if (e != hipSuccess) return fail_hip(e, "launch k_inflate");
     // second pass, same stream: streams in which pass 1 met a dynamic-tree block (status 6) are redone, again one lane each
-    // (k_inflate_tok<true>; HDLZ_INFLATE_BYTE_LOCKSTEP keeps round 1's pair: one wave per such stream); everything else is
-    // left untouched
-    e = ((flags & HDLZ_INFLATE_BYTE_LOCKSTEP) || nstreams > 0xFFFFFFFFull) ? hdlz::launch_inflate_dyn(a, st, false)
-                                                                            : hdlz::launch_inflate_tok_dyn(a, st, false);
+    // (k_inflate_tok<true>); everything else is left untouched
+    e = nstreams > 0xFFFFFFFFull ? hdlz::launch_inflate_dyn(a, st, false) : hdlz::launch_inflate_tok_dyn(a, st, false, w);
     if (e != hipSuccess) return fail_hip(e, "launch the dynamic-tree pass");
     return HDLZ_OK;
+}
+}  // namespace
+
+extern "C" {
+
+size_t hdlz_inflate_work_bytes(uint64_t nstreams, uint32_t in_len, uint64_t out_pitch, uint32_t flags, int ragged) {
+    if (nstreams == 0) return 0;
+    size_t need = hdlz::inflate_tok_work_bytes(nstreams, ragged != 0);
+    if (ragged && in_len >= 0x10000000u) in_len = 0;
+    if (par_applies(nstreams, in_len, flags)) {
+        const size_t p = hdlz::inflate_par_work_bytes(in_len, nstreams, out_pitch);
+        if (p > need) need = p;
+    }
+    return need < 256u ? 256u : need;
+}
+
+int hdlz_inflate_batch_ws(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
+                          uint64_t nstreams, uint32_t flags, uint32_t obsize, uint8_t* d_out, uint64_t out_pitch,
+                          uint32_t* d_out_len, uint32_t* d_status, void* d_work, size_t work_bytes, void* stream) {
+    const hdlz::Work w{static_cast<uint8_t*>(d_work), d_work ? work_bytes : 0u, true};
+    return inflate_batch_impl(d_in, d_in_off, in_pitch, in_len, nstreams, flags, obsize, d_out, out_pitch, d_out_len, d_status, w, stream);
+}
+
+int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
+                       uint64_t nstreams, uint32_t flags, uint32_t obsize, uint8_t* d_out, uint64_t out_pitch,
+                       uint32_t* d_out_len, uint32_t* d_status, void* stream) {
+    if (nstreams) { const int rc = refuse_capture(stream, "hdlz_inflate_batch_ws"); if (rc != HDLZ_OK) return rc; }
+    const hdlz::Work w{nullptr, 0u, false};                  // scratch from the library's stream-ordered pool
+    return inflate_batch_impl(d_in, d_in_off, in_pitch, in_len, nstreams, flags, obsize, d_out, out_pitch, d_out_len, d_status, w, stream);
 }
 
 int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, const uint64_t* d_off,
@@ -249,15 +293,32 @@ int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t
     return HDLZ_OK;
 }
 
-int hdlz_archive_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, uint64_t nblocks,
-                       uint8_t* d_archive, uint64_t archive_cap, uint64_t* d_off, void* stream) {
+static int archive_impl(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, uint64_t nblocks,
+                        uint8_t* d_archive, uint64_t archive_cap, uint64_t* d_off, const hdlz::Work& w, void* stream) {
     if (!d_off || (nblocks && (!d_rows || !d_len || !d_archive))) return fail_param("null device pointer");
     if (nblocks > 0x7FFFFFFFull) return fail_param("nblocks too large for one launch (2^31 - 1 rows)");   // (32-bit tile and word counts)
+    if (w.caller && nblocks && (!w.base || w.bytes < hdlz::archive_work_bytes(nblocks))) return fail_param("d_work smaller than hdlz_archive_work_bytes(nblocks)");
+    if (w.caller && (reinterpret_cast<uintptr_t>(w.base) & 7u)) return fail_param("d_work must be 8-byte aligned");
     int rc = check_device();
     if (rc != HDLZ_OK) return rc;
-    hipError_t e = hdlz::launch_archive(d_rows, row_pitch, d_len, nblocks, d_archive, archive_cap, d_off, static_cast<hipStream_t>(stream));
+    hipError_t e = hdlz::launch_archive(d_rows, row_pitch, d_len, nblocks, d_archive, archive_cap, d_off, static_cast<hipStream_t>(stream), w);
     if (e != hipSuccess) return fail_hip(e, "launch k_archive");
     return HDLZ_OK;
+}
+
+size_t hdlz_archive_work_bytes(uint64_t nblocks) { return nblocks > 0x7FFFFFFFull ? 0u : hdlz::archive_work_bytes(nblocks); }
+
+int hdlz_archive_batch_ws(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, uint64_t nblocks,
+                          uint8_t* d_archive, uint64_t archive_cap, uint64_t* d_off, void* d_work, size_t work_bytes, void* stream) {
+    const hdlz::Work w{static_cast<uint8_t*>(d_work), d_work ? work_bytes : 0u, true};
+    return archive_impl(d_rows, row_pitch, d_len, nblocks, d_archive, archive_cap, d_off, w, stream);
+}
+
+int hdlz_archive_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, uint64_t nblocks,
+                       uint8_t* d_archive, uint64_t archive_cap, uint64_t* d_off, void* stream) {
+    if (nblocks) { const int rc = refuse_capture(stream, "hdlz_archive_batch_ws"); if (rc != HDLZ_OK) return rc; }
+    const hdlz::Work w{nullptr, 0u, false};
+    return archive_impl(d_rows, row_pitch, d_len, nblocks, d_archive, archive_cap, d_off, w, stream);
 }
 
 size_t hdlz_stream_work_bytes(size_t in_len) { return hdlz_streams_work_bytes(in_len, 1); }

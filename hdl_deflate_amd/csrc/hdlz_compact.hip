@@ -152,13 +152,18 @@ __global__ __launch_bounds__(256) void k_archive(const uint8_t* __restrict__ row
     }
 }
 
+size_t archive_work_bytes(uint64_t nblocks) {                  // ticket (+ pad), then one 64-bit descriptor per tile
+    const uint64_t ntiles = (nblocks + AT - 1u) / AT;
+    return ntiles ? (sizeof(uint32_t) * (2u + 2u * (size_t)ntiles) + 255u) & ~(size_t)255u : 0u;
+}
+
 hipError_t launch_archive(const uint8_t* rows, uint64_t pitch, const uint32_t* len, uint64_t nblocks, uint8_t* archive, uint64_t cap,
-                          uint64_t* off, hipStream_t stream) {
+                          uint64_t* off, hipStream_t stream, const Work& w) {
     const uint64_t ntiles = (nblocks + AT - 1u) / AT;
     if (ntiles == 0) return zero_words(reinterpret_cast<uint32_t*>(off), 2u, stream);      // off[0] = 0: an empty archive
     uint32_t* ws = nullptr;                                    // ticket (+ pad), then one 64-bit descriptor per tile
     const size_t words = 2u + 2u * (size_t)ntiles;
-    hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * words, stream);
+    hipError_t e = w.get(sizeof(uint32_t) * words, stream, reinterpret_cast<uint8_t**>(&ws));
     if (e != hipSuccess) return e;
     e = zero_words(ws, (uint32_t)words, stream);
     if (e == hipSuccess) {
@@ -166,7 +171,7 @@ hipError_t launch_archive(const uint8_t* rows, uint64_t pitch, const uint32_t* l
                            reinterpret_cast<unsigned long long*>(ws + 2), ws);
         e = hipGetLastError();
     }
-    const hipError_t e2 = hipFreeAsync(ws, stream);
+    const hipError_t e2 = w.put(reinterpret_cast<uint8_t*>(ws), stream);
     return e != hipSuccess ? e : e2;
 }
 

@@ -67,11 +67,23 @@ __host__ __device__ __forceinline__ void static_for(F&& f) {
 
 hipError_t launch_compress(const CompressArgs& a, hipStream_t stream);
 hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int ncu);
-hipError_t launch_inflate(const InflateArgs& a, hipStream_t stream);
-hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream);
+// The scratch of ONE call.  caller == true (the hdlz_*_ws entry points): [base, base + bytes) is the caller's device buffer and
+// nothing is allocated -- a request that does not fit FAILS and the call takes a path that needs less (same results).  caller == false
+// (the entry points without d_work): requests go to the library's stream-ordered pool (scratch_alloc / hipFreeAsync).
+struct Work {
+    uint8_t* base;
+    size_t bytes;
+    bool caller;
+    hipError_t get(size_t need, hipStream_t stream, uint8_t** p) const;
+    hipError_t put(uint8_t* p, hipStream_t stream) const;
+};
+size_t inflate_tok_work_bytes(uint64_t nstreams, bool ragged);              // pass 1's ordered list / pass 2's lists (max of the two)
+size_t inflate_par_work_bytes(uint32_t in_len, uint64_t nstreams, uint64_t out_pitch);    // all streams at once (0: the path does not apply)
+size_t archive_work_bytes(uint64_t nblocks);
+hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream, const Work& w);
 hipError_t launch_inflate_grp(const InflateArgs& a, hipStream_t stream);
-hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool all);
-hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used);
+hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool all, const Work& w);
+hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used, const Work& w);
 hipError_t launch_inflate_dyn(const InflateArgs& a, hipStream_t stream, bool all, const uint32_t* few_n = nullptr, uint32_t lane_min = 0);
 hipError_t launch_inflate_dyn_flagged(const InflateArgs& a, hipStream_t stream);
 size_t stream_work_bytes(uint32_t n, uint32_t nblocks);
@@ -96,6 +108,6 @@ hipError_t launch_compact(const uint8_t* rows, uint64_t pitch, const uint32_t* l
                           uint64_t nblocks, uint8_t* archive, hipStream_t stream);
 
 hipError_t launch_archive(const uint8_t* rows, uint64_t pitch, const uint32_t* len, uint64_t nblocks, uint8_t* archive, uint64_t cap,
-                          uint64_t* off, hipStream_t stream);
+                          uint64_t* off, hipStream_t stream, const Work& w);
 
 }  // namespace hdlz

@@ -99,10 +99,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_grp(InflateArgs a) {
     bool need_header = true;
     uint32_t qw = 0;            // the FIFO dword at ipq, read when its predecessor was taken: the refill itself waits for nothing
     uint64_t nxt = 0;           // this lane's 8 bytes of the NEXT half, [loaded + 8 l, + 8): requested a whole half ahead of the reader
+    // (the FIFO is written and read as uint32_t -- one type for the compiler's alias analysis -- and wave_lds_order() keeps the
+    //  reader's loads behind the stores: the LDS executes a wave's instructions in order)
+#define GRP_FIFO_PUT(dw, v64) do { fifo[(dw)] = (uint32_t)(v64); fifo[(dw) + 1u] = (uint32_t)((v64) >> 32); } while (0)
     if (active) {
-        *reinterpret_cast<uint64_t*>(&fifo[2u * l]) = load8(z2, 8u * l, zn2);
-        *reinterpret_cast<uint64_t*>(&fifo[(FH / 4u) + 2u * l]) = load8(z2, FH + 8u * l, zn2);
+        const uint64_t h0 = load8(z2, 8u * l, zn2), h1 = load8(z2, FH + 8u * l, zn2);
+        GRP_FIFO_PUT(2u * l, h0);
+        GRP_FIFO_PUT((FH / 4u) + 2u * l, h1);
         nxt = load8(z2, FB + 8u * l, zn2);
+        wave_lds_order();
         qw = fifo[0];
     }
 #define GRP_IP() (ipq + 2u)
@@ -124,10 +129,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_grp(InflateArgs a) {
             const bool adv = active && ipq + FH >= loaded;
             if (ballot64(adv) != 0ull) {
                 if (adv) {
-                    *reinterpret_cast<uint64_t*>(&fifo[((loaded & FMASK) >> 2) + 2u * l]) = nxt;
+                    GRP_FIFO_PUT(((loaded & FMASK) >> 2) + 2u * l, nxt);
                     loaded += FH;
                     nxt = load8(z2, loaded + 8u * l, zn2);
                 }
+                wave_lds_order();
             }
         }
         if (active) GRP_REFILL();
@@ -184,7 +190,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_grp(InflateArgs a) {
         }
         GT(1);
         // ------------------------------------------------------------ 3. slow path (wave-uniform branch, rare): k_inflate_tok's, verbatim in
-        // its checks and their order
+        // its checks and their order.  ONE block header or end-of-block per step: the FIFO advances once per step (part 1, one half of
+        // 128 bytes), and a step that walked through any number of empty blocks -- 5 bytes per empty stored block, 10 bits per empty
+        // fixed one -- would read past what is loaded (~26 empty stored blocks in a row did)
         if (ballot64(slow || (active && srem != 0u)) != 0ull) {
             while (slow && active && rem == 0u && srem == 0u && litn == 0u) {
                 GRP_REFILL();
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_grp(InflateArgs a) {
                     } else {
                         bb >>= 3; bc -= 3u;
                     }
-                    continue;
+                    break;                                               // (the block's first token: next step)
                 }
                 // NEXT (deflate.py:1409-1445)
                 const uint32_t e = lds.lit[(uint32_t)bb & 511u];
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_grp(InflateArgs a) {
                 if (code == 256u) {
                     if (final_) { out_len = o; active = false; break; }   // D6
                     need_header = true;
-                    continue;
+                    break;                                               // (the next block's header: next step)
                 }
                 if (code < 256u) {
                     if (o >= cap) { GRP_FAIL(HDLZ_E_OUT_CAPACITY); break; }
@@ -321,6 +329,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inflate_grp(InflateArgs a) {
         if (ballot64(active || rem != 0u) == 0ull) break;
     }
 #undef GRP_REFILL
+#undef GRP_FIFO_PUT
 #undef GRP_FAIL
 #undef GRP_BITPOS
 #undef GRP_IP

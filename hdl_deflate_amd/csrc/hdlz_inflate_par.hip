@@ -27,6 +27,7 @@
 // listed chains, the token lists) and 4 bytes per possible output byte (markers; 8 up to round 4: two buffers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "hdlz_device.h"
 #include "hdlz_inflate_tables.h"
 
@@ -814,21 +815,34 @@ __global__ __launch_bounds__(64) void k_par_zero(ParArgs a_) {
 }
 static_assert(C_WORDS <= 64, "k_par_zero: one wave");
 
+// streams of a batch that the chain could not take (no scratch left for their group): flagged like the chain's own give-ups
+__global__ __launch_bounds__(64) void k_par_flag_rest(uint32_t* out_len, uint32_t* status, uint32_t n) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i < n) { out_len[i] = 0u; status[i] = HDLZ_E_DYNAMIC_UNSUPPORTED; }
+}
+
 }  // namespace par
 
 // a.nstreams streams of at least HDLZ_INFLATE_PAR_MIN bytes each (fixed pitch form): the parallel chain -- every kernel once, blockIdx.y =
 // the stream --, then the serial decoder for what it gave up on: ONE stream: one wave, only if needed; several: the streams the chain
 // flagged (status HDLZ_E_DYNAMIC_UNSUPPORTED, as pass 1 of the batch kernels flags them)
-hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used) {
-    using namespace par;
-    *used = false;
-    const uint32_t zn = a.in_len;
-    const uint32_t nstr = (uint32_t)a.nstreams;
-    if (a.nstreams == 0 || a.nstreams > 65535u) return hipSuccess;
-    const uint64_t cap64 = a.out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00ull : a.out_pitch;
-    uint64_t srcn = (uint64_t)zn * 172u + 258u;            // a token of 13 bits makes at most 258 bytes
-    if (srcn > cap64) srcn = cap64;
-    if (srcn > (1ull << 30)) return hipSuccess;            // (4 GiB of scratch: leave it to the serial decoder)
+namespace par {
+// the scratch of ONE stream of the launch: every array of the chain, each aligned to 256 bytes (so `stride` is a multiple of 256 and
+// every stream's arrays are aligned like the first one's)
+struct Layout {
+    uint32_t chbits, nchunks, sub, ngroups;
+    uint64_t cap64, srcn;
+    size_t o_ctl, o_ex, o_nb, o_en, o_op, o_gx, o_gs, o_gn, o_ge, o_go, o_mx, o_mn, o_fe, o_fo, o_tk, o_nt, o_sa, o_me, o_rp, o_cp, o_cx, o_cn,
+           o_cmx, o_cmn, stride;
+    bool ok;
+};
+static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch) {
+    Layout L;
+    memset(&L, 0, sizeof(L));
+    L.cap64 = out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00ull : out_pitch;
+    L.srcn = (uint64_t)zn * 172u + 258u;                   // a token of 13 bits makes at most 258 bytes
+    if (L.srcn > L.cap64) L.srcn = L.cap64;
+    if (L.srcn > (1ull << 30)) return L;                   // (4 GiB of scratch: leave it to the serial decoder)
     // (with the de-duplicated speculation: 1024-bit pieces 1.10 ms at 16 MiB -- markers, scans --, 4096 bits with 8 sub-pieces 0.67, these 0.64)
     // measured with the final kernels, 1 / 4 / 16 MiB of output: 1024-bit pieces 0.191 / 0.328 / 1.00 ms, 2048 bits 0.241 / 0.286 / 0.65, 4096 bits 0.317 / 0.361 / 0.571
     // (the piece size follows the bytes of the whole LAUNCH: 256 streams of 1 MiB are cut like one stream of 256 MiB, not like 256 small ones)
@@ -840,23 +854,57 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
     const uint32_t ngroups = (nchunks + GROUP - 1u) / GROUP;
-    const size_t o_ctl = take(4u * C_WORDS), o_ex = take((size_t)nchunks * 32u), o_nb = take((size_t)nchunks * 128u),
-                 o_en = take(nchunks), o_op = take((size_t)nchunks * 4u), o_gx = take((size_t)ngroups * 32u), o_gs = take((size_t)ngroups * 32u),
-                 o_gn = take((size_t)ngroups * 128u), o_ge = take(ngroups), o_go = take((size_t)ngroups * 4u),
-                 o_mx = take((size_t)nchunks * (sub - 1u) * 32u), o_mn = take((size_t)nchunks * (sub - 1u) * 128u),
-                 o_fe = take((size_t)nchunks * sub), o_fo = take((size_t)nchunks * sub * 4u),
-                 o_tk = take((size_t)nchunks * sub * tmax_of(chbits / sub) * 4u), o_nt = take((size_t)nchunks * sub * 4u), o_sa = take((size_t)srcn * 4u),
-                 o_me = take((size_t)nchunks * 4u),
-                 o_rp = take((size_t)nchunks * 128u), o_cp = take((size_t)nchunks * 128u), o_cx = take((size_t)nchunks * 32u),
-                 o_cn = take((size_t)nchunks * 128u), o_cmx = take((size_t)nchunks * 32u * (sub - 1u)), o_cmn = take((size_t)nchunks * 128u * (sub - 1u));
-    uint8_t* ws = nullptr;
-    const size_t stride = off;                                  // (a multiple of 256: every stream's arrays are aligned like the first one's)
-    // more than 4 GiB of scratch: the batch goes through in groups of streams, one chain of launches each (a group of that size fills the
-    // GPU as well; its scratch is the one the group in front of it gave back, stream-ordered)
+    L.chbits = chbits; L.nchunks = nchunks; L.sub = sub; L.ngroups = ngroups;
+    L.o_ctl = take(4u * C_WORDS); L.o_ex = take((size_t)nchunks * 32u); L.o_nb = take((size_t)nchunks * 128u);
+    L.o_en = take(nchunks); L.o_op = take((size_t)nchunks * 4u); L.o_gx = take((size_t)ngroups * 32u); L.o_gs = take((size_t)ngroups * 32u);
+    L.o_gn = take((size_t)ngroups * 128u); L.o_ge = take(ngroups); L.o_go = take((size_t)ngroups * 4u);
+    L.o_mx = take((size_t)nchunks * (sub - 1u) * 32u); L.o_mn = take((size_t)nchunks * (sub - 1u) * 128u);
+    L.o_fe = take((size_t)nchunks * sub); L.o_fo = take((size_t)nchunks * sub * 4u);
+    L.o_tk = take((size_t)nchunks * sub * tmax_of(chbits / sub) * 4u); L.o_nt = take((size_t)nchunks * sub * 4u); L.o_sa = take((size_t)L.srcn * 4u);
+    L.o_me = take((size_t)nchunks * 4u);
+    L.o_rp = take((size_t)nchunks * 128u); L.o_cp = take((size_t)nchunks * 128u); L.o_cx = take((size_t)nchunks * 32u);
+    L.o_cn = take((size_t)nchunks * 128u); L.o_cmx = take((size_t)nchunks * 32u * (sub - 1u)); L.o_cmn = take((size_t)nchunks * 128u * (sub - 1u));
+    L.stride = off;
+    L.ok = true;
+    return L;
+}
+}  // namespace par
+
+// what the path asks for when all `nstreams` streams go through it at once (less: it runs them in groups, or not at all)
+size_t inflate_par_work_bytes(uint32_t in_len, uint64_t nstreams, uint64_t out_pitch) {
+    if (nstreams == 0 || nstreams > 65535u || in_len < HDLZ_INFLATE_PAR_MIN) return 0;
+    const par::Layout L = par::layout_of(in_len, (uint32_t)nstreams, out_pitch);
+    if (!L.ok) return 0;
     constexpr size_t BUDGET = (size_t)4 << 30;
+    const size_t all = L.stride * (size_t)nstreams;
+    return all > BUDGET && nstreams > 1 ? (BUDGET / L.stride ? (BUDGET / L.stride) * L.stride : L.stride) : all;
+}
+
+hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used, const Work& w) {
+    using namespace par;
+    *used = false;
+    const uint32_t zn = a.in_len;
+    const uint32_t nstr = (uint32_t)a.nstreams;
+    if (a.nstreams == 0 || a.nstreams > 65535u) return hipSuccess;
+    const Layout L = layout_of(zn, nstr, a.out_pitch);
+    if (!L.ok) return hipSuccess;
+    const uint64_t cap64 = L.cap64, srcn = L.srcn;
+    const uint32_t chbits = L.chbits, nchunks = L.nchunks, sub = L.sub, ngroups = L.ngroups;
+    const size_t o_ctl = L.o_ctl, o_ex = L.o_ex, o_nb = L.o_nb, o_en = L.o_en, o_op = L.o_op, o_gx = L.o_gx, o_gs = L.o_gs, o_gn = L.o_gn,
+                 o_ge = L.o_ge, o_go = L.o_go, o_mx = L.o_mx, o_mn = L.o_mn, o_fe = L.o_fe, o_fo = L.o_fo, o_tk = L.o_tk, o_nt = L.o_nt,
+                 o_sa = L.o_sa, o_me = L.o_me, o_rp = L.o_rp, o_cp = L.o_cp, o_cx = L.o_cx, o_cn = L.o_cn, o_cmx = L.o_cmx, o_cmn = L.o_cmn;
+    uint8_t* ws = nullptr;
+    const size_t stride = L.stride;
+    // more scratch than the budget (4 GiB from the library's pool; the caller's buffer otherwise): the batch goes through in groups of
+    // streams, one chain of launches each (its scratch is the one the group in front of it used: the launches are stream-ordered).
+    // NOTE the piece size follows the group's bytes, so a group is laid out again by the recursive call.
+    const size_t BUDGET = w.caller ? w.bytes : (size_t)4 << 30;
+    if (stride > BUDGET) return hipSuccess;                     // not even one stream: the caller's other paths
     if (nstr > 1u && stride * (size_t)nstr > BUDGET) {
-        const uint32_t gs = (uint32_t)(BUDGET / stride);
-        if (gs == 0u) return hipSuccess;                        // (cannot happen: one stream's scratch is below 4 GiB + its pieces)
+        uint32_t gs = (uint32_t)(BUDGET / stride);
+        // (a smaller group may be cut into smaller pieces with more lists per byte: shrink until the group's own layout fits)
+        while (gs > 1u && layout_of(zn, gs, a.out_pitch).stride * (size_t)gs > BUDGET) gs = gs * 3u / 4u;
+        if (gs == 0u || layout_of(zn, gs, a.out_pitch).stride * (size_t)gs > BUDGET) return hipSuccess;
         if (gs < nstr) {
             for (uint32_t s0 = 0; s0 < nstr; s0 += gs) {
                 InflateArgs g = a;
@@ -866,17 +914,33 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                 g.out_len = a.out_len + s0;
                 g.status = a.status + s0;
                 g.nstreams = nstr - s0 < gs ? nstr - s0 : gs;
+                // (the last, smaller group could be laid out with smaller pieces and need more per stream than fits)
+                if (layout_of(zn, (uint32_t)g.nstreams, a.out_pitch).stride * (size_t)g.nstreams > BUDGET) {
+                    if (s0 == 0) return hipSuccess;
+                    // hand the rest to the batch kernels: mark them as the chain's give-ups
+                    hipLaunchKernelGGL(k_par_flag_rest, dim3((unsigned)((g.nstreams + 63u) / 64u)), dim3(64), 0, stream, g.out_len, g.status, (uint32_t)g.nstreams);
+                    hipError_t er = hipGetLastError();
+                    if (er == hipSuccess) er = launch_inflate_dyn_flagged(g, stream);
+                    if (er != hipSuccess) return er;
+                    continue;
+                }
                 bool u = false;
-                const hipError_t eg = launch_inflate_par(g, stream, &u);
+                const hipError_t eg = launch_inflate_par(g, stream, &u, w);
                 if (eg != hipSuccess) return eg;
-                // (a group without scratch: the caller's batch kernels redo the whole batch, which is harmless)
-                if (!u) return hipSuccess;
+                // (a first group without scratch: the caller's batch kernels redo the whole batch, which is harmless)
+                if (!u) {
+                    if (s0 == 0) return hipSuccess;
+                    hipLaunchKernelGGL(k_par_flag_rest, dim3((unsigned)((g.nstreams + 63u) / 64u)), dim3(64), 0, stream, g.out_len, g.status, (uint32_t)g.nstreams);
+                    hipError_t er = hipGetLastError();
+                    if (er == hipSuccess) er = launch_inflate_dyn_flagged(g, stream);
+                    if (er != hipSuccess) return er;
+                }
             }
             *used = true;
             return hipSuccess;
         }
     }
-    hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), stride * nstr, stream);
+    hipError_t e = w.get(stride * nstr, stream, &ws);
     if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // no scratch: the caller goes on with the serial decoder
     {
         ParArgs p{a.in, zn, a.flags, a.obsize, a.out, (uint32_t)cap64, (uint32_t)srcn, a.out_len, a.status, nchunks, chbits,
@@ -920,7 +984,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         if (e == hipSuccess) e = nstr == 1u ? launch_inflate_dyn(a, stream, true, p.ctl + C_OK, 1u) : launch_inflate_dyn_flagged(a, stream);
         *used = true;
     }
-    const hipError_t e2 = hipFreeAsync(ws, stream);
+    const hipError_t e2 = w.put(ws, stream);
     return e != hipSuccess ? e : e2;
 }
 

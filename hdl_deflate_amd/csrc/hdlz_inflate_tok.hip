@@ -1,10 +1,10 @@
 // hdlz_inflate_tok.hip -- STARTD for a batch of independent zlib streams, one LANE per stream, TOKENS (not bytes) per round.
 //
-// Same contract and same reference lines as hdlz_inflate.hip (/root/reference/deflate.py:635-732 IDLE/HEADER, :1402-1445 NEXT,
-// :1519-1591 INFLATE, :1593-1659 COPY, :517-533 get4/adv); rule names D0..D8 are SURVEY.md 8(a)'s.  k_inflate (round 1) runs its 64
-// streams in lockstep ONE OUTPUT BYTE per iteration, which keeps the output offset wave-uniform -- but every iteration pays the
-// whole token decode (~50 VALU + ~40 SALU instructions) although only the lanes standing at a token boundary need it: with
-// ~6 bytes per token the decode is paid six times.  Here a ROUND decodes, in every lane, up to three literals and the match behind
+// Replaces the reference's inflate FSM (/root/reference/deflate.py:635-732 IDLE/HEADER, :1402-1445 NEXT, :1519-1591 INFLATE,
+// :1593-1659 COPY, :517-533 get4/adv); rule names D0..D8 are SURVEY.md 8(a)'s.  Inflate is serial per stream, so the parallelism is
+// ACROSS streams: 64 per wave.  (Round 1's kernel ran them in lockstep ONE OUTPUT BYTE per iteration -- the reference's COPY state
+// moves one byte per clock too, deflate.py:1627-1659 -- and paid the whole token decode, ~50 VALU + ~40 SALU instructions, every
+// iteration although only the lanes at a token boundary need it; it was slower everywhere measured and left with round 6.)  Here a ROUND decodes, in every lane, up to three literals and the match behind
 // them, and a short loop moves the bytes: up to four per lane and iteration (the literals, or the next bytes of a copy out of the
 // ring) and, behind the loop, up to sixteen bytes of far history in one step, so the decode is paid once per token.  What changes with it:
 //   * every lane has its own output position.  The ring stays lane-interleaved (dword w of lane l at dword index w*64 + l: each
@@ -14,8 +14,11 @@
 //     full 64-byte sector per lane); flushes are batched: they run when a quarter of the wave is ready or one lane is about to overrun;
 //   * near history (distance <= 112) is read from the ring, far history from the stream's own flushed output (one 16-byte load
 //     when the token is decoded, taken a round later; a longer far copy asks for its next 16 bytes when it takes the last ones);
-//   * input arrives through 16-byte LDS-DMA slots per lane (hdlz_inflate.hip explains the ordering rule).
-// Status codes and the ORDER of the reference's checks are those of k_inflate: the slow path is the same code.
+//   * input arrives through 16-byte LDS-DMA slots per lane.  The ordering rule: with the next bytes prefetched into a VGPR the wave
+//     would wait for ITS LATEST load before any lane could consume an OLDER one (s_waitcnt counts instructions, not lanes); an LDS-DMA
+//     load has no destination VGPR, so the compiler adds no wait, and the consumer waits by hand -- loads complete in order, so a
+//     request with `after` LDS-DMA instructions issued behind it has landed once at most `after` loads are outstanding.
+// Status codes follow the ORDER of the reference's checks: the wave-uniform slow path (headers, EOB, stored blocks, failing checks).
 //
 // DYN = true is the same kernel for streams with DYNAMIC-TREE blocks (BTYPE = 2; deflate.py:1084-1202 BL/READBL/REPEAT, :1204-1400
 // HF1..HF4/SPREAD, :1447-1517 D_NEXT), the second pass over the streams the first one flagged HDLZ_E_DYNAMIC_UNSUPPORTED.  A lane
@@ -1015,7 +1018,14 @@ static hipError_t bin_streams(const uint64_t* in_off, uint32_t n, uint32_t* bins
 
 }  // namespace tok
 
-hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
+size_t inflate_tok_work_bytes(uint64_t nstreams, bool ragged) {
+    if (nstreams == 0 || nstreams > 0xFFFFFFFFull) return 0;
+    const size_t pass1 = ragged && nstreams > HDLZ_INFLATE_BIN_MIN ? sizeof(uint32_t) * ((size_t)nstreams + tok::BIN_WORDS) : 0u;
+    const size_t pass2 = sizeof(uint32_t) * ((size_t)2u + tok::BIN_WORDS + nstreams + (ragged && nstreams > HDLZ_INFLATE_BIN_MIN ? (size_t)nstreams : 0u));
+    return ((pass1 > pass2 ? pass1 : pass2) + 255u) & ~(size_t)255u;
+}
+
+hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream, const Work& w) {
     if (a.nstreams == 0) return hipSuccess;
     typedef tok::Lds<false, tok::CAP_FULL> L;
     const uint64_t per_wg = 64u * L::WAVES;
@@ -1024,7 +1034,7 @@ hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
     if (a.in_off && a.nstreams > HDLZ_INFLATE_BIN_MIN && a.nstreams <= 0xFFFFFFFFull) {
         uint32_t* ws = nullptr;                  // ws[0 .. BIN_WORDS): the bins (see tok::BIN_WORDS); the list behind them
         const uint32_t n = (uint32_t)a.nstreams;
-        hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * ((size_t)n + tok::BIN_WORDS), stream);
+        hipError_t e = w.get(sizeof(uint32_t) * ((size_t)n + tok::BIN_WORDS), stream, reinterpret_cast<uint8_t**>(&ws));
         if (e == hipSuccess) {
             e = tok::bin_streams(a.in_off, n, ws, ws + tok::BIN_WORDS, stream);
             if (e == hipSuccess) {
@@ -1033,7 +1043,7 @@ hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
                                    (const uint32_t*)(ws + tok::NBIN), (const uint32_t*)nullptr);
                 e = hipGetLastError();
             }
-            const hipError_t e2 = hipFreeAsync(ws, stream);
+            const hipError_t e2 = w.put(reinterpret_cast<uint8_t*>(ws), stream);
             return e != hipSuccess ? e : e2;
         }
         (void)hipGetLastError();                 // no scratch: stream order
@@ -1048,7 +1058,7 @@ hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream) {
 // the ones it leaves flagged -- a literal/length code of more than CAP_SMALL symbols, or a fixed block between dynamic ones --
 // are collected again and go through the CAP_FULL build.  Either stage hands its streams to k_inflate_dyn (one wave each) when
 // they are fewer than `lane_min`; the counts stay on the device.  The lists live in stream-ordered scratch (4 bytes per stream).
-hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool all) {
+hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool all, const Work& w) {
     if (a.nstreams == 0 || (a.flags & HDLZ_INFLATE_ASSUME_FIXED)) return hipSuccess;
     const dim3 grid((unsigned)((a.nstreams + 63u) / 64u)), block(64);
     const dim3 cgrid((unsigned)((a.nstreams + 255u) / 256u)), cblock(256);
@@ -1063,7 +1073,7 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
     const bool binned = a.in_off != nullptr && a.nstreams > HDLZ_INFLATE_BIN_MIN && a.nstreams <= 0xFFFFFFFFull && !all;   // (32-bit stream ids in the lists)
     const uint32_t head = 2u + tok::BIN_WORDS;
     const size_t nws = (size_t)head + a.nstreams + (binned ? (size_t)a.nstreams : 0u);
-    hipError_t e = scratch_alloc(reinterpret_cast<void**>(&ws), sizeof(uint32_t) * nws, stream);
+    hipError_t e = w.get(sizeof(uint32_t) * nws, stream, reinterpret_cast<uint8_t**>(&ws));
     if (e != hipSuccess) {                      // no scratch: the wave-per-stream pass needs none and finishes the job
         (void)hipGetLastError();
         return launch_inflate_dyn(a, stream, all);
@@ -1107,9 +1117,8 @@ hipError_t launch_inflate_tok_dyn(const InflateArgs& a, hipStream_t stream, bool
         e = hipGetLastError();
         if (e == hipSuccess && lane_min != 0u) e = launch_inflate_dyn(a, stream, false, ws + 1, lane_min);
     }
-    const hipError_t e2 = hipFreeAsync(ws, stream);
+    const hipError_t e2 = w.put(reinterpret_cast<uint8_t*>(ws), stream);
     return e != hipSuccess ? e : e2;
 }
-
 
 }  // namespace hdlz

@@ -67,8 +67,10 @@ class Engine(object):
             if max_len is None:
                 max_len = ilen if in_off is None else int((in_off[1:] - in_off[:-1]).max().item()) if nb else 0
             out_pitch = pitch_for(max_len)
-        if in_off is not None and max_len is not None:
-            ilen = max_len               # ragged: upper bound on the block lengths (lets the library pack small blocks)
+        if in_off is not None:
+            # ragged: the bound the library gets is `max_len` (it packs small blocks per wave from it and gives a LONGER block
+            # HDLZ_E_BAD_PARAM); `in_len` is not a bound here, as before round 5
+            ilen = max_len if max_len is not None else 0
         if out is None:
             out = torch.empty((nb, out_pitch), dtype=torch.uint8, device=d_in.device)
         out_len = torch.empty(nb, dtype=torch.int32, device=d_in.device)
@@ -117,10 +119,13 @@ class Engine(object):
     # -- STARTD for a batch
     @_on_device
     def inflate_batch(self, d_in, in_off=None, in_len=None, nblocks=None, out_pitch=None, flags=0, obsize=0,
-                      out=None):
+                      out=None, work=None):
         """STARTD for a batch: d_in uint8 [B, pitch] (a stream per row, `in_len` bytes of it: default the pitch) or flat uint8 with in_off
-        int64[B + 1] -- then `in_len`, if given, is an UPPER BOUND on the stream lengths: with it a batch of up to 4096 streams (1024
-        below 16 KiB) can take the whole-GPU path (a stream longer than the bound is still decoded, by the serial pass).
+        int64[B + 1] -- then `in_len`, if given, is an UPPER BOUND on the stream lengths: with it a batch of large streams can take
+        the whole-GPU path (a stream longer than the bound is still decoded, by the serial pass).
+        `work`: the call's scratch, a uint8 device tensor (hdlz_inflate_batch_ws: the library allocates nothing); default: a tensor of
+        hdlz_inflate_work_bytes(...) bytes from torch's allocator, stream-ordered like every other tensor of the call; a smaller one
+        (or an empty one) gives the same results through mappings that need less.
         -> (out uint8[B, out_pitch], out_len int32[B], status int32[B]); per-stream failures are statuses."""
         off_ptr, pitch, ilen, nb = self._prep(d_in, in_off, in_len, nblocks)
         assert out_pitch is not None and out_pitch % 4 == 0
@@ -128,10 +133,14 @@ class Engine(object):
             out = torch.empty((nb, out_pitch), dtype=torch.uint8, device=d_in.device)
         out_len = torch.empty(nb, dtype=torch.int32, device=d_in.device)
         status = torch.empty(nb, dtype=torch.int32, device=d_in.device)
-        rc = self.lib.hdlz_inflate_batch(d_in.data_ptr(), off_ptr, pitch, ilen, nb, flags, obsize,
-                                         out.data_ptr(), out_pitch, out_len.data_ptr(), status.data_ptr(),
-                                         self._stream())
-        self._check(rc, "hdlz_inflate_batch")
+        if work is None:
+            work = torch.empty(self.lib.hdlz_inflate_work_bytes(nb, ilen, out_pitch, flags, 0 if in_off is None else 1),
+                               dtype=torch.uint8, device=d_in.device)
+        assert work.is_cuda and work.dtype == torch.uint8 and work.is_contiguous() and work.device == self.device
+        rc = self.lib.hdlz_inflate_batch_ws(d_in.data_ptr(), off_ptr, pitch, ilen, nb, flags, obsize,
+                                            out.data_ptr(), out_pitch, out_len.data_ptr(), status.data_ptr(),
+                                            work.data_ptr() if work.numel() else None, work.numel(), self._stream())
+        self._check(rc, "hdlz_inflate_batch_ws")
         return out, out_len, status
 
     # -- archive compaction
@@ -158,7 +167,7 @@ class Engine(object):
         return archive, offsets
 
     @_on_device
-    def archive(self, rows, lens, archive=None, offsets=None):
+    def archive(self, rows, lens, archive=None, offsets=None, work=None):
         """rows uint8[B, pitch], lens int32[B] -> (archive uint8[cap], offsets int64[B + 1]) in ONE launch (hdlz_archive_batch): the
         exclusive scan of the lengths is made on the device, offsets[B] is the archive's length (no host sync: read it when needed),
         offsets is directly the `in_off` of a ragged inflate / compress call.  `archive` defaults to a buffer of B * pitch bytes."""
@@ -172,9 +181,11 @@ class Engine(object):
             offsets = torch.empty(B + 1, dtype=torch.int64, device=rows.device)
         assert archive.is_cuda and archive.dtype == torch.uint8 and archive.is_contiguous()
         assert offsets.is_cuda and offsets.dtype == torch.int64 and offsets.numel() == B + 1 and offsets.is_contiguous()
-        rc = self.lib.hdlz_archive_batch(rows.data_ptr(), pitch, lens.data_ptr(), B, archive.data_ptr(), archive.numel(),
-                                         offsets.data_ptr(), self._stream())
-        self._check(rc, "hdlz_archive_batch")
+        if work is None:                 # the call's scratch (8 bytes per 256 rows), caller-owned like every other buffer of the call
+            work = torch.empty(max(8, self.lib.hdlz_archive_work_bytes(B)) // 8, dtype=torch.int64, device=rows.device)
+        rc = self.lib.hdlz_archive_batch_ws(rows.data_ptr(), pitch, lens.data_ptr(), B, archive.data_ptr(), archive.numel(),
+                                            offsets.data_ptr(), work.data_ptr(), work.numel() * work.element_size(), self._stream())
+        self._check(rc, "hdlz_archive_batch_ws")
         return archive, offsets
 
     # -- the job from HOST buffers: the PCIe hops overlapped with the kernels

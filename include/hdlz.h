@@ -7,16 +7,23 @@
  * byte per clock through i_data/o_byte (deflate.py:599-605); here whole batches of independent
  * blocks are handed over as device buffers.  The Python port-protocol adapter
  * (hdl_deflate_amd/port.py) re-creates the IDLE/WRITE/READ/STARTC/STARTD surface on top of
- * these entry points; INTEGRATION.md shows the binding a reference maintainer would add.
+ * these entry points; INTEGRATION.md shows the binding a reference maintainer would add and
+ * keeps the history of this ABI (what changed in which version, measured crossovers).
  *
  * Conventions
- *   - every pointer named d_* is a DEVICE pointer (HBM); the library never allocates, frees or
- *     retains caller memory; all work is enqueued asynchronously on `stream` (a hipStream_t
- *     passed as void*; NULL = the default stream);
+ *   - every pointer named d_* is a DEVICE pointer (HBM); the library never frees or retains caller
+ *     memory; all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream);
+ *   - OWNERSHIP (the DUT owns only its own RAMs, deflate.py:229-230, :275-286): the caller
+ *     allocates every device buffer, scratch included -- the entry points that need scratch take it as
+ *     (d_work, work_bytes) next to a hdlz_*_work_bytes() query and allocate NOTHING, so they can be
+ *     captured into a HIP graph.  hdlz_inflate_batch / hdlz_archive_batch without d_work are conveniences
+ *     that draw the same scratch from a library-owned stream-ordered pool; NOT inside a graph capture
+ *     (they return HDLZ_E_BAD_PARAM there: graph memory nodes are unreliable on ROCm 7.2,
+ *     tools/repro/graph_scratch.hip);
  *   - block b of a batch is d_in[in_off[b] .. in_off[b+1]) when d_in_off != NULL, otherwise
- *     d_in[b*in_pitch .. b*in_pitch + in_len); with d_in_off, hdlz_compress_batch takes in_len as an optional
- *     upper bound on the block lengths (0 = unknown): a bound <= 1024 lets it pack several small blocks per wave
- *     (a block longer than a stated bound gets HDLZ_E_BAD_PARAM in its status word);
+ *     d_in[b*in_pitch .. b*in_pitch + in_len); with d_in_off, in_len is an optional UPPER BOUND on the
+ *     block lengths (0 = not stated), see the two batch calls;
  *   - output of block b goes to d_out + b*out_pitch; out_pitch % 4 == 0 and d_out 4-byte
  *     aligned (16 recommended); d_out_len[b] receives the byte count (the reference's final
  *     o_oprogress, deflate.py:814 / :1554), d_status[b] one of HDLZ_OK / HDLZ_E_*;
@@ -34,10 +41,7 @@
 extern "C" {
 #endif
 
-#define HDLZ_VERSION 0x000500   /* 0x000500, round 5: + a third inflate mapping, 16 lanes per stream with the stream's history in LDS (HDLZ_INFLATE_GROUP_PER_STREAM = 64,
-                                   the default for batches of HDLZ_INFLATE_GROUP_MIN .. _MAX streams); new compress kernels (same bytes).  0x000401: same ABI, new inflate lane kernels (register-queue refill, second token group per round): the PMC records
-                                   of profiles/traffic.json are tied to the version.  0x000400, round 4: + hdlz_release_scratch (bounded scratch pool); hdlz_compact_batch accepts a pinned-host destination; the opt-in
-                                   two-phase inflate of 0x000301 (HDLZ_INFLATE_TWO_PHASE = 64) was measured slower than the one-pass kernel and is gone */
+#define HDLZ_VERSION 0x000600   /* history: INTEGRATION.md 4 */
 
 /* command codes of the reference port surface (deflate.py:18) -- used by the adapter */
 enum { HDLZ_IDLE = 0, HDLZ_WRITE = 1, HDLZ_READ = 2, HDLZ_STARTC = 3, HDLZ_STARTD = 4 };
@@ -51,7 +55,7 @@ enum {
     HDLZ_E_BAD_BTYPE = 3,           /* "Bad method" (deflate.py:719-721) */
     HDLZ_E_BAD_DISTANCE = 4,        /* distance code 30/31, distance > bytes produced or > obsize (deflate.py:1506-1508, :1581) */
     HDLZ_E_NO_EOF = 5,              /* "NO EOF!" (deflate.py:1535-1539) or input exhausted (:1600-1602 would stall) */
-    HDLZ_E_DYNAMIC_UNSUPPORTED = 6, /* internal hand-over mark between the two inflate passes; never returned */
+    HDLZ_E_DYNAMIC_UNSUPPORTED = 6, /* internal hand-over mark between the inflate passes; never returned */
     HDLZ_E_BAD_SYMBOL = 7,          /* literal/length symbol 286/287 ("< 1 bits", deflate.py:1437-1439) */
     HDLZ_E_BAD_PARAM = 8,
     HDLZ_E_HIP = 9,                 /* HIP runtime error / no device; see hdlz_last_error() */
@@ -59,56 +63,25 @@ enum {
                                        builds garbage tables there, deflate.py:1204-1400; zlib's rules are used) */
 };
 
-/* inflate flags */
-#define HDLZ_INFLATE_ASSUME_FIXED 1u /* DYNAMIC=False build: every block is decoded as BTYPE=1 (deflate.py:724-732) */
-/* ONEBLOCK=True build (deflate.py:40-41; forced by LOWLUT, :43-49): BFINAL is never read (deflate.py:678) and the stream
- * ends at the end of its FIRST block -- EOB (deflate.py:1542) or the last stored byte (:1617) -- whatever follows */
-#define HDLZ_INFLATE_ONEBLOCK 8u
-/* mapping hints (results are identical): by default batches of at most HDLZ_INFLATE_WAVE_THRESHOLD streams are decoded
- * one wave per stream, larger ones one lane per stream, with a second pass for the streams that hold dynamic-tree blocks:
- * again one lane per stream when there are at least HDLZ_INFLATE_DYN_LANE_MIN of them (counted on the device), else one
- * wave per stream (measured crossovers on 2 KiB and 16 KiB streams, tools/bench_inflate_mapping.py) */
-#define HDLZ_INFLATE_LANE_PER_STREAM 2u
-#define HDLZ_INFLATE_WAVE_PER_STREAM 4u
-#define HDLZ_INFLATE_WAVE_THRESHOLD 22528u
-#define HDLZ_INFLATE_DYN_LANE_MIN 28672u
-/* lane mapping, ragged input (d_in_off given) of more than this many streams: the lanes take the streams in the order of their
- * compressed-length class (a counting sort on the device, 4 bytes per stream of stream-ordered scratch; stream order if that
- * allocation fails) -- a wave runs as long as its longest stream, so streams of similar length share a wave.  Results are
- * identical; the output rows stay where their stream index puts them. */
-#define HDLZ_INFLATE_BIN_MIN 64u
-/* a batch of ONE stream of at least this many bytes (fixed-pitch form, no mapping hint) is cut into 1 KiB pieces and decoded by
- * the whole GPU when it is a single fixed-Huffman block -- the streams STARTC writes --, else by one wave as before (decided on
- * the device, same results); scratch: stream-ordered, 4 bytes per possible output byte (min(out_pitch, 172 * in_len); 8 up to round 4).
- * A batch of up to HDLZ_INFLATE_PAR_BATCH_MAX such streams (fixed pitch, no mapping hint) goes through the same path, every kernel
- * launched ONCE for all of them (round 5; one chain of launches per stream before): the batch kernels decode a stream as one serial
- * chain -- 5.9 ms for a 64 KiB stream however few there are -- so 256 streams of 64 KiB take 0.48 ms instead of 5.9, 256 of 1 MiB 4.4 ms
- * instead of 42; from ~8192 streams on the batch kernels win (profiles/r05_inflate_mapping.txt).  Scratch as above, per stream (more than 4 GiB: the batch goes through in groups of streams).
- * Streams shorter than HDLZ_INFLATE_PAR_LONG take the path in batches of up to HDLZ_INFLATE_PAR_BATCH_SHORT_MAX (the chain of launches costs
- * ~0.12 ms: one 8 KiB stream 0.12 instead of 0.75 ms, 1024 streams of 2 KiB 0.21 instead of 0.33 ms; 4096 of them: the wave mapping wins).
- * (The threshold was 16384 up to the first builds of 0x000500: the path cost 0.35 ms then.)
- * Ragged input (d_in_off given): in_len, if not 0, is the caller's UPPER BOUND on the stream lengths and the thresholds above apply to it (0 =
- * not stated: the batch kernels, as before); a stream longer than the bound is decoded by the serial pass -- right, only slower.
- * While `stream` is being captured into a HIP graph only ONE fixed-pitch stream of >= HDLZ_INFLATE_PAR_LONG bytes takes the path (what it
- * took before round 5; a batch goes to the batch kernels): same results, see hdlz_api.hip. */
-#ifndef HDLZ_INFLATE_PAR_MIN          /* (A/B builds override it) */
-#define HDLZ_INFLATE_PAR_MIN 2048u
+/* ---- inflate flags (semantics) */
+#define HDLZ_INFLATE_ASSUME_FIXED 1u     /* DYNAMIC=False build: every block is decoded as BTYPE=1 (deflate.py:724-732) */
+#define HDLZ_INFLATE_ONEBLOCK 8u         /* ONEBLOCK=True build (deflate.py:40-49): BFINAL is not read, the stream ends with its FIRST block */
+/* ---- inflate flags (mapping hints: results are identical; at most one; none = chosen from the batch's shape) */
+#define HDLZ_INFLATE_LANE_PER_STREAM 2u  /* 64 streams per wave (k_inflate_tok) + a second pass for streams with dynamic-tree blocks */
+#define HDLZ_INFLATE_WAVE_PER_STREAM 4u  /* one wave per stream (k_inflate_dyn), any block type */
+#define HDLZ_INFLATE_GROUP_PER_STREAM 64u /* 16 lanes per stream, history in LDS (k_inflate_grp) + the second pass */
+/* ---- the shapes the default mapping switches at (measured crossovers; provenance: INTEGRATION.md 4) */
+#define HDLZ_INFLATE_WAVE_THRESHOLD 22528u   /* up to this many streams: a wave per stream */
+#define HDLZ_INFLATE_DYN_LANE_MIN 28672u     /* second pass: a lane per stream from this many flagged streams on, else a wave each */
+#define HDLZ_INFLATE_BIN_MIN 64u             /* lane mapping, ragged input of more streams than this: lanes take the streams ordered by length class */
+#define HDLZ_INFLATE_GROUP_MIN 8192u         /* 16 lanes per stream for batches of GROUP_MIN .. GROUP_MAX streams */
+#define HDLZ_INFLATE_GROUP_MAX 16384u
+#ifndef HDLZ_INFLATE_PAR_MIN                 /* (A/B builds override it) */
+#define HDLZ_INFLATE_PAR_MIN 2048u           /* whole-GPU path (k_par_*): streams of at least this many bytes (in_len; ragged: the stated bound) ... */
 #endif
-#define HDLZ_INFLATE_PAR_LONG 16384u
+#define HDLZ_INFLATE_PAR_LONG 16384u         /* ... up to PAR_BATCH_MAX of them when in_len >= PAR_LONG, else up to PAR_BATCH_SHORT_MAX */
 #define HDLZ_INFLATE_PAR_BATCH_MAX 4096u
 #define HDLZ_INFLATE_PAR_BATCH_SHORT_MAX 1024u
-/* 16 lanes per stream (hdlz_inflate_grp.hip; round 5): the stream's history in a 2 KiB LDS ring, input and output in full lines, four
- * streams per wave -- the mapping for batches too small to fill the GPU one lane per stream and too large to give every stream a
- * wave: the default for HDLZ_INFLATE_GROUP_MIN <= nstreams <= HDLZ_INFLATE_GROUP_MAX (measured crossovers, tools/bench_inflate_mapping.py),
- * and for any batch when the flag is given.  Streams with dynamic-tree blocks take the usual second pass.  (The value 64 was the
- * two-phase inflate of 0x000301, rejected as unknown by 0x000400 / 0x000401.) */
-#define HDLZ_INFLATE_GROUP_PER_STREAM 64u
-#define HDLZ_INFLATE_GROUP_MIN 8192u
-#define HDLZ_INFLATE_GROUP_MAX 16384u
-/* lane-per-stream kernel variant (results are identical): the default and 16 = one token per round (k_inflate_tok),
- * 32 = one output byte per lockstep iteration (k_inflate, the round-1 kernel) */
-#define HDLZ_INFLATE_TOKEN_ROUNDS 16u
-#define HDLZ_INFLATE_BYTE_LOCKSTEP 32u
 
 int hdlz_version(void);
 const char* hdlz_status_string(int status);
@@ -121,10 +94,8 @@ int hdlz_device_count(void);
  * per literal + 7 EOB bits, padded, + 4 Adler bytes = 6 + ceil((9n+10)/8)  (SURVEY 8(a)). */
 size_t hdlz_out_bound(size_t n);
 
-/* The calls that need stream-ordered scratch (the dynamic-tree pass of the lane mapping, the parallel single-stream inflate) draw it
- * from the library's own per-device memory pool, which keeps up to 256 MiB cached between calls (a fresh device allocation per call
- * costs 10-40 ms) and returns anything above that to the device when the stream synchronises.  hdlz_release_scratch() gives the
- * cached rest of the CURRENT device back as well (e.g. before the caller's own large allocations).  HDLZ_OK / HDLZ_E_HIP. */
+/* The library-owned scratch pool behind the entry points WITHOUT d_work keeps up to 256 MiB cached between calls and returns
+ * anything above that to the device when the stream synchronises; this gives the cached rest of the CURRENT device back as well. */
 int hdlz_release_scratch(void);
 
 /*
@@ -136,6 +107,8 @@ int hdlz_release_scratch(void);
  * :423-515 (fill_buf).  Output is bit-identical to the reference for the same
  * (bytes, CWINDOW, MATCH10): cwindow in [1,256] (reference builds: 32 FAST/LOWLUT, 256
  * otherwise, deflate.py:56-59), maxmatch 10 (MATCH10=True) or 5 (deflate.py:34-35).
+ * Ragged input: a stated bound in_len <= 1024 lets the call pack several small blocks per wave; a block longer
+ * than a stated bound gets HDLZ_E_BAD_PARAM in its status word.  Needs no scratch.
  */
 int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
                         uint64_t nblocks, int cwindow, int maxmatch, uint8_t* d_out, uint64_t out_pitch,
@@ -143,21 +116,27 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
 
 /*
  * STARTD for a batch of independent zlib streams: 2 header bytes skipped unvalidated, blocks
- * until BFINAL, stored (BTYPE 0), fixed-Huffman (BTYPE 1) and dynamic-tree (BTYPE 2, deflate.py:1084-1517;
- * handled by a second pass over the streams that hold such blocks -- see the mapping hints above; in the lane
- * mapping that pass runs in two stages, the second one for the few streams whose block codes more than 144
- * literal/length symbols, and keeps the list of its streams in stream-ordered scratch memory, hipMallocAsync /
- * hipFreeAsync on `stream`, 4 bytes per stream (if that allocation fails the wave mapping finishes the job); the
- * parallel path for ONE large stream or up to HDLZ_INFLATE_PAR_BATCH_MAX of them -- HDLZ_INFLATE_PAR_MIN below -- allocates 4 bytes per possible
- * output byte the same way, whatever the flags; no other case allocates, and every case stays capturable into a HIP
- * graph) blocks, 4 trailer bytes required
- * but Adler-32 not verified -- exactly the reference's acceptance (deflate.py:635-651 IDLE/STARTD,
- * :656-732 HEADER, :1402-1445 NEXT, :1519-1591 INFLATE, :1593-1659 COPY, :517-533 get4/adv).
+ * until BFINAL -- stored (BTYPE 0), fixed-Huffman (BTYPE 1) and dynamic-tree (BTYPE 2, deflate.py:1084-1517) --,
+ * 4 trailer bytes required but Adler-32 not verified: exactly the reference's acceptance (deflate.py:635-651
+ * IDLE/STARTD, :656-732 HEADER, :1402-1445 NEXT, :1519-1591 INFLATE, :1593-1659 COPY, :517-533 get4/adv).
  * `obsize` != 0 selects the reference-exact behaviour of an OBSIZE build (deflate.py:61-62):
  * back-references may reach at most obsize bytes and a stored block's LEN is taken modulo
  * 2^floor(log2(obsize)) because the reference's `length` register is LOBSIZE bits wide
  * (deflate.py:329, :714).  obsize == 0 = RFC1951 behaviour (32 KiB history, 16-bit LEN).
+ * Ragged input: in_len, if not 0, is the caller's UPPER BOUND on the stream lengths (the whole-GPU path sizes its pieces from it;
+ * a stream longer than the bound is still decoded, by the serial pass).
+ *
+ * hdlz_inflate_batch_ws: the call with CALLER-OWNED scratch.  d_work: device memory, 256-byte aligned, work_bytes long, used only
+ * during the call's own launches (stream-ordered: it may be reused by the next call on the same stream).
+ * hdlz_inflate_work_bytes(nstreams, in_len, out_pitch, flags, ragged) is what the fastest mapping of that shape uses; with LESS
+ * (down to d_work = NULL) the call still succeeds with the same results through mappings that need less: the whole-GPU path runs the
+ * streams in groups that fit or is skipped, the lane mapping takes the streams in index order, the second pass runs a wave per stream.
+ * Nothing is allocated; every launch is capturable.  hdlz_inflate_batch is the same call with scratch from the library's pool.
  */
+size_t hdlz_inflate_work_bytes(uint64_t nstreams, uint32_t in_len, uint64_t out_pitch, uint32_t flags, int ragged);
+int hdlz_inflate_batch_ws(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
+                          uint64_t nstreams, uint32_t flags, uint32_t obsize, uint8_t* d_out, uint64_t out_pitch,
+                          uint32_t* d_out_len, uint32_t* d_status, void* d_work, size_t work_bytes, void* stream);
 int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t in_pitch, uint32_t in_len,
                        uint64_t nstreams, uint32_t flags, uint32_t obsize, uint8_t* d_out, uint64_t out_pitch,
                        uint32_t* d_out_len, uint32_t* d_status, void* stream);
@@ -166,18 +145,23 @@ int hdlz_inflate_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
  * Archive compaction (no reference counterpart -- the reference drains its output
  * one byte per READ, deflate.py:601): copies d_len[b] bytes of row b (d_rows + b*row_pitch) to
  * d_archive + d_off[b].  d_off is the exclusive scan of the lengths, computed by the caller (across GPUs:
- * after the all-gather of the lengths).  Works for compress and inflate outputs alike.
+ * after the all-gather of the lengths).  Works for compress and inflate outputs alike; d_archive may be pinned host memory.
  */
 int hdlz_compact_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, const uint64_t* d_off,
                        uint64_t nblocks, uint8_t* d_archive, void* stream);
 
 /*
- * The same gather with the scan inside (round 5): d_off[0 .. nblocks] is WRITTEN -- d_off[b] = sum of d_len[0 .. b), d_off[nblocks] =
+ * The same gather with the scan inside: d_off[0 .. nblocks] is WRITTEN -- d_off[b] = sum of d_len[0 .. b), d_off[nblocks] =
  * the archive's length -- and row b is copied to d_archive + d_off[b], all in one launch (a ticketed decoupled look-back over tiles
- * of 256 rows; stream-ordered scratch: 8 bytes per tile).  d_off is at once the ragged-input index hdlz_inflate_batch / hdlz_compress_batch
- * take (d_in_off).  archive_cap: bytes writable at d_archive; rows that would end beyond it are not copied -- compare d_off[nblocks]
- * with archive_cap after the call (sum of row bounds = always enough).  d_archive must be device memory.  nblocks < 2^31.
+ * of 256 rows).  d_off is at once the ragged-input index hdlz_inflate_batch / hdlz_compress_batch take (d_in_off).  archive_cap:
+ * bytes writable at d_archive; rows that would end beyond it are not copied -- compare d_off[nblocks] with archive_cap after the
+ * call (sum of row bounds = always enough).  d_archive must be device memory.  nblocks < 2^31.
+ * _ws: d_work of at least hdlz_archive_work_bytes(nblocks) bytes (8 per tile of 256 rows), 8-byte aligned, REQUIRED (else
+ * HDLZ_E_BAD_PARAM); nothing is allocated.  hdlz_archive_batch takes the same scratch from the library's pool.
  */
+size_t hdlz_archive_work_bytes(uint64_t nblocks);
+int hdlz_archive_batch_ws(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, uint64_t nblocks,
+                          uint8_t* d_archive, uint64_t archive_cap, uint64_t* d_off, void* d_work, size_t work_bytes, void* stream);
 int hdlz_archive_batch(const uint8_t* d_rows, uint64_t row_pitch, const uint32_t* d_len, uint64_t nblocks,
                        uint8_t* d_archive, uint64_t archive_cap, uint64_t* d_off, void* stream);
 

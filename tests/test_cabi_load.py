@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_bound_and_strings():
     from hdl_deflate_amd import _lib, out_bound
     L = _lib.load()
-    assert L.hdlz_version() == 0x000500
+    assert L.hdlz_version() == 0x000600
     for n in (0, 5, 256, 2048, 65536, 1 << 24):
         assert L.hdlz_out_bound(n) == out_bound(n) == 6 + (9 * n + 10 + 7) // 8
     assert L.hdlz_status_string(0) == b"OK" and b"SHORT" in L.hdlz_status_string(1)
@@ -49,6 +49,18 @@ def test_no_cpu_fallback_without_gpu():
     assert L.hdlz_archive_batch(buf, 64, buf, 1 << 31, buf, 64, off, None) == E_BAD_PARAM and b"2^31" in L.hdlz_last_error()
     assert L.hdlz_archive_batch(buf, 64, buf, 1, buf, 64, None, None) == E_BAD_PARAM
     assert L.hdlz_archive_batch(buf, 64, buf, 1, buf, 64, off, None) == E_HIP
+    # the entry points with caller-owned scratch: sizes are host arithmetic (no device needed), the calls have no CPU path either
+    assert L.hdlz_archive_work_bytes(0) == 0 and L.hdlz_archive_work_bytes(1) >= 16 and L.hdlz_archive_work_bytes(1 << 20) >= 8 * 4096
+    assert L.hdlz_archive_batch_ws(buf, 64, buf, 1, buf, 64, off, None, 0, None) == E_BAD_PARAM and b"hdlz_archive_work_bytes" in L.hdlz_last_error()
+    assert L.hdlz_archive_batch_ws(buf, 64, buf, 1, buf, 64, off, buf, 4096, None) == E_HIP
+    assert L.hdlz_inflate_work_bytes(0, 0, 0, 0, 0) == 0
+    lanes = L.hdlz_inflate_work_bytes(1 << 20, 0, 2048, 0, 1)             # ragged lane mapping: the ordered lists, ~8 bytes per stream
+    assert 8 << 20 <= lanes <= 9 << 20
+    one = L.hdlz_inflate_work_bytes(1, 1 << 24, 1 << 26, 0, 0)            # ONE 16 MiB stream: the whole-GPU path's markers and lists
+    assert one >= 1 << 26 and L.hdlz_inflate_work_bytes(1, 1 << 24, 1 << 26, 2, 0) < 1 << 16      # (a mapping hint keeps the batch kernels)
+    assert L.hdlz_inflate_work_bytes(4096, 1 << 20, 1 << 22, 0, 0) <= (4 << 30) + (1 << 20)         # a batch: bounded by the 4 GiB budget
+    assert L.hdlz_inflate_batch_ws(buf, None, 64, 64, 1, 0, 0, buf, 64, buf, buf, None, 0, None) == E_HIP
+    assert L.hdlz_inflate_batch_ws(buf, None, 64, 64, 1, 16, 0, buf, 64, buf, buf, None, 0, None) == E_BAD_PARAM      # flags 16 / 32 left with round 6
     try:
         hdl_deflate_amd.Engine()
     except RuntimeError as e:

@@ -70,7 +70,7 @@ def test_configs3_every_stream_vs_oracle(engine, oracle):
         flat = np.frombuffer(b"".join(p for p, _ in parts) + bytes(64), dtype=np.uint8)
         d_in = torch.from_numpy(flat.copy()).cuda()
         d_off = torch.from_numpy(off).cuda()
-        for flags in (1, 1 | 32, 1 | 64):               # DYNAMIC=False semantics: the token-round kernel (default), the byte-lockstep kernel, 16 lanes per stream
+        for flags in (1, 1 | 2, 1 | 64):                # DYNAMIC=False semantics: the default mapping, the lane kernel by hint, 16 lanes per stream
             out, ol, st = engine.inflate_batch(d_in, in_off=d_off, out_pitch=N, flags=flags)
             torch.cuda.synchronize()
             assert int((st != 0).sum().item()) == 0 and int((ol != N).sum().item()) == 0

@@ -11,7 +11,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-MAPPINGS = (2, 4, 2 | 32, 64)   # hdlz_inflate_batch mapping hints: lane per stream (token rounds), wave per stream, lane per stream (byte lockstep), 16 lanes per stream
+MAPPINGS = (2, 4, 64)   # hdlz_inflate_batch mapping hints: lane per stream, wave per stream, 16 lanes per stream
 
 
 _r = random.Random(8)
@@ -274,8 +274,11 @@ def test_compress_stream_multiwave_vs_oracle(engine, oracle):
 
 
 def test_calls_are_hip_graph_capturable(engine, oracle):
-    """the C-ABI only enqueues asynchronous work on the caller's stream: batch compress, stream compress and
-    inflate captured into ONE HIP graph, replayed on new data in the same buffers, must still match the oracle"""
+    """the C-ABI only enqueues asynchronous work on the caller's stream and -- round 6 -- allocates nothing: every buffer, scratch
+    included, is the caller's (hdlz_inflate_batch_ws / hdlz_archive_batch_ws).  Batch compress, stream compress, the whole-GPU inflate
+    in its SEVERAL-STREAMS form (512 streams of >= HDLZ_INFLATE_PAR_MIN bytes: the form whose pool scratch, as graph memory nodes, aborted
+    in hipGraphLaunch in round 5 -- profiles/r06_graph_abort_cause.txt), the lane mapping with its second-pass lists, the archive
+    and the 16-lane mapping captured into ONE HIP graph, launched FIFTY times on new data in the same buffers"""
     import torch
     from hdl_deflate_amd.data import make_blocks
     from hdl_deflate_amd.constants import pitch_for
@@ -291,6 +294,11 @@ def test_calls_are_hip_graph_capturable(engine, oracle):
     back3 = torch.empty((B, n), dtype=torch.uint8, device="cuda")
     arch = torch.empty(B * out.shape[1] + 64, dtype=torch.uint8, device="cuda")
     aoff = torch.empty(B + 1, dtype=torch.int64, device="cuda")
+    L = engine.lib
+    iw = torch.empty(L.hdlz_inflate_work_bytes(B, out.shape[1], n, 0, 0), dtype=torch.uint8, device="cuda")     # one scratch buffer for
+    assert iw.numel() >= L.hdlz_inflate_work_bytes(B, out.shape[1], n, 2, 0) and iw.numel() >= L.hdlz_inflate_work_bytes(B, 0, n, 64, 1)   # the three inflate calls
+    aw = torch.empty(L.hdlz_archive_work_bytes(B), dtype=torch.uint8, device="cuda")
+    assert iw.numel() > 4 * B * n                                       # (the whole-GPU path's markers: this call takes that path)
     engine.compress_batch(d, out=out, out_pitch=out.shape[1])          # eager once: device properties get cached
     engine.compress_stream(big, nbig, out=sout, work=work)
     torch.cuda.synchronize()
@@ -300,29 +308,75 @@ def test_calls_are_hip_graph_capturable(engine, oracle):
         with torch.cuda.graph(g, stream=s):
             _, ol, st = engine.compress_batch(d, out=out, out_pitch=out.shape[1])
             _, sl, ss = engine.compress_stream(big, nbig, out=sout, work=work)
-            _, bl, bs = engine.inflate_batch(out, in_len=None, out_pitch=n, out=back)
-            # the lane mapping: pass 1, then the device-side list of streams with dynamic blocks in stream-ordered scratch memory
-            _, bl2, bs2 = engine.inflate_batch(out, in_len=None, out_pitch=n, out=back2, flags=2)
-            # round 5: scan + gather in one launch (a ticket and descriptors in stream-ordered scratch), then the 16-lanes-per-stream
-            # mapping on the ragged archive it made
-            engine.archive(out, ol, archive=arch, offsets=aoff)
-            _, bl3, bs3 = engine.inflate_batch(arch, in_off=aoff, out_pitch=n, out=back3, flags=64)
-    for seed in (11, 12):
+            _, bl, bs = engine.inflate_batch(out, in_len=None, out_pitch=n, out=back, work=iw)              # k_par_*, blockIdx.y = the stream
+            # the lane mapping: pass 1, then the device-side list of streams with dynamic blocks
+            _, bl2, bs2 = engine.inflate_batch(out, in_len=None, out_pitch=n, out=back2, flags=2, work=iw)
+            # scan + gather in one launch (a ticket and descriptors in scratch), then the 16-lanes-per-stream mapping on the ragged archive
+            engine.archive(out, ol, archive=arch, offsets=aoff, work=aw)
+            _, bl3, bs3 = engine.inflate_batch(arch, in_off=aoff, out_pitch=n, out=back3, flags=64, work=iw)
+            # the entry points that allocate from the library's pool refuse a capturing stream (and leave the capture intact)
+            q = bl3.data_ptr()
+            assert L.hdlz_inflate_batch(out.data_ptr(), None, out.shape[1], out.shape[1], B, 0, 0, back.data_ptr(), n, q, q, s.cuda_stream) == 8
+            assert b"hdlz_inflate_batch_ws" in L.hdlz_last_error()
+            assert L.hdlz_archive_batch(out.data_ptr(), out.shape[1], ol.data_ptr(), B, arch.data_ptr(), arch.numel(), aoff.data_ptr(), s.cuda_stream) == 8
+    for seed in range(11, 61):
         d.copy_(make_blocks(B, n, "cuda", seed=seed))
         big.copy_(make_blocks(40, n, "cuda", seed=seed + 100).reshape(-1))
-        out.zero_(); sout.zero_(); back.zero_(); back2.zero_(); back3.zero_(); aoff.zero_()
+        out.zero_(); sout.zero_(); back.zero_(); back2.zero_(); back3.zero_(); aoff.zero_(); iw.fill_(0xA5); aw.fill_(0x5A)
         g.replay()
         torch.cuda.synchronize()
-        assert int((st != 0).sum()) == 0 and int(ss.item()) == 0
-        h, ho, hl = d.cpu().numpy(), out.cpu().numpy(), ol.cpu().numpy()
-        for b in (0, 1, B // 2, B - 1):
-            assert ho[b, :hl[b]].tobytes() == oracle.compress(h[b].tobytes())[1]
-        assert sout[:int(sl.item())].cpu().numpy().tobytes() == oracle.compress(big[:nbig].cpu().numpy().tobytes())[1]
+        assert int((st != 0).sum()) == 0 and int(ss.item()) == 0, seed
+        if seed < 13:
+            h, ho, hl = d.cpu().numpy(), out.cpu().numpy(), ol.cpu().numpy()
+            for b in (0, 1, B // 2, B - 1):
+                assert ho[b, :hl[b]].tobytes() == oracle.compress(h[b].tobytes())[1]
+            assert sout[:int(sl.item())].cpu().numpy().tobytes() == oracle.compress(big[:nbig].cpu().numpy().tobytes())[1]
         # inflate took the full pitch as in_len: trailing zero bytes after the Adler-32 are ignored (D6)
-        assert int((bs != 0).sum()) == 0 and torch.equal(back, d) and int((bl != n).sum()) == 0
-        assert int((bs2 != 0).sum()) == 0 and torch.equal(back2, d) and int((bl2 != n).sum()) == 0
-        assert int(aoff[-1].item()) == int(ol.to(torch.int64).sum().item())
-        assert int((bs3 != 0).sum()) == 0 and torch.equal(back3, d) and int((bl3 != n).sum()) == 0
+        assert int((bs != 0).sum()) == 0 and torch.equal(back, d) and int((bl != n).sum()) == 0, seed
+        assert int((bs2 != 0).sum()) == 0 and torch.equal(back2, d) and int((bl2 != n).sum()) == 0, seed
+        assert int(aoff[-1].item()) == int(ol.to(torch.int64).sum().item()), seed
+        assert int((bs3 != 0).sum()) == 0 and torch.equal(back3, d) and int((bl3 != n).sum()) == 0, seed
+
+
+def test_inflate_with_less_scratch_than_asked_for(engine, oracle):
+    """hdlz_inflate_batch_ws with LESS scratch than hdlz_inflate_work_bytes (down to none): the same results through mappings that need
+    less -- the whole-GPU path in groups of streams that fit, or skipped; the lane mapping in index order; the second pass a wave per
+    stream.  Shapes: a few large fixed-block streams (k_par_*), a ragged batch with dynamic-tree streams (lane mapping + second pass)"""
+    import zlib
+    import numpy as np
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    L = engine.lib
+    # (a) 48 streams of 64 KiB, fixed pitch: the whole-GPU path
+    d = make_blocks(48 * 32, 2048, "cuda", seed=21).reshape(48, 65536)
+    z, zl, st = engine.compress_batch(d)
+    full = L.hdlz_inflate_work_bytes(48, z.shape[1], 65536, 0, 0)
+    assert full > 48 * 65536 * 2
+    for wb in (full, full // 2, full // 5, full // 48 + 4096, 70000, 256, 0):
+        w = torch.full((wb,), 0xEE, dtype=torch.uint8, device="cuda")
+        back, bl, bs = engine.inflate_batch(z, out_pitch=65536, work=w)
+        assert int((bs != 0).sum()) == 0 and int((bl != 65536).sum()) == 0 and torch.equal(back, d), wb
+    # (b) 3000 ragged streams, every third one with dynamic trees, the others Z_FIXED
+    blocks = make_blocks(3000, 2048, "cuda", seed=22, families=(1, 2, 4)).cpu().numpy()
+    zs = []
+    for k in range(3000):
+        co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_DEFAULT_STRATEGY if k % 3 == 0 else zlib.Z_FIXED)
+        zs.append(co.compress(blocks[k].tobytes()) + co.flush())
+    off = np.zeros(3001, np.int64)
+    off[1:] = np.cumsum([len(x) for x in zs])
+    flat = torch.from_numpy(np.frombuffer(b"".join(zs) + bytes(64), dtype=np.uint8).copy()).cuda()
+    d_off = torch.from_numpy(off).cuda()
+    want = torch.from_numpy(blocks).cuda()
+    for flags in (2, 64, 0):
+        full = L.hdlz_inflate_work_bytes(3000, 0, 2048, flags, 1)
+        for wb in (full, full // 2, 1024, 0):
+            w = torch.full((wb,), 0xEE, dtype=torch.uint8, device="cuda")
+            back, bl, bs = engine.inflate_batch(flat, in_off=d_off, out_pitch=2048, flags=flags, work=w)
+            assert int((bs != 0).sum()) == 0 and int((bl != 2048).sum()) == 0 and torch.equal(back, want), (flags, wb)
+    # the C-ABI's own checks: alignment of d_work; the archive call needs its scratch
+    q = bl.data_ptr()
+    assert L.hdlz_inflate_batch_ws(flat.data_ptr(), d_off.data_ptr(), 0, 0, 3000, 0, 0, back.data_ptr(), 2048, q, q, w.data_ptr() + 8 if wb else 8, 4096, None) == 8
+    assert L.hdlz_archive_batch_ws(back.data_ptr(), 2048, bl.data_ptr(), 3000, flat.data_ptr(), 64, d_off.data_ptr(), None, 0, None) == 8
 
 
 def test_api_edge_cases(engine, oracle):
@@ -767,6 +821,68 @@ def test_inflate_small_streams_every_kind(engine, oracle):
                 assert np.array_equal(ol.cpu().numpy().astype(np.uint32), rl), (rd, fl, mapping)
                 assert np.array_equal(out.cpu().numpy()[m], ref[m]), (rd, fl, mapping)
             assert len(set(rs.tolist())) >= 3           # (the batch really holds good, cut and damaged streams)
+
+
+def _empty_blocks_stream(data, nstored, nfixed, nstored2=1, level=6, strategy=None):
+    """a zlib stream whose payload block(s) stand behind `nstored` empty stored blocks (5 bytes each once aligned), `nfixed` empty
+    fixed blocks (3 header bits + the 7-bit EOB: what Z_PARTIAL_FLUSH writes) and `nstored2` >= 1 more empty stored blocks, the last
+    of which re-aligns the stream to a byte -- hand-made bits, RFC 1951 3.2.3 / 3.2.4"""
+    bits = []
+    def put(v, n):
+        for k in range(n):
+            bits.append((v >> k) & 1)
+    def empty_stored():
+        put(0, 3)                                   # BFINAL = 0, BTYPE = 00
+        while len(bits) % 8:
+            bits.append(0)
+        put(0x0000, 16); put(0xFFFF, 16)            # LEN = 0, NLEN
+    for _ in range(nstored):
+        empty_stored()
+    for _ in range(nfixed):
+        put(0, 1); put(1, 2); put(0, 7)             # BFINAL = 0, BTYPE = 01, EOB (7 zero bits)
+    for _ in range(nstored2):
+        empty_stored()
+    head = bytes(sum(bits[i + k] << k for k in range(8)) for i in range(0, len(bits), 8))
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, zlib.Z_FIXED if strategy is None else strategy)
+    raw = c.compress(data) + c.flush()
+    return b"\x78\x9c" + head + raw + zlib.adler32(data).to_bytes(4, "big")
+
+
+def test_inflate_long_runs_of_empty_blocks(engine, oracle):
+    """a step of the 16-lane mapping walked through any number of empty blocks while its input FIFO advances one
+    half per step -- ~26 empty stored blocks (or ~100 empty fixed ones) in a row read stale FIFO words.  Streams with 200 empty stored
+    and 500 empty fixed blocks in front of the data (and shorter runs at every phase of the FIFO), every mapping and the default
+    choices (one large stream: the whole-GPU path hands it to the serial decoder), against the oracle and stock zlib"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    h = make_blocks(40, 2048, "cpu", seed=77, families=(1, 2, 4)).numpy()
+    zs, plain = [], []
+    shapes = [(200, 500, 1), (0, 500, 1), (200, 0, 1), (26, 0, 1), (27, 3, 2), (1, 100, 1), (0, 101, 3), (60, 60, 60)] + \
+             [(k, 7 * k % 11, 1 + k % 3) for k in range(20, 52)]
+    for k, (ns, nf, ns2) in enumerate(shapes):
+        data = h[k % 40].tobytes()[: 2048 - 13 * (k % 7)]
+        z = _empty_blocks_stream(data, ns, nf, ns2, strategy=zlib.Z_DEFAULT_STRATEGY if k % 5 == 4 else None)
+        assert zlib.decompress(z) == data
+        zs.append(z); plain.append(data)
+    B = len(zs)
+    off = np.zeros(B + 1, np.int64)
+    np.cumsum([len(z) for z in zs], out=off[1:])
+    flat = np.frombuffer(b"".join(zs) + bytes(64), dtype=np.uint8).copy()
+    ref, rl, rs = oracle.inflate_batch(flat, off.astype(np.uint64), 2048, flags=0, nthreads=4)
+    assert (rs == 0).all() and all(ref[k, :rl[k]].tobytes() == plain[k] for k in range(B))
+    zin, zoff = torch.from_numpy(flat).cuda(), torch.from_numpy(off).cuda()
+    m = np.arange(2048)[None, :] < rl[:, None]
+    for mapping in (0,) + MAPPINGS:
+        out, ol, st = engine.inflate_batch(zin, in_off=zoff, out_pitch=2048, flags=mapping)
+        torch.cuda.synchronize()
+        assert np.array_equal(st.cpu().numpy().astype(np.uint32), rs), mapping
+        assert np.array_equal(ol.cpu().numpy().astype(np.uint32), rl), mapping
+        assert np.array_equal(out.cpu().numpy()[m], ref[m]), mapping
+    # one stream at a time, fixed pitch (the shape the port's STARTD has): >= HDLZ_INFLATE_PAR_MIN bytes takes the whole-GPU path first
+    for k in (0, 1, 2, 7):
+        z = np.frombuffer(zs[k] + bytes(64), dtype=np.uint8).copy()
+        out, ol, st = engine.inflate_batch(torch.from_numpy(z).cuda().reshape(1, -1), in_len=len(zs[k]), out_pitch=2048)
+        assert int(st.item()) == 0 and out[0, :int(ol.item())].cpu().numpy().tobytes() == plain[k], k
 
 
 def test_inflate_length_binned_lanes(engine, oracle):
