@@ -93,7 +93,7 @@ def test_rccl_length_allgather_over_visible_devices(oracle):
 def _run_bench(world, env_extra, args):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", str(world)] + args
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", str(world), "--detail", ""] + args
     p = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -125,7 +125,7 @@ def test_bench_gpus_n_without_a_launcher():
     import torch
     ndev = torch.cuda.device_count()
     n = max(2, ndev)
-    base = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--cfg5-blocks", "2048", "--steps", "2", "--warmup", "1"]
+    base = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--cfg5-blocks", "2048", "--steps", "2", "--warmup", "1", "--detail", ""]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HDLZ_BENCH_BACKEND")}
     if ndev < n:
         p = subprocess.run(base, cwd=REPO, env=env, capture_output=True, text=True, timeout=300)
