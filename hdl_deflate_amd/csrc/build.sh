@@ -18,12 +18,12 @@ lib="$out/libhdlz${var:+_$var}.so"
 mkdir -p "$out" "$objdir"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${HDLZ_DEFS:-}"
-srcs="hdlz_compress hdlz_compress_small hdlz_compress_stream hdlz_compress_chunk hdlz_inflate_tok hdlz_inflate_grp hdlz_inflate_par hdlz_inflate_dyn hdlz_compact hdlz_api"
+srcs="hdlz_compress hdlz_compress_small hdlz_compress_stream hdlz_compress_chunk hdlz_inflate_tok hdlz_inflate_grp hdlz_inflate_par hdlz_inflate_any hdlz_inflate_dyn hdlz_compact hdlz_api"
 only="${HDLZ_ONLY:-$srcs}"
 pids=()
 for f in $only; do
   src="$here/$f.hip"; obj="$objdir/$f.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$here/hdlz_device.h" -nt "$obj" ] || [ "$here/hdlz_compress_common.h" -nt "$obj" ] || [ "$here/hdlz_inflate_tables.h" -nt "$obj" ] || [ "$here/../../include/hdlz.h" -nt "$obj" ] || [ "${BASH_SOURCE[0]}" -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$here/hdlz_device.h" -nt "$obj" ] || [ "$here/hdlz_compress_common.h" -nt "$obj" ] || [ "$here/hdlz_inflate_tables.h" -nt "$obj" ] || [ "$here/hdlz_inflate_par.h" -nt "$obj" ] || [ "$here/../../include/hdlz.h" -nt "$obj" ] || [ "${BASH_SOURCE[0]}" -nt "$obj" ]; then
     ( "$HIPCC" $FLAGS -c "$src" -o "$obj" ) &
     pids+=($!)
   fi

@@ -262,7 +262,7 @@ size_t hdlz_inflate_work_bytes(uint64_t nstreams, uint32_t in_len, uint64_t out_
     size_t need = hdlz::inflate_tok_work_bytes(nstreams, ragged != 0);
     if (ragged && in_len >= 0x10000000u) in_len = 0;
     if (par_applies(nstreams, in_len, flags)) {
-        const size_t p = hdlz::inflate_par_work_bytes(in_len, nstreams, out_pitch);
+        const size_t p = hdlz::inflate_par_work_bytes(in_len, nstreams, out_pitch, flags);
         if (p > need) need = p;
     }
     return need < 256u ? 256u : need;

@@ -78,7 +78,7 @@ struct Work {
     hipError_t put(uint8_t* p, hipStream_t stream) const;
 };
 size_t inflate_tok_work_bytes(uint64_t nstreams, bool ragged);              // pass 1's ordered list / pass 2's lists (max of the two)
-size_t inflate_par_work_bytes(uint32_t in_len, uint64_t nstreams, uint64_t out_pitch);    // all streams at once (0: the path does not apply)
+size_t inflate_par_work_bytes(uint32_t in_len, uint64_t nstreams, uint64_t out_pitch, uint32_t flags);    // all streams at once (0: the path does not apply)
 size_t archive_work_bytes(uint64_t nblocks);
 hipError_t launch_inflate_tok(const InflateArgs& a, hipStream_t stream, const Work& w);
 hipError_t launch_inflate_grp(const InflateArgs& a, hipStream_t stream);

@@ -1,0 +1,814 @@
+// hdlz_inflate_any.hip -- STARTD for ONE large stream of ANY block types (or a batch of them, blockIdx.y = the stream) on the whole GPU:
+// what the reference's default build (DYNAMIC=True, /root/reference/deflate.py:32) accepts -- any stock-zlib stream: a sequence of
+// stored, fixed and dynamic-tree blocks (deflate.py:656-732 HEADER loop over blocks, :1084-1202 BL/READBL, :1204-1400 HF1..SPREAD,
+// :1402-1445 NEXT, :1447-1517 D_NEXT, :1519-1591 INFLATE, :1593-1659 COPY).  Round 6: up to round 5 only a stream
+// that is one fixed block took the whole-GPU path (hdlz_inflate_par.hip); everything else went to ONE wave (11 MB/s).
+//
+// A dynamic block cannot be entered in the middle without its code, and where a block starts is only known to whoever decoded the
+// block in front of it.  But a dynamic block HEADER is recognisable: BTYPE = 10, HLIT <= 29, HDIST <= 29, a COMPLETE code-length code,
+// HLIT + HDIST + 258 lengths that decode without overrun, a literal/length code with an end-of-block symbol that is complete, a
+// distance code that is complete (or has at most one symbol) -- the serial decoder's own acceptance rules (hdlz_inflate_dyn.hip) --
+// which 1 bit position in ~10^8 of arbitrary data passes.  So:
+//   1. k_any_find     every bit position of the stream is tested for the first 17 + 3 * (HCLEN + 4) bits of such a header
+//                     (0.085 % of the positions pass), the survivors are listed;
+//      k_any_headers  one LANE per survivor decodes the code lengths and applies the rest of the rules: the CANDIDATE blocks;
+//      k_any_sort     ... ordered by position;   k_any_tables: one workgroup per candidate builds its decode tables (an 11-bit
+//                     and a 9-bit look-up table + the canonical lists for longer codes), slot `maxb` holds the fixed code's;
+//   2. k_any_owner    every piece of the stream (1024 bits) belongs to the last candidate whose payload starts in front of it;
+//      k_any_spec     one WAVE per piece decodes it with its owner's tables from the 64 bit offsets a token can start at behind
+//                     its first bit (a token is at most 15 + 5 + 15 + 13 = 48 bits long): exit offset / end-of-block position and
+//                     the bytes produced, for every entry offset (the maps of hdlz_inflate_par.hip, per block);
+//   3. k_any_walk     one LANE per candidate walks its block: the first partial piece serially, then through the maps to the
+//                     block's end-of-block code; behind it the blocks that cannot be found by search are followed serially --
+//                     stored blocks (a length and a jump), fixed blocks (decoded by this lane: they are short in streams that
+//                     also hold dynamic blocks; long ones give up) -- up to the next dynamic header, which must be a candidate
+//                     (binary search): the block's successor.  A pseudo-node does the same from the stream's first header;
+//      k_any_rank     one thread follows the successors from the pseudo-node: the TRUE chain of blocks, every block's output
+//                     position, the total length.  A candidate that is not on the chain (a false positive, or a header-like
+//                     pattern inside stored data) is simply never visited; a piece that was decoded for the wrong owner is an
+//                     inconsistency the walk notices -> fallback;
+//   4. k_any_tokens   one LANE per piece (and per partial piece / fixed-block piece the walks listed) decodes for real, with the
+//                     reference's checks, into a token list;  k_any_stored copies the stored blocks;
+//      k_par_emit / k_par_jump (hdlz_inflate_par.hip) turn the token lists into bytes: history that is not there yet becomes
+//                     markers, pointer jumping resolves them.
+// Whatever this chain cannot do -- more candidates, items or stored blocks than its lists hold, a fixed block of more than
+// FIX_MAX_BITS, a failed check, an inconsistency -- sets its fallback flag and the serial decoder (k_inflate_dyn) redoes the
+// stream: statuses and bytes are the serial decoder's by construction, this path only ever reports HDLZ_OK.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "hdlz_device.h"
+#include "hdlz_inflate_tables.h"
+#include "hdlz_inflate_par.h"
+
+namespace hdlz {
+namespace any {
+
+using par::C_FALLBACK;
+using par::C_FNUSED;
+using par::C_MARK;
+using par::C_NUSED;
+using par::C_OK;
+using par::C_TOTAL;
+using par::NONE;
+using par::TOK_LIT;
+
+constexpr uint32_t PB = 1024;                 // bits per piece
+constexpr uint32_t LB = 11, DB = 9;           // bits of the two primary look-up tables
+constexpr uint32_t FIX_MAX_BITS = 16 * PB;    // a fixed block behind a dynamic one is decoded by ONE lane: up to this many bits
+constexpr uint32_t NO_OWNER = 0xFFFFu;
+constexpr uint32_t N_END = 0xFFFFFFFEu, N_BAD = 0xFFFFFFFFu;      // successor of a node: the stream ends / no valid successor
+enum { A_NCAND = par::C_ANY0, A_NBLK, A_NX, A_NS, A_OVER };       // this chain's counters in its control words
+
+// decode tables of one block (global memory; a wave of k_any_spec copies its owner's into LDS)
+struct __attribute__((aligned(256))) Tab {
+    uint16_t ll[1u << LB];        // by the next LB stream bits: symbol | length << 9 of a literal/length code of up to LB bits; 0 = longer or none
+    uint16_t dd[1u << DB];        // ... distance code of up to DB bits: symbol | length << 5
+    uint16_t lsym[288], dsym[32]; // the symbols sorted by (length, value)
+    uint16_t lfirst[16], lcnt[16], loff[16];      // canonical form: first code of each length (MSB first), count, index of its first symbol in lsym
+    uint16_t dfirst[16], dcnt[16], doff[16];
+};
+static_assert(sizeof(Tab) % 256 == 0, "tables are copied in 16-byte words");
+
+struct Blk { uint32_t hdr, pay, fin, nlen; };                         // a candidate: header bit, first payload bit, BFINAL, HLIT + 257
+struct Node { uint32_t next, nbytes, ok, obase; };                    // result of its walk; obase: k_any_rank
+struct XItem { uint32_t start, limit, rel, node_slot; };              // an extra decode item: bits [start, limit), rel = bytes of its node in front; node | slot << 16
+struct SItem { uint32_t src, len, rel, node; };                       // a stored block: `len` bytes from stream byte `src`
+
+struct Args {
+    const uint8_t* z;
+    uint32_t zn, flags, obsize;
+    uint8_t* out;
+    uint32_t cap, srcn;
+    uint64_t in_pitch, out_pitch;
+    const uint64_t* in_off;
+    uint8_t* ws;                  // this chain's scratch of stream 0
+    size_t stride;                // bytes from a stream's scratch to the next stream's
+    const uint32_t* gate;         // stream 0's gate word (the fixed-block chain's C_NOTFIXED)
+    uint32_t* srcA;               // stream 0's marker words
+    uint32_t nchunks, candcap, maxb, maxx, maxs, tcap;
+    size_t o_cand, o_blk, o_blen, o_shdr, o_spay, o_sidx, o_tab, o_owner, o_map, o_pent, o_prel, o_pnode, o_node, o_xitem, o_sitem,
+           o_opos, o_ntok, o_tok, o_mext;
+};
+// one stream's view
+struct View {
+    const uint8_t* z;
+    uint32_t zn;
+    uint8_t* out;
+    uint32_t* ctl;
+    bool run;                     // the gate is open and nothing has failed so far
+    uint32_t* cand; Blk* blk; uint8_t* blen; uint32_t* shdr; uint32_t* spay; uint32_t* sidx; Tab* tab; uint16_t* owner; uint32_t* map;
+    uint8_t* pent; uint32_t* prel; uint16_t* pnode; Node* node; XItem* xitem; SItem* sitem; uint32_t* opos; uint32_t* ntok; uint32_t* tok;
+    uint32_t* mext; uint32_t* srcA;
+};
+template <typename T> __device__ __forceinline__ T* at(uint8_t* base, size_t off) { return reinterpret_cast<T*>(base + off); }
+__device__ __forceinline__ View view(const Args& a) {
+    const uint32_t s = blockIdx.y;
+    View v;
+    if (a.in_off) {
+        const uint64_t o0 = a.in_off[s], n64 = a.in_off[s + 1u] - o0;
+        v.z = a.z + o0;
+        v.zn = n64 > (uint64_t)a.zn ? 0u : (uint32_t)n64;          // longer than the stated bound: not this chain's (zn = 0 fails every test)
+    } else { v.z = a.z + (uint64_t)s * a.in_pitch; v.zn = a.zn; }
+    v.out = a.out + (uint64_t)s * a.out_pitch;
+    uint8_t* w = a.ws + (size_t)s * a.stride;
+    v.ctl = reinterpret_cast<uint32_t*>(w);
+    const uint32_t* gate = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(a.gate) + (size_t)s * a.stride);
+    v.run = *gate != 0u && v.ctl[C_FALLBACK] == 0u;
+    v.cand = at<uint32_t>(w, a.o_cand); v.blk = at<Blk>(w, a.o_blk); v.blen = at<uint8_t>(w, a.o_blen); v.shdr = at<uint32_t>(w, a.o_shdr);
+    v.spay = at<uint32_t>(w, a.o_spay); v.sidx = at<uint32_t>(w, a.o_sidx); v.tab = at<Tab>(w, a.o_tab); v.owner = at<uint16_t>(w, a.o_owner);
+    v.map = at<uint32_t>(w, a.o_map); v.pent = at<uint8_t>(w, a.o_pent); v.prel = at<uint32_t>(w, a.o_prel); v.pnode = at<uint16_t>(w, a.o_pnode);
+    v.node = at<Node>(w, a.o_node); v.xitem = at<XItem>(w, a.o_xitem); v.sitem = at<SItem>(w, a.o_sitem); v.opos = at<uint32_t>(w, a.o_opos);
+    v.ntok = at<uint32_t>(w, a.o_ntok); v.tok = at<uint32_t>(w, a.o_tok); v.mext = at<uint32_t>(w, a.o_mext);
+    v.srcA = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(a.srcA) + (size_t)s * a.stride);
+    return v;
+}
+__device__ __forceinline__ void give_up(const View& v) { atomicExch(&v.ctl[C_FALLBACK], 1u); }
+
+// ---- bit reader of one lane, straight from the stream (bytes at or beyond zn read as zero)
+struct Bits {
+    const uint8_t* z;
+    uint32_t zn, ip, bc, nxt, pos;
+    uint64_t bb;
+    __device__ __forceinline__ void init(const uint8_t* z_, uint32_t zn_, uint32_t pos_) {
+        z = z_; zn = zn_; pos = pos_;
+        ip = (pos >> 3) & ~3u;
+        bc = 64u - (pos - 8u * ip);
+        bb = (((uint64_t)tok::load32(z, ip + 4u, zn) << 32) | tok::load32(z, ip, zn)) >> (pos - 8u * ip);
+        ip += 8u;
+        nxt = tok::load32(z, ip, zn);
+    }
+    __device__ __forceinline__ void refill() {          // >= 33 valid bits afterwards
+        if (bc <= 32u) { bb |= (uint64_t)nxt << bc; bc += 32u; ip += 4u; nxt = tok::load32(z, ip, zn); }
+    }
+    __device__ __forceinline__ void take(uint32_t n) { bb >>= n; bc -= n; pos += n; }
+};
+
+// ---- one symbol of a canonical code: the primary table by the next bits, the canonical lists for codes longer than it.
+// -> symbol, length (0: no code starts with these bits).  x: at least 15 stream bits, LSB first.
+template <uint32_t PBITS, uint32_t SHIFT, uint32_t SMASK>
+__device__ __forceinline__ void sym_of(const uint16_t* prim, const uint16_t* first, const uint16_t* cnt, const uint16_t* off,
+                                       const uint16_t* syms, uint32_t x, uint32_t& sym, uint32_t& len) {
+    const uint32_t e = prim[x & ((1u << PBITS) - 1u)];
+    sym = e & SMASK; len = e >> SHIFT;
+    if (e == 0u) {
+        const uint32_t rv = __builtin_bitreverse32(x) >> 17;        // the next 15 bits as an MSB-first code
+#pragma unroll 1
+        for (uint32_t l = PBITS + 1u; l <= 15u; l++) {
+            const uint32_t idx = (rv >> (15u - l)) - (uint32_t)first[l];
+            if (idx < (uint32_t)cnt[l]) { sym = syms[(uint32_t)off[l] + idx]; len = l; break; }
+        }
+    }
+}
+// one token at the reader's position, CONSUMED (an invalid one is not).  -> kind: 0 literal, 1 match, 2 end of block, 3 invalid; value /
+// length / distance; nb = bits of the literal/length code, used = bits of the whole token
+struct Token { uint32_t kind, lit, length, dist, nb, used; };
+__device__ __forceinline__ Token token_at(const Tab* t, Bits& r) {
+    Token k;
+    r.refill();
+    uint32_t sym, len;
+    sym_of<LB, 9u, 511u>(t->ll, t->lfirst, t->lcnt, t->loff, t->lsym, (uint32_t)r.bb, sym, len);
+    k.nb = len; k.used = len; k.lit = sym; k.length = 0; k.dist = 0;
+    if (len == 0u) { k.kind = 3u; return k; }
+    if (sym < 256u) { k.kind = 0u; r.take(len); return k; }
+    if (sym == 256u) { k.kind = 2u; r.take(len); return k; }
+    if (sym >= 286u) { k.kind = 3u; return k; }                     // (the fixed code has 286 / 287: BAD_SYMBOL in the serial decoder)
+    uint32_t lbase, leb;
+    tok::length_info(sym - 257u, lbase, leb);
+    const uint32_t x1 = (uint32_t)(r.bb >> len);
+    k.length = lbase + (x1 & ((1u << leb) - 1u));
+    r.take(len + leb);
+    r.refill();
+    uint32_t ds, dl;
+    sym_of<DB, 5u, 31u>(t->dd, t->dfirst, t->dcnt, t->doff, t->dsym, (uint32_t)r.bb, ds, dl);
+    if (dl == 0u || ds >= 30u) { k.kind = 3u; return k; }           // (the fixed code has 30 / 31: BAD_DISTANCE)
+    uint32_t dbase, deb;
+    tok::dist_info(ds, dbase, deb);
+    k.dist = dbase + ((uint32_t)(r.bb >> dl) & ((1u << deb) - 1u));
+    r.take(dl + deb);
+    k.used = len + leb + dl + deb;
+    k.kind = 1u;
+    return k;
+}
+
+// ================================================================================================ 1. the candidates
+// the first 17 + 3 n bits of a dynamic block header (lo = the next 64 stream bits, hi = the 32 behind them; LSB first): BTYPE, HLIT,
+// HDIST, and a COMPLETE code-length code (hdlz_inflate_dyn.hip: `left[0] != 0` is HDLZ_E_BAD_TREE)
+__device__ __forceinline__ bool header_start_ok(uint64_t lo, uint32_t hi) {
+    const uint32_t x = (uint32_t)lo;
+    if (((x >> 1) & 3u) != 2u) return false;
+    const uint32_t hlit = (x >> 3) & 31u, hdist = (x >> 8) & 31u, n = ((x >> 13) & 15u) + 4u;
+    if (hlit > 29u || hdist > 29u) return false;
+    uint64_t f = (lo >> 17) | ((uint64_t)hi << 47);                 // 47 + 32 bits behind the 17: 57 needed
+    int32_t left = 128;                                             // Kraft sum in units of 1/128
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t l = (uint32_t)f & 7u;
+        f >>= 3;
+        left -= l ? (int32_t)(128u >> l) : 0;
+    }
+    return left == 0;
+}
+constexpr uint32_t FIND_T = 256, FIND_CAP = 2048;
+__global__ __launch_bounds__(FIND_T) void k_any_find(Args a) {
+    const View v = view(a);
+    __shared__ uint32_t lst[FIND_CAP];
+    __shared__ uint32_t ln, gbase;
+    if (!v.run) return;
+    const uint32_t tid = threadIdx.x;
+    // (this kernel also presets the per-piece and per-item words the later ones only write where something is: no owner, no node, no tokens)
+    for (uint32_t i = blockIdx.x * FIND_T + tid; i < a.nchunks + a.maxx; i += gridDim.x * FIND_T) {
+        v.ntok[i] = 0u; v.mext[i] = 0u; v.opos[i] = 0u;
+        if (i < a.nchunks) { v.owner[i] = (uint16_t)NO_OWNER; v.pnode[i] = (uint16_t)NO_OWNER; }
+    }
+    if (tid == 0u) ln = 0u;
+    __syncthreads();
+    const uint32_t nbits = 8u * v.zn;
+    auto flush = [&]() {                                            // (called by all threads)
+        const uint32_t n = min(ln, FIND_CAP);
+        if (tid == 0u) gbase = n ? atomicAdd(&v.ctl[A_NCAND], n) : 0u;
+        __syncthreads();
+        for (uint32_t k = tid; k < n; k += FIND_T) { if (gbase + k < a.candcap) v.cand[gbase + k] = lst[k]; }
+        if (tid == 0u && (gbase + n > a.candcap || ln > FIND_CAP)) v.ctl[A_OVER] = 1u;
+        __syncthreads();
+        if (tid == 0u) ln = 0u;
+        __syncthreads();
+    };
+    // a thread takes the 8 bit positions of one stream byte: 12 bytes cover the 7 + 17 + 57 bits behind its first bit
+    for (uint32_t base = blockIdx.x * FIND_T; base < v.zn; base += gridDim.x * FIND_T) {
+        const uint32_t B = base + tid;
+        if (B >= 2u && B < v.zn) {
+            const uint32_t d0 = tok::load32(v.z, B, v.zn), d1 = tok::load32(v.z, B + 4u, v.zn), d2 = tok::load32(v.z, B + 8u, v.zn);
+            const uint64_t w01 = ((uint64_t)d1 << 32) | d0;
+#pragma unroll 1
+            for (uint32_t j = 0; j < 8u; j++) {
+                const uint64_t lo = j ? ((w01 >> j) | ((uint64_t)d2 << (64u - j))) : w01;
+                const uint32_t hi = d2 >> j;
+                const uint32_t p = 8u * B + j;
+                if (p + 17u + 12u <= nbits && header_start_ok(lo, hi)) {
+                    const uint32_t k = atomicAdd(&ln, 1u);
+                    if (k < FIND_CAP) lst[k] = p;
+                }
+            }
+        }
+        __syncthreads();
+        if (ln > FIND_CAP / 2u) flush();                            // (uniform: every thread reads ln behind the barrier, nobody writes it before the next one)
+        else __syncthreads();
+    }
+    flush();
+}
+
+// one LANE per listed position: the code lengths, and the rest of the serial decoder's acceptance rules (hdlz_inflate_dyn.hip, "BL" ..
+// "canon_build": over-subscribed sets rejected, incomplete ones only with a single code -- for the distance code also with none --,
+// an end-of-block code must exist, the header must leave room for the reference's end-of-input margin)
+struct HdrLds {
+    uint8_t clut[128][64];        // the code-length code by the next 7 bits: symbol << 3 | length, per lane
+    uint8_t cl[19][64];
+    uint8_t lens[320][64];
+    uint16_t cnt[32][64];         // code counts per length: [0, 16) literal/length, [16, 32) distance
+};
+__global__ __launch_bounds__(64) void k_any_headers(Args a) {
+    const View v = view(a);
+    __shared__ HdrLds L;
+    if (!v.run) return;
+    if (v.ctl[A_OVER] != 0u) { if (threadIdx.x == 0u && blockIdx.x == 0u) give_up(v); return; }
+    const uint32_t lane = threadIdx.x, ncand = min(v.ctl[A_NCAND], a.candcap);
+    const uint32_t nbits = 8u * v.zn;
+    const int32_t isize = (int32_t)v.zn - 1;
+    for (uint32_t c0 = blockIdx.x * 64u; c0 < ncand; c0 += gridDim.x * 64u) {
+        const uint32_t i = c0 + lane;
+        bool ok = i < ncand;
+        const uint32_t p = ok ? v.cand[i] : 16u;
+        Bits r;
+        r.init(v.z, v.zn, p);
+        const uint32_t fin = (uint32_t)r.bb & 1u;
+        r.take(3u);
+        r.refill();
+        const uint32_t nlen = ((uint32_t)r.bb & 31u) + 257u, ndist = (((uint32_t)r.bb >> 5) & 31u) + 1u, ncode = (((uint32_t)r.bb >> 10) & 15u) + 4u;
+        r.take(14u);
+        const uint32_t total = nlen + ndist;
+        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        for (uint32_t k = 0; k < 19u; k++) L.cl[k][lane] = 0;
+        uint64_t cnt8 = 0;                                          // counts of the lengths 1..7, 8 bits each
+        for (uint32_t k = 0; k < 19u; k++) {
+            if (ok && k < ncode) {
+                r.refill();
+                const uint32_t l = (uint32_t)r.bb & 7u;
+                r.take(3u);
+                L.cl[order[k]][lane] = (uint8_t)l;
+                cnt8 += l ? (1ull << (8u * l)) : 0ull;
+            }
+        }
+        // canonical codes of the code-length code (complete: k_any_find checked), spread over the 7-bit table
+        uint64_t next8 = 0;                                         // next code of each length, 8 bits each
+        {
+            uint32_t code = 0;
+            for (uint32_t l = 1; l < 8u; l++) {
+                code = (code + (uint32_t)((cnt8 >> (8u * (l - 1u))) & 255u) * (l > 1u ? 1u : 0u)) << 1;
+                next8 |= (uint64_t)(code & 255u) << (8u * l);
+            }
+        }
+        for (uint32_t s = 0; s < 19u; s++) {
+            const uint32_t l = ok ? L.cl[s][lane] : 0u;
+            if (l) {
+                const uint32_t code = (uint32_t)(next8 >> (8u * l)) & 255u;
+                next8 += 1ull << (8u * l);
+                const uint32_t rv = __builtin_bitreverse32(code) >> (32u - l);
+                for (uint32_t k = rv; k < 128u; k += 1u << l) L.clut[k][lane] = (uint8_t)((s << 3) | l);
+            }
+        }
+        // READBL / REPEAT (deflate.py:1116-1164, :1190-1202)
+        uint32_t idx = 0, prev = 0;
+        while (ballot64(ok && idx < total) != 0ull) {
+            if (ok && idx < total) {
+                r.refill();
+                const uint32_t e = L.clut[(uint32_t)r.bb & 127u][lane], l = e & 7u, sy = e >> 3;
+                r.take(l);
+                uint32_t rep = 1, val = sy;
+                if (sy == 16u) { if (idx == 0u) ok = false; rep = 3u + ((uint32_t)r.bb & 3u); r.take(2u); val = prev; }
+                else if (sy == 17u) { rep = 3u + ((uint32_t)r.bb & 7u); r.take(3u); val = 0u; }
+                else if (sy == 18u) { rep = 11u + ((uint32_t)r.bb & 127u); r.take(7u); val = 0u; }
+                if (idx + rep > total || r.pos > nbits) ok = false;
+                if (ok) for (uint32_t k = 0; k < rep; k++) L.lens[idx + k][lane] = (uint8_t)val;
+                prev = val;
+                idx += rep;
+            }
+        }
+        if (ok) {
+            for (uint32_t k = 0; k < 32u; k++) L.cnt[k][lane] = 0;
+            for (uint32_t k = 0; k < total; k++) { const uint32_t l = L.lens[k][lane]; L.cnt[(k < nlen ? 0u : 16u) + l][lane]++; }
+            if (L.lens[256][lane] == 0) ok = false;                                         // no end-of-block code
+            int32_t l1 = 1, l2 = 1;
+            for (uint32_t l = 1; l < 16u; l++) { l1 = (l1 << 1) - (int32_t)L.cnt[l][lane]; if (l1 < 0) break; }
+            for (uint32_t l = 1; l < 16u; l++) { l2 = (l2 << 1) - (int32_t)L.cnt[16u + l][lane]; if (l2 < 0) break; }
+            if (l1 < 0 || (l1 > 0 && (int32_t)nlen - (int32_t)L.cnt[0][lane] != 1)) ok = false;
+            if (l2 < 0 || (l2 > 0 && (int32_t)ndist - (int32_t)L.cnt[16][lane] > 1)) ok = false;
+            if ((int32_t)(r.pos >> 3) > isize - 3) ok = false;                              // (the serial decoder's NO EOF at the end of a header)
+        }
+        if (ok) {
+            const uint32_t slot = atomicAdd(&v.ctl[A_NBLK], 1u);
+            if (slot < a.maxb) {
+                v.blk[slot] = Blk{p, r.pos, fin, nlen};
+                uint8_t* bl = v.blen + (size_t)slot * 320u;
+                for (uint32_t k = 0; k < 320u; k++) bl[k] = k < total ? L.lens[k][lane] : (uint8_t)0;
+            } else v.ctl[A_OVER] = 1u;
+        }
+    }
+}
+
+// the candidates ordered by position (all distinct): rank by counting, one workgroup
+constexpr uint32_t SORT_T = 1024;
+__global__ __launch_bounds__(SORT_T) void k_any_sort(Args a) {
+    const View v = view(a);
+    extern __shared__ uint32_t hs[];                                // [maxb]
+    if (!v.run) return;
+    if (v.ctl[A_OVER] != 0u) { if (threadIdx.x == 0u) give_up(v); return; }
+    const uint32_t n = min(v.ctl[A_NBLK], a.maxb);
+    for (uint32_t i = threadIdx.x; i < n; i += SORT_T) hs[i] = v.blk[i].hdr;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += SORT_T) {
+        const uint32_t h = hs[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) rank += hs[j] < h ? 1u : 0u;
+        v.shdr[rank] = h; v.spay[rank] = v.blk[i].pay; v.sidx[rank] = i;
+    }
+}
+
+// the decode tables of candidate `r` (slot r; slot maxb: the fixed code, deflate.py:1066-1073), one workgroup each
+struct TabLds {
+    Tab t;
+    uint8_t len[320];
+    uint32_t cnt[32], first[32], off[32];
+};
+constexpr uint32_t TAB_T = 256;
+__global__ __launch_bounds__(TAB_T) void k_any_tables(Args a) {
+    const View v = view(a);
+    __shared__ TabLds L;
+    if (!v.run) return;
+    const uint32_t tid = threadIdx.x, n = min(v.ctl[A_NBLK], a.maxb);
+    for (uint32_t r = blockIdx.x; r <= n; r += gridDim.x) {
+        const uint32_t slot = r < n ? r : a.maxb;
+        uint32_t nlen = 288u;
+        __syncthreads();
+        if (r < n) {
+            const uint32_t bi = v.sidx[r];
+            nlen = v.blk[bi].nlen;
+            const uint8_t* bl = v.blen + (size_t)bi * 320u;
+            for (uint32_t k = tid; k < 320u; k += TAB_T) L.len[k] = bl[k];
+        } else {
+            for (uint32_t k = tid; k < 320u; k += TAB_T) L.len[k] = (uint8_t)(k < 144u ? 8 : k < 256u ? 9 : k < 280u ? 7 : k < 288u ? 8 : 5);
+        }
+        uint32_t* tw = reinterpret_cast<uint32_t*>(&L.t);
+        for (uint32_t k = tid; k < sizeof(Tab) / 4u; k += TAB_T) tw[k] = 0u;
+        if (tid < 32u) L.cnt[tid] = 0u;
+        __syncthreads();
+        const uint32_t ndist = 320u - nlen;                          // (lengths beyond HDIST + 1 are zero)
+        for (uint32_t k = tid; k < 320u; k += TAB_T) { const uint32_t l = L.len[k]; if (l) atomicAdd(&L.cnt[(k < nlen ? 0u : 16u) + l], 1u); }
+        __syncthreads();
+        if (tid < 2u) {
+            uint32_t code = 0, o = 0;
+            const uint32_t b = 16u * tid;
+            L.first[b] = 0u; L.off[b] = 0u;
+            for (uint32_t l = 1; l < 16u; l++) {
+                code = (code + (l > 1u ? L.cnt[b + l - 1u] : 0u)) << 1;
+                L.first[b + l] = code; L.off[b + l] = o;
+                o += L.cnt[b + l];
+            }
+        }
+        __syncthreads();
+        if (tid < 16u) {
+            L.t.lfirst[tid] = (uint16_t)L.first[tid]; L.t.lcnt[tid] = (uint16_t)(tid ? L.cnt[tid] : 0u); L.t.loff[tid] = (uint16_t)L.off[tid];
+            L.t.dfirst[tid] = (uint16_t)L.first[16u + tid]; L.t.dcnt[tid] = (uint16_t)(tid ? L.cnt[16u + tid] : 0u); L.t.doff[tid] = (uint16_t)L.off[16u + tid];
+        }
+        // every symbol: its place among the codes of its length (by value), its canonical code, its table entries
+        for (uint32_t k = tid; k < 320u; k += TAB_T) {
+            const uint32_t l = L.len[k];
+            if (l == 0u) continue;
+            const bool isd = k >= nlen;
+            const uint32_t k0 = isd ? nlen : 0u, sym = k - k0, b = isd ? 16u : 0u;
+            uint32_t rank = 0;
+            for (uint32_t j = k0; j < k; j++) rank += L.len[j] == l ? 1u : 0u;
+            const uint32_t code = L.first[b + l] + rank;
+            const uint32_t rv = __builtin_bitreverse32(code) >> (32u - l);
+            if (isd) {
+                L.t.dsym[L.off[b + l] + rank] = (uint16_t)sym;
+                if (l <= DB) for (uint32_t e = rv; e < (1u << DB); e += 1u << l) L.t.dd[e] = (uint16_t)(sym | (l << 5));
+            } else {
+                L.t.lsym[L.off[b + l] + rank] = (uint16_t)sym;
+                if (l <= LB) for (uint32_t e = rv; e < (1u << LB); e += 1u << l) L.t.ll[e] = (uint16_t)(sym | (l << 9));
+            }
+        }
+        (void)ndist;
+        __syncthreads();
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&v.tab[slot]);
+        for (uint32_t k = tid; k < sizeof(Tab) / 4u; k += TAB_T) dst[k] = tw[k];
+    }
+}
+
+// ================================================================================================ 2. pieces and their maps
+// piece q = the stream bits [q PB, (q + 1) PB); its owner: the last candidate whose payload starts at or in front of its first bit
+__global__ __launch_bounds__(64) void k_any_owner(Args a) {
+    const View v = view(a);
+    if (!v.run) return;
+    const uint32_t n = min(v.ctl[A_NBLK], a.maxb);
+    for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const uint32_t q0 = (v.spay[r] + PB - 1u) / PB;
+        const uint32_t q1 = r + 1u < n ? min((v.spay[r + 1u] + PB - 1u) / PB, a.nchunks) : a.nchunks;
+        for (uint32_t q = q0 + threadIdx.x; q < q1; q += 64u) v.owner[q] = (uint16_t)r;
+    }
+}
+
+// a map entry: kind << 30 | offset << 19 | bytes.  kind 0: the chain leaves the piece `offset` bits behind its end; 2: it meets the
+// block's end-of-block code, which ends `offset` bits behind the piece's FIRST bit; 3: a bit pattern that is no code
+constexpr uint32_t SPEC_W = 4;                // waves per workgroup, each with its own tables
+struct SpecLds {
+    Tab t[SPEC_W];
+    uint32_t win[SPEC_W][PB / 32 + 8];
+};
+__global__ __launch_bounds__(64 * SPEC_W) void k_any_spec(Args a) {
+    const View v = view(a);
+    __shared__ SpecLds L;
+    if (!v.run) return;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t nw = gridDim.x * SPEC_W, g = blockIdx.x * SPEC_W + wv;
+    const uint32_t per = (a.nchunks + nw - 1u) / nw;
+    const uint32_t q0 = g * per, q1 = min(q0 + per, a.nchunks);
+    const Tab* t = &L.t[wv];
+    uint32_t* win = L.win[wv];
+    uint32_t cur = NO_OWNER;
+    for (uint32_t q = q0; q < q1; q++) {
+        const uint32_t r = v.owner[q];
+        if (r == NO_OWNER) continue;
+        if (r != cur) {
+            const tok::u32x4* src = reinterpret_cast<const tok::u32x4*>(&v.tab[r]);
+            tok::u32x4* dst = reinterpret_cast<tok::u32x4*>(&L.t[wv]);
+            for (uint32_t k = lane; k < sizeof(Tab) / 16u; k += 64u) dst[k] = src[k];
+            cur = r;
+        }
+        const uint32_t b0 = q * PB, end = b0 + PB;
+        for (uint32_t k = lane; k < PB / 32u + 8u; k += 64u) win[k] = tok::load32(v.z, (b0 >> 3) + 4u * k, v.zn);
+        wave_lds_order();
+        __builtin_amdgcn_wave_barrier();
+        uint32_t pos = b0 + lane, nbytes = 0, res = 0;
+        bool run = true;
+        while (ballot64(run) != 0ull) {
+            if (run) {
+                const uint32_t rel = pos - b0, w = rel >> 5, sh = rel & 31u;
+                const uint32_t d0 = win[w], d1 = win[w + 1u], d2 = win[w + 2u];
+                const uint64_t x = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+                uint32_t sym, len;
+                sym_of<LB, 9u, 511u>(t->ll, t->lfirst, t->lcnt, t->loff, t->lsym, (uint32_t)x, sym, len);
+                if (len == 0u) { res = 3u << 30; run = false; }
+                else if (sym < 256u) { pos += len; nbytes += 1u; }
+                else if (sym == 256u) { res = (2u << 30) | ((pos + len - b0) << 19) | nbytes; run = false; }
+                else {
+                    uint32_t lbase, leb, ds, dl;
+                    tok::length_info(sym - 257u, lbase, leb);
+                    const uint64_t x1 = x >> len;
+                    const uint32_t tl = lbase + ((uint32_t)x1 & ((1u << leb) - 1u));
+                    sym_of<DB, 5u, 31u>(t->dd, t->dfirst, t->dcnt, t->doff, t->dsym, (uint32_t)(x1 >> leb), ds, dl);
+                    if (dl == 0u) { res = 3u << 30; run = false; }
+                    else {
+                        const uint32_t deb = ds < 4u ? 0u : (ds >> 1) - 1u;
+                        pos += len + leb + dl + deb;
+                        nbytes += tl;
+                    }
+                }
+                if (run && pos >= end) { res = ((pos - end) << 19) | nbytes; run = false; }
+                if (nbytes >= (1u << 19)) { res = 3u << 30; run = false; }       // (cannot happen: 512 tokens of 258 bytes)
+            }
+        }
+        v.map[(size_t)q * 64u + lane] = res;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ================================================================================================ 3. the chain of blocks
+__device__ __forceinline__ uint32_t find_rank(const uint32_t* shdr, uint32_t n, uint32_t hdr) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (shdr[m] < hdr) lo = m + 1u; else hi = m; }
+    return lo < n && shdr[lo] == hdr ? lo : N_BAD;
+}
+__global__ __launch_bounds__(64) void k_any_walk(Args a) {
+    const View v = view(a);
+    if (!v.run) return;
+    const uint32_t n = min(v.ctl[A_NBLK], a.maxb);
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;                // node: candidate rank i < n, or the pseudo-node i == n (stored at index maxb)
+    if (i > n) return;
+    const uint32_t nbits = 8u * v.zn;
+    const int32_t isize = (int32_t)v.zn - 1;
+    const uint32_t len_mask = a.obsize ? ((1u << (31u - (uint32_t)__builtin_clz(a.obsize))) - 1u) : 0xFFFFu;     // deflate.py:329,:714
+    const uint32_t node_id = i < n ? i : a.maxb;
+    uint64_t nb = 0;                      // bytes of this node so far
+    uint32_t ebit = 16u, fin = 0u, next = N_BAD;
+    bool ok = true;
+    Bits rd;
+    auto add_xitem = [&](uint32_t start, uint32_t limit, uint32_t slot) {
+        const uint32_t k = atomicAdd(&v.ctl[A_NX], 1u);
+        if (k < a.maxx) v.xitem[k] = XItem{start, limit, (uint32_t)nb, node_id | (slot << 16)};
+        else { v.ctl[A_OVER] = 1u; ok = false; }
+    };
+    // bits [rd.pos, limit) with the tables of `slot`, counting bytes; -> true at the end-of-block code (consumed)
+    auto run_to = [&](const Tab* t, uint32_t limit, bool& eob) {
+        eob = false;
+        while (ok && rd.pos < limit) {
+            const Token k = token_at(t, rd);
+            if (k.kind == 3u) { ok = false; break; }
+            if (k.kind == 2u) { eob = true; break; }
+            nb += k.kind == 0u ? 1u : k.length;
+        }
+    };
+    if (i < n) {
+        const Blk b = v.blk[v.sidx[i]];
+        fin = b.fin;
+        rd.init(v.z, v.zn, b.pay);
+        bool eob = false;
+        uint32_t q = b.pay / PB;
+        if (b.pay % PB != 0u) {                                       // the first, partial piece: by this lane
+            const uint32_t limit = (q + 1u) * PB;
+            add_xitem(b.pay, limit, i);
+            run_to(&v.tab[i], limit, eob);
+            q++;
+        }
+        uint32_t pos = rd.pos;
+        while (ok && !eob) {                                          // whole pieces: through the maps
+            if (q >= a.nchunks || v.owner[q] != i || pos - q * PB >= 64u) { ok = false; break; }
+            const uint32_t e = pos - q * PB;
+            const uint32_t m = v.map[(size_t)q * 64u + e], kind = m >> 30, off = (m >> 19) & 2047u;
+            v.pent[q] = (uint8_t)e; v.prel[q] = (uint32_t)nb; v.pnode[q] = (uint16_t)i;
+            nb += m & 0x7FFFFu;
+            if (kind == 0u) { pos = (q + 1u) * PB + off; q++; }
+            else if (kind == 2u) { pos = q * PB + off; eob = true; }
+            else ok = false;
+        }
+        ebit = pos;
+        if (nb > 0xFFFFFFFFull) ok = false;
+    }
+    // behind the block: the blocks that cannot be found by search, up to the next dynamic header
+    uint32_t guard = 0;
+    while (ok) {
+        if (fin) { next = N_END; break; }
+        if (ebit + 3u > nbits || ++guard > 0x100000u) { ok = false; break; }
+        rd.init(v.z, v.zn, ebit);
+        const uint32_t f = (uint32_t)rd.bb & 1u, ty = ((uint32_t)rd.bb >> 1) & 3u;
+        if (ty == 2u) { next = find_rank(v.shdr, n, ebit); ok = next != N_BAD; break; }
+        if (ty == 3u) { ok = false; break; }
+        if (ty == 0u) {
+            // stored (deflate.py:709-717, :1603-1626): LEN sits `skip` bits behind the header's first bit, NLEN is not checked (D2)
+            const uint32_t dio = ebit & 7u;
+            uint32_t skip = 8u - dio;
+            if (skip <= 2u) skip = 16u - dio;
+            const uint32_t length = (uint32_t)(rd.bb >> skip) & 0xFFFFu & len_mask;
+            const uint32_t p0 = (ebit + skip + 32u) >> 3;
+            const uint32_t i_noeof = (int32_t)p0 >= isize ? 0u : (uint32_t)isize - p0;
+            if (length > i_noeof || (int32_t)(p0 + length) >= isize) { ok = false; break; }
+            if (length) {
+                const uint32_t k = atomicAdd(&v.ctl[A_NS], 1u);
+                if (k < a.maxs) v.sitem[k] = SItem{p0, length, (uint32_t)nb, node_id};
+                else { v.ctl[A_OVER] = 1u; ok = false; break; }
+            }
+            nb += length;
+            ebit = 8u * (p0 + length);
+        } else {
+            // fixed: decoded by this lane, an item per piece it touches
+            rd.take(3u);
+            const uint32_t stop = rd.pos + FIX_MAX_BITS;
+            bool eob = false;
+            while (ok && !eob) {
+                const uint32_t limit = (rd.pos / PB + 1u) * PB;
+                if (rd.pos >= stop) { ok = false; break; }
+                add_xitem(rd.pos, limit, a.maxb);
+                run_to(&v.tab[a.maxb], limit, eob);
+            }
+            ebit = rd.pos;
+        }
+        if (nb > 0xFFFFFFFFull) { ok = false; break; }
+        fin = f;
+    }
+    v.node[node_id] = Node{next, (uint32_t)nb, ok ? 1u : 0u, 0u};
+}
+
+// one thread follows the successors from the pseudo-node: the true chain, the output position of every block on it, the total
+__global__ __launch_bounds__(256) void k_any_rank(Args a) {
+    const View v = view(a);
+    extern __shared__ uint32_t nl[];                                // [maxb + 1][2]: next, bytes | ok << 31 ... kept as two words
+    if (!v.run) return;
+    const uint32_t n = min(v.ctl[A_NBLK], a.maxb);
+    if (v.ctl[A_OVER] != 0u) { if (threadIdx.x == 0u) give_up(v); return; }
+    for (uint32_t k = threadIdx.x; k <= n; k += 256u) {
+        const Node nd = v.node[k < n ? k : a.maxb];
+        nl[2u * k] = nd.ok ? nd.next : N_BAD; nl[2u * k + 1u] = nd.nbytes;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0u) return;
+    uint64_t acc = 0;
+    uint32_t cur = n, steps = 0;
+    bool good = true;
+    for (;;) {
+        const uint32_t nx = nl[2u * cur], by = nl[2u * cur + 1u];
+        if (nx == N_BAD) { good = false; break; }
+        Node* nd = &v.node[cur < n ? cur : a.maxb];
+        nd->obase = (uint32_t)acc; nd->ok = 2u;
+        acc += by;
+        if (acc > (uint64_t)a.cap || acc > (uint64_t)a.srcn) { good = false; break; }
+        if (nx == N_END) break;
+        cur = nx;
+        if (cur >= n || ++steps > n + 1u) { good = false; break; }
+    }
+    const uint32_t nx_items = v.ctl[A_NX], ns_items = v.ctl[A_NS];
+    if (nx_items > a.maxx || ns_items > a.maxs) good = false;
+    if (!good) { give_up(v); return; }
+    v.ctl[C_TOTAL] = (uint32_t)acc;
+    v.ctl[C_NUSED] = a.nchunks + nx_items;
+    v.ctl[C_FNUSED] = a.nchunks + nx_items;
+    v.ctl[C_OK] = 1u;
+}
+
+// ================================================================================================ 4. the real decode
+// one LANE per item: the pieces the walks went through (entry offset and position from the walk) and the extra items; the reference's
+// checks (deflate.py:1409-1445, :1519-1591, :1447-1517, :1600) are all evaluated -- WHICH one failed does not matter here, any failure
+// hands the stream to the serial decoder, which reports the reference's status in the reference's order
+__global__ __launch_bounds__(64) void k_any_tokens(Args a) {
+    const View v = view(a);
+    if (!v.run || v.ctl[C_OK] == 0u) return;
+    const uint32_t nitems = v.ctl[C_NUSED];
+    const int32_t isize = (int32_t)v.zn - 1;
+    const uint32_t obsize = a.obsize ? a.obsize : 32768u;
+    bool bad = false;
+    for (uint32_t i0 = blockIdx.x * 64u; i0 < nitems; i0 += gridDim.x * 64u) {
+        const uint32_t i = i0 + threadIdx.x;
+        if (i >= nitems) continue;
+        uint32_t start, limit, rel, nid, slot;
+        if (i < a.nchunks) {
+            nid = v.pnode[i];
+            if (nid == NO_OWNER) continue;
+            start = i * PB + v.pent[i]; limit = (i + 1u) * PB; rel = v.prel[i]; slot = nid;
+        } else {
+            const XItem x = v.xitem[i - a.nchunks];
+            start = x.start; limit = x.limit; rel = x.rel; nid = x.node_slot & 0xFFFFu; slot = x.node_slot >> 16;
+        }
+        const Node nd = v.node[nid];
+        if (nd.ok != 2u) continue;                                   // not on the chain
+        const Tab* t = &v.tab[slot];
+        uint32_t P = nd.obase + rel, nt = 0;
+        uint32_t* tk = v.tok + (size_t)i * a.tcap;
+        v.opos[i] = P;
+        Bits rd;
+        rd.init(v.z, v.zn, start);
+        while (rd.pos < limit) {
+            const uint32_t p0 = rd.pos;
+            const Token k = token_at(t, rd);
+            bool f = k.kind == 3u || (int32_t)((p0 + k.nb) >> 3) > isize - 3;                      // no code; NO EOF (deflate.py:1535-1539)
+            if (k.kind == 2u) { bad |= f; break; }
+            const uint32_t made = k.kind == 0u ? 1u : k.length;
+            f |= (uint64_t)P + made > a.cap;
+            f |= k.kind == 1u && (k.dist > P || k.dist > obsize || (int32_t)((p0 + k.used) >> 3) >= isize - 2);     // D8; COPY hold (:1600)
+            f |= nt >= a.tcap;
+            if (f) { bad = true; break; }
+            tk[nt++] = k.kind == 0u ? (TOK_LIT | k.lit) : (k.length | (k.dist << 9));
+            P += made;
+        }
+        v.ntok[i] = nt;
+    }
+    if (ballot64(bad) != 0ull && (threadIdx.x & 63u) == 0u) give_up(v);
+}
+
+// the stored blocks: straight copies; their bytes are there (no marker)
+__global__ __launch_bounds__(256) void k_any_stored(Args a) {
+    const View v = view(a);
+    if (!v.run || v.ctl[C_OK] == 0u) return;
+    const uint32_t ns = min(v.ctl[A_NS], a.maxs);
+    for (uint32_t k = blockIdx.x; k < ns; k += gridDim.x) {
+        const SItem s = v.sitem[k];
+        const Node nd = v.node[s.node];
+        if (nd.ok != 2u) continue;
+        const uint32_t P = nd.obase + s.rel;
+        for (uint32_t j = threadIdx.x; j < s.len; j += 256u) { v.out[P + j] = v.z[s.src + j]; v.srcA[P + j] = NONE; }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_any_zero(Args a) {
+    uint32_t* ctl = reinterpret_cast<uint32_t*>(a.ws + (size_t)blockIdx.y * a.stride);
+    if (threadIdx.x < par::C_WORDS) ctl[threadIdx.x] = 0u;
+}
+
+constexpr uint32_t ANY_MIN = 16384;           // streams below this stay with the serial decoder (the chain of launches costs ~0.1 ms)
+struct Lay {
+    uint32_t nchunks, candcap, maxb, maxx, maxs, tcap;
+    size_t o_cand, o_blk, o_blen, o_shdr, o_spay, o_sidx, o_tab, o_owner, o_map, o_pent, o_prel, o_pnode, o_node, o_xitem, o_sitem,
+           o_opos, o_ntok, o_tok, o_mext, bytes;
+};
+static Lay lay_of(uint32_t zn) {
+    Lay L;
+    memset(&L, 0, sizeof(L));
+    const uint64_t nbits = 8ull * zn;
+    L.nchunks = (uint32_t)((nbits + PB - 1u) / PB);
+    L.candcap = (uint32_t)(nbits / 512u) + 1024u;
+    L.maxb = zn / 2048u < 64u ? 64u : zn / 2048u > 4096u ? 4096u : zn / 2048u;
+    L.maxx = 4u * L.maxb + 256u;
+    L.maxs = zn / 4096u + 256u;
+    L.tcap = 256u;
+    size_t off = 256;                                               // the control words in front
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
+    const size_t items = (size_t)L.nchunks + L.maxx;
+    L.o_cand = take(4u * (size_t)L.candcap); L.o_blk = take(sizeof(Blk) * L.maxb); L.o_blen = take(320u * (size_t)L.maxb);
+    L.o_shdr = take(4u * L.maxb); L.o_spay = take(4u * L.maxb); L.o_sidx = take(4u * L.maxb);
+    L.o_tab = take(sizeof(Tab) * ((size_t)L.maxb + 1u)); L.o_owner = take(2u * (size_t)L.nchunks); L.o_map = take(256u * (size_t)L.nchunks);
+    L.o_pent = take(L.nchunks); L.o_prel = take(4u * (size_t)L.nchunks); L.o_pnode = take(2u * (size_t)L.nchunks);
+    L.o_node = take(sizeof(Node) * ((size_t)L.maxb + 1u)); L.o_xitem = take(sizeof(XItem) * L.maxx); L.o_sitem = take(sizeof(SItem) * L.maxs);
+    L.o_opos = take(4u * items); L.o_ntok = take(4u * items); L.o_tok = take(4u * (size_t)L.tcap * items); L.o_mext = take(4u * items);
+    L.bytes = off;
+    return L;
+}
+
+}  // namespace any
+
+size_t any_work_bytes(uint32_t in_len, uint64_t out_pitch, uint32_t flags) {
+    (void)out_pitch;
+    if (in_len < any::ANY_MIN || (flags & (HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_ONEBLOCK))) return 0;     // (those builds read every block as fixed / stop at the first one)
+    return any::lay_of(in_len).bytes;
+}
+
+hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, size_t ws_stride, size_t ws_off, size_t sa_off,
+                              const uint32_t* gate, uint32_t srcn, uint32_t cap, hipStream_t stream, uint32_t* passes_out) {
+    using namespace any;
+    const Lay L = lay_of(a.in_len);
+    Args g;
+    memset(&g, 0, sizeof(g));
+    g.z = a.in; g.zn = a.in_len; g.flags = a.flags; g.obsize = a.obsize; g.out = a.out; g.cap = cap; g.srcn = srcn;
+    g.in_pitch = a.in_pitch; g.out_pitch = a.out_pitch; g.in_off = a.in_off;
+    g.ws = ws + ws_off; g.stride = ws_stride; g.gate = gate; g.srcA = reinterpret_cast<uint32_t*>(ws + sa_off);
+    g.nchunks = L.nchunks; g.candcap = L.candcap; g.maxb = L.maxb; g.maxx = L.maxx; g.maxs = L.maxs; g.tcap = L.tcap;
+    g.o_cand = L.o_cand; g.o_blk = L.o_blk; g.o_blen = L.o_blen; g.o_shdr = L.o_shdr; g.o_spay = L.o_spay; g.o_sidx = L.o_sidx; g.o_tab = L.o_tab;
+    g.o_owner = L.o_owner; g.o_map = L.o_map; g.o_pent = L.o_pent; g.o_prel = L.o_prel; g.o_pnode = L.o_pnode; g.o_node = L.o_node;
+    g.o_xitem = L.o_xitem; g.o_sitem = L.o_sitem; g.o_opos = L.o_opos; g.o_ntok = L.o_ntok; g.o_tok = L.o_tok; g.o_mext = L.o_mext;
+    const uint32_t nitems = L.nchunks + L.maxx;
+    auto gx = [](uint64_t work, uint32_t cap_) { return (unsigned)(work < 1u ? 1u : work > cap_ ? cap_ : work); };
+    hipLaunchKernelGGL(k_any_zero, dim3(1, nstr), dim3(64), 0, stream, g);
+    hipLaunchKernelGGL(k_any_find, dim3(gx((a.in_len + FIND_T - 1u) / FIND_T, 4096u), nstr), dim3(FIND_T), 0, stream, g);
+    hipLaunchKernelGGL(k_any_headers, dim3(gx((L.candcap + 63u) / 64u, 1280u), nstr), dim3(64), 0, stream, g);
+    hipLaunchKernelGGL(k_any_sort, dim3(1, nstr), dim3(SORT_T), 4u * L.maxb, stream, g);
+    hipLaunchKernelGGL(k_any_tables, dim3(gx(L.maxb + 1u, 1024u), nstr), dim3(TAB_T), 0, stream, g);
+    hipLaunchKernelGGL(k_any_owner, dim3(gx(L.maxb, 1024u), nstr), dim3(64), 0, stream, g);
+    hipLaunchKernelGGL(k_any_spec, dim3(gx((L.nchunks + SPEC_W - 1u) / SPEC_W, 1536u), nstr), dim3(64 * SPEC_W), 0, stream, g);
+    hipLaunchKernelGGL(k_any_walk, dim3((L.maxb + 1u + 63u) / 64u, nstr), dim3(64), 0, stream, g);
+    hipLaunchKernelGGL(k_any_rank, dim3(1, nstr), dim3(256), 8u * (L.maxb + 1u), stream, g);
+    hipLaunchKernelGGL(k_any_tokens, dim3(gx((nitems + 63u) / 64u, 8192u), nstr), dim3(64), 0, stream, g);
+    hipLaunchKernelGGL(k_any_stored, dim3(gx(L.maxs, 1024u), nstr), dim3(256), 0, stream, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // the bytes: the kernels of hdlz_inflate_par.hip on this chain's items (one "piece" each, no sub-pieces)
+    par::ParArgs p;
+    memset(&p, 0, sizeof(p));
+    p.z = a.in; p.zn = a.in_len; p.flags = a.flags; p.obsize = a.obsize; p.out = a.out; p.cap = cap; p.srcn = srcn;
+    p.out_len = a.out_len; p.status = a.status; p.nchunks = nitems; p.chbits = PB;
+    p.ctl = reinterpret_cast<uint32_t*>(g.ws);
+    p.opos = reinterpret_cast<uint32_t*>(g.ws + L.o_opos); p.tokens = reinterpret_cast<uint32_t*>(g.ws + L.o_tok); p.tcap = L.tcap;
+    p.ntok = reinterpret_cast<uint32_t*>(g.ws + L.o_ntok); p.srcA = g.srcA; p.sub = 1u; p.cnu = par::C_NUSED;
+    p.mext = reinterpret_cast<uint32_t*>(g.ws + L.o_mext);
+    p.in_pitch = a.in_pitch; p.out_pitch = a.out_pitch; p.in_off = a.in_off; p.ws_stride = ws_stride; p.batch = nstr > 1u ? 1u : 0u;
+    const uint32_t passes = par::passes_for(nitems);
+    *passes_out = passes;
+    return par::par_launch_emit_jump(p, nitems, passes, nstr, stream);
+}
+
+}  // namespace hdlz

@@ -30,6 +30,7 @@
 #include <string.h>
 #include "hdlz_device.h"
 #include "hdlz_inflate_tables.h"
+#include "hdlz_inflate_par.h"
 
 namespace hdlz {
 namespace par {
@@ -39,53 +40,6 @@ using tok::T_EOB;
 using tok::T_LIT;
 using tok::T_LEN;
 
-constexpr uint32_t CH_BITS_MAX = 8192;        // a piece: 1 KiB of the stream -- 512 bytes for streams below 24 MiB, 256 below 3 MiB, 128 below 1.25 MiB: a piece is ONE
-                                              // wave's (lane's) serial chain in k_par_spec and k_par_tokens, and 16 MiB in 1 KiB pieces do not fill the
-                                              // GPU twice (16 MiB: 1.37 -> 1.24 ms, 1 MiB: 0.76 -> 0.45 ms with 512-byte pieces)
-constexpr uint32_t WIN_DW = CH_BITS_MAX / 32 + 8; // its staged window: the piece, the 31 + 64 bits a token starting at its end may read
-constexpr uint32_t FIRST_BIT = 19;            // 2 zlib header bytes, BFINAL, BTYPE
-constexpr uint32_t X_EOB = 0x40, X_BAD = 0x80;
-constexpr uint32_t SUB = 4;                   // sub-pieces per piece: the granularity of the real decode and the emit (k_par_spec)
-constexpr uint32_t NONE = 0xFFFFFFFFu;
-enum { C_FALLBACK = 0, C_NUSED = 1, C_TOTAL = 2, C_OK = 3, C_MARK = 4, C_FNUSED = 5, C_PASS0 = 8, C_WORDS = 64 };
-
-struct ParArgs {
-    const uint8_t* z;
-    uint32_t zn;
-    uint32_t flags, obsize;
-    uint8_t* out;
-    uint32_t cap;               // output capacity (bytes)
-    uint32_t srcn;              // entries of srcA
-    uint32_t* out_len;
-    uint32_t* status;
-    uint32_t nchunks;
-    uint32_t chbits;            // bits per piece
-    uint32_t* ctl;              // C_WORDS control words (zeroed)
-    uint8_t* exit8;             // [nchunks][32]
-    uint32_t* nb32;             // [nchunks][32]
-    uint8_t* entry8;            // [nchunks]
-    uint32_t* opos;             // [nchunks]
-    uint8_t* gexit8;            // [ngroups][32]  the same maps for groups of 64 pieces
-    uint8_t* gstop8;            // [ngroups][32]  piece of the group in which the chain ends
-    uint32_t* gnb32;            // [ngroups][32]
-    uint8_t* gentry8;           // [ngroups]
-    uint32_t* gopos;            // [ngroups]
-    uint32_t* tokens;           // [nchunks][tmax_of(chbits)]  the tokens of every piece
-    uint32_t* ntok;             // [nchunks]
-    uint32_t* srcA;             // [srcn]  marker of every output byte: the absolute position it comes from; NONE / ROOT | r: the byte is there
-    uint32_t sub;               // k_par_spec: sub-pieces per piece (SUB), whose boundaries get maps of their own
-    uint8_t* mexit8;            // [nchunks][SUB-1][32]  offset behind sub-boundary s for entry offset e (X_EOB: the chain ended in front of it)
-    uint32_t* mnb32;            // [nchunks][SUB-1][32]  bytes of the tokens that start in front of that boundary
-    uint32_t cnu;               // the control word that holds the number of pieces in use at THIS granularity (C_NUSED / C_FNUSED)
-    uint32_t* mext;             // [nchunks]  bytes from a piece's first output byte to behind its LAST marker (0: it has none)
-    // SEVERAL streams in the same launches (round 5): blockIdx.y is the stream; stream s reads z + s * in_pitch, writes out + s * out_pitch,
-    // out_len[s], status[s], and owns the scratch ws_stride bytes behind stream s - 1's (every array above, same layout)
-    uint64_t in_pitch, out_pitch;
-    const uint64_t* in_off;     // nullable.  Ragged input: stream s is z[in_off[s] .. in_off[s + 1]); zn is then the caller's BOUND on the lengths (the
-                                // pieces are laid out for it; bytes behind a stream's own end read as zero, like the padding of a pitched row)
-    size_t ws_stride;
-    uint32_t batch;             // != 0: a stream the path gives up on is FLAGGED for the serial pass (status HDLZ_E_DYNAMIC_UNSUPPORTED)
-};
 // (pointer arithmetic, NOT a round trip through an integer: that makes the pointer generic and every access through it a flat_load /
 //  flat_store, which waits on the LDS counter as well -- k_par_emit ran 7.7 ms instead of 0.15 that way)
 template <typename T> __device__ __forceinline__ void shift_ptr(T*& p, size_t bytes) {
@@ -225,7 +179,6 @@ struct Chains {
     uint8_t* cmx;               // [chains][SUB-1]  the sub-boundary maps, as in ParArgs::mexit8 / mnb32 (bytes from cpos on)
     uint32_t* cmn;
 };
-enum { C_NCHAIN = 6 };
 __device__ __forceinline__ Chains of_stream(Chains ch, size_t ws_stride) {
     const size_t d = (size_t)blockIdx.y * ws_stride;
     shift_ptr(ch.rep, d); shift_ptr(ch.cpos, d); shift_ptr(ch.cexit, d); shift_ptr(ch.cnb, d); shift_ptr(ch.cmx, d); shift_ptr(ch.cmn, d);
@@ -421,7 +374,7 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a_) {
     __shared__ uint8_t pathb[8][32][8], segmap[8][32], segstop[8][32], segent[8];
     const uint32_t lane = threadIdx.x;                     // (256 threads: staging, and 8 segments x 32 entry offsets for the walk)
     // the stream must be one fixed block (or be read as one: the DYNAMIC=False / ONEBLOCK builds)
-    if (!one_fixed_block(a)) { if (lane == 0u) a.ctl[C_FALLBACK] = 1u; return; }
+    if (!one_fixed_block(a)) { if (lane == 0u) { a.ctl[C_FALLBACK] = 1u; a.ctl[C_NOTFIXED] = 1u; } return; }
     const uint32_t ngroups = (a.nchunks + GROUP - 1u) / GROUP;
     if (lane == 0u) { sh_stop = 0; sh_e = 0; sh_bad = 0; sh_nused = 0; sh_acc = 0; }
     __syncthreads();
@@ -540,8 +493,6 @@ __global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a_, uint8_t* fen
 // ---- 3a. the real decode, tokens only: one LANE per piece (64 pieces per wave), the reference's checks
 // in the reference's order, the tokens into a list per piece.  (One WAVE per piece decoding and copying kept the CU's one scalar unit
 // 89 % busy -- the token chain of a piece is wave-uniform, 115 scalar instructions per token: 8.2 of 13.7 ms at 256 MiB.)
-constexpr uint32_t TOK_LIT = 0x80000000u;     // a token: TOK_LIT | byte, or length | distance << 9
-__host__ __device__ inline uint32_t tmax_of(uint32_t chbits) { return chbits / 8u + 2u; }      // the shortest token is 8 bits long
 template <bool ROWS>
 __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a_) {
     const ParArgs a = of_stream(a_);
@@ -560,7 +511,7 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a_) {
     const uint32_t obsize = a.obsize ? a.obsize : 32768u;
     const uint32_t b_c = FIRST_BIT + c * a.chbits, end = b_c + a.chbits;
     uint32_t pos = have ? b_c + a.entry8[c] : 0u, P = have ? a.opos[c] : 0u;
-    uint32_t* tk = a.tokens + (size_t)c * tmax_of(a.chbits);
+    uint32_t* tk = a.tokens + (size_t)c * a.tcap;
     // bit reader straight from the stream (64 KB of LDS windows per wave left two waves per CU and every LDS / store round trip
     // exposed: 2.9 ms at 256 MiB): bb holds bc valid bits from `pos` on, `nxt` is the dword behind them, requested a refill ahead
     uint32_t ip = (pos >> 3) & ~3u, bc = 64u - (pos - 8u * ip), n = 0, jn = 2u;
@@ -648,7 +599,7 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a_) {
         const uint32_t f = c * nsub + sbi;
         if (f >= fnused) break;
         const uint32_t n = a.ntok[f];
-        const uint32_t* tk = a.tokens + (size_t)f * tmax_of(a.chbits / nsub);
+        const uint32_t* tk = a.tokens + (size_t)f * a.tcap;
         // (the piece's tokens staged in LDS first -- no global load in front of a batch -- cost more in occupancy than it saved: 245 -> 301 us)
         for (uint32_t base = 0; base < n;) {
             const uint32_t k = base + lane;
@@ -751,7 +702,7 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a_) {
 // a launch) or the new one -- is a valid ancestor.  The one thing a reader must not do is take the BYTE of a position that was resolved
 // in the launch it runs in (that store may not be visible yet): a resolved position keeps ROOT | r, r = the byte of the emit its chain
 // ends in -- final since the emit -- and a chain that arrives there takes out[r], not out[p].
-constexpr uint32_t HOPS = 256;                // (8 in round 2: a pass that finds nothing left still costs a launch, 4.5 us -- three passes cover 65536 pieces)
+// (HOPS, hdlz_inflate_par.h: 8 in round 2 -- a pass that finds nothing left still costs a launch, 4.5 us; three passes of 256 cover 65536 pieces)
 constexpr uint32_t ROOT = 0x80000000u;        // src word: ROOT | r = resolved, the byte is out[r] (NONE: a byte of the emit, its own root); positions are < 2^30
 __global__ __launch_bounds__(64) void k_par_jump(ParArgs a_, uint32_t pass) {
     const ParArgs a = of_stream(a_);
@@ -798,12 +749,20 @@ __global__ __launch_bounds__(64) void k_par_jump(ParArgs a_, uint32_t pass) {
 }
 
 // ---- 5. the verdict: HDLZ_OK and the length, or the serial decoder's turn
-__global__ __launch_bounds__(64) void k_par_finish(ParArgs a_, uint32_t passes) {
+// (`actl`: the control words of the chain for any block types, stream 0's; null when that chain was not launched)
+__global__ __launch_bounds__(64) void k_par_finish(ParArgs a_, uint32_t passes, const uint32_t* actl, uint32_t apasses) {
     const ParArgs a = of_stream(a_);
     if (threadIdx.x != 0) return;
     const uint32_t left = a.ctl[C_MARK] == 0u ? 0u : a.ctl[C_PASS0 + passes - 1u];
-    const bool ok = a.ctl[C_FALLBACK] == 0u && left == 0u;
-    if (ok) { a.out_len[0] = a.ctl[C_TOTAL]; a.status[0] = HDLZ_OK; }
+    bool ok = a.ctl[C_FALLBACK] == 0u && left == 0u;
+    uint32_t total = a.ctl[C_TOTAL];
+    if (!ok && actl && a.ctl[C_NOTFIXED] != 0u) {
+        actl = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(actl) + (size_t)blockIdx.y * a_.ws_stride);
+        const uint32_t aleft = actl[C_MARK] == 0u ? 0u : actl[C_PASS0 + apasses - 1u];
+        ok = actl[C_FALLBACK] == 0u && actl[C_OK] != 0u && aleft == 0u;
+        total = actl[C_TOTAL];
+    }
+    if (ok) { a.out_len[0] = total; a.status[0] = HDLZ_OK; }
     else if (a.batch) { a.out_len[0] = 0u; a.status[0] = HDLZ_E_DYNAMIC_UNSUPPORTED; }      // several streams: the serial pass redoes the flagged ones
     a.ctl[C_OK] = ok ? 1u : 0u;
 }
@@ -823,6 +782,12 @@ __global__ __launch_bounds__(64) void k_par_flag_rest(uint32_t* out_len, uint32_
 
 }  // namespace par
 
+hipError_t par::par_launch_emit_jump(const ParArgs& p, uint32_t nitems, uint32_t passes, uint32_t nstr, hipStream_t stream) {
+    hipLaunchKernelGGL(k_par_emit, dim3(nitems, nstr), dim3(64), 0, stream, p);
+    for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(nitems, nstr), dim3(64), 0, stream, p, j);
+    return hipGetLastError();
+}
+
 // a.nstreams streams of at least HDLZ_INFLATE_PAR_MIN bytes each (fixed pitch form): the parallel chain -- every kernel once, blockIdx.y =
 // the stream --, then the serial decoder for what it gave up on: ONE stream: one wave, only if needed; several: the streams the chain
 // flagged (status HDLZ_E_DYNAMIC_UNSUPPORTED, as pass 1 of the batch kernels flags them)
@@ -833,10 +798,10 @@ struct Layout {
     uint32_t chbits, nchunks, sub, ngroups;
     uint64_t cap64, srcn;
     size_t o_ctl, o_ex, o_nb, o_en, o_op, o_gx, o_gs, o_gn, o_ge, o_go, o_mx, o_mn, o_fe, o_fo, o_tk, o_nt, o_sa, o_me, o_rp, o_cp, o_cx, o_cn,
-           o_cmx, o_cmn, stride;
+           o_cmx, o_cmn, o_any, any_bytes, stride;
     bool ok;
 };
-static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch) {
+static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch, uint32_t flags) {
     Layout L;
     memset(&L, 0, sizeof(L));
     L.cap64 = out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00ull : out_pitch;
@@ -864,6 +829,9 @@ static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch) {
     L.o_me = take((size_t)nchunks * 4u);
     L.o_rp = take((size_t)nchunks * 128u); L.o_cp = take((size_t)nchunks * 128u); L.o_cx = take((size_t)nchunks * 32u);
     L.o_cn = take((size_t)nchunks * 128u); L.o_cmx = take((size_t)nchunks * 32u * (sub - 1u)); L.o_cmn = take((size_t)nchunks * 128u * (sub - 1u));
+    // the chain for any block types: its own arrays behind these (it shares the marker words: one of the two chains writes them)
+    L.any_bytes = any_work_bytes(zn, out_pitch, flags);
+    L.o_any = take(L.any_bytes);
     L.stride = off;
     L.ok = true;
     return L;
@@ -871,9 +839,9 @@ static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch) {
 }  // namespace par
 
 // what the path asks for when all `nstreams` streams go through it at once (less: it runs them in groups, or not at all)
-size_t inflate_par_work_bytes(uint32_t in_len, uint64_t nstreams, uint64_t out_pitch) {
+size_t inflate_par_work_bytes(uint32_t in_len, uint64_t nstreams, uint64_t out_pitch, uint32_t flags) {
     if (nstreams == 0 || nstreams > 65535u || in_len < HDLZ_INFLATE_PAR_MIN) return 0;
-    const par::Layout L = par::layout_of(in_len, (uint32_t)nstreams, out_pitch);
+    const par::Layout L = par::layout_of(in_len, (uint32_t)nstreams, out_pitch, flags);
     if (!L.ok) return 0;
     constexpr size_t BUDGET = (size_t)4 << 30;
     const size_t all = L.stride * (size_t)nstreams;
@@ -886,7 +854,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     const uint32_t zn = a.in_len;
     const uint32_t nstr = (uint32_t)a.nstreams;
     if (a.nstreams == 0 || a.nstreams > 65535u) return hipSuccess;
-    const Layout L = layout_of(zn, nstr, a.out_pitch);
+    const Layout L = layout_of(zn, nstr, a.out_pitch, a.flags);
     if (!L.ok) return hipSuccess;
     const uint64_t cap64 = L.cap64, srcn = L.srcn;
     const uint32_t chbits = L.chbits, nchunks = L.nchunks, sub = L.sub, ngroups = L.ngroups;
@@ -903,8 +871,8 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     if (nstr > 1u && stride * (size_t)nstr > BUDGET) {
         uint32_t gs = (uint32_t)(BUDGET / stride);
         // (a smaller group may be cut into smaller pieces with more lists per byte: shrink until the group's own layout fits)
-        while (gs > 1u && layout_of(zn, gs, a.out_pitch).stride * (size_t)gs > BUDGET) gs = gs * 3u / 4u;
-        if (gs == 0u || layout_of(zn, gs, a.out_pitch).stride * (size_t)gs > BUDGET) return hipSuccess;
+        while (gs > 1u && layout_of(zn, gs, a.out_pitch, a.flags).stride * (size_t)gs > BUDGET) gs = gs * 3u / 4u;
+        if (gs == 0u || layout_of(zn, gs, a.out_pitch, a.flags).stride * (size_t)gs > BUDGET) return hipSuccess;
         if (gs < nstr) {
             for (uint32_t s0 = 0; s0 < nstr; s0 += gs) {
                 InflateArgs g = a;
@@ -915,7 +883,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                 g.status = a.status + s0;
                 g.nstreams = nstr - s0 < gs ? nstr - s0 : gs;
                 // (the last, smaller group could be laid out with smaller pieces and need more per stream than fits)
-                if (layout_of(zn, (uint32_t)g.nstreams, a.out_pitch).stride * (size_t)g.nstreams > BUDGET) {
+                if (layout_of(zn, (uint32_t)g.nstreams, a.out_pitch, a.flags).stride * (size_t)g.nstreams > BUDGET) {
                     if (s0 == 0) return hipSuccess;
                     // hand the rest to the batch kernels: mark them as the chain's give-ups
                     hipLaunchKernelGGL(k_par_flag_rest, dim3((unsigned)((g.nstreams + 63u) / 64u)), dim3(64), 0, stream, g.out_len, g.status, (uint32_t)g.nstreams);
@@ -946,8 +914,8 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         ParArgs p{a.in, zn, a.flags, a.obsize, a.out, (uint32_t)cap64, (uint32_t)srcn, a.out_len, a.status, nchunks, chbits,
                   reinterpret_cast<uint32_t*>(ws + o_ctl), ws + o_ex, reinterpret_cast<uint32_t*>(ws + o_nb), ws + o_en,
                   reinterpret_cast<uint32_t*>(ws + o_op), ws + o_gx, ws + o_gs, reinterpret_cast<uint32_t*>(ws + o_gn), ws + o_ge,
-                  reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_tk), reinterpret_cast<uint32_t*>(ws + o_nt),
-                  reinterpret_cast<uint32_t*>(ws + o_sa), sub, ws + o_mx,
+                  reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_tk), tmax_of(chbits / sub),
+                  reinterpret_cast<uint32_t*>(ws + o_nt), reinterpret_cast<uint32_t*>(ws + o_sa), sub, ws + o_mx,
                   reinterpret_cast<uint32_t*>(ws + o_mn), (uint32_t)C_NUSED, reinterpret_cast<uint32_t*>(ws + o_me),
                   a.in_pitch, a.out_pitch, a.in_off, stride, nstr > 1u ? 1u : 0u};
         hipLaunchKernelGGL(k_par_zero, dim3(1, nstr), dim3(64), 0, stream, p);
@@ -955,9 +923,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         ParArgs pf = p;
         pf.nchunks = nchunks * sub; pf.chbits = chbits / sub; pf.cnu = C_FNUSED;
         pf.entry8 = ws + o_fe; pf.opos = reinterpret_cast<uint32_t*>(ws + o_fo);
-        uint32_t passes = 1;                                            // chains of up to `nchunks` hops, HOPS-fold shorter per pass
-        for (uint64_t reach = 1; reach < (uint64_t)nchunks + 1u; reach *= HOPS) passes++;
-        if (passes > C_WORDS - C_PASS0) passes = C_WORDS - C_PASS0;
+        const uint32_t passes = passes_for(nchunks);
 #ifdef HDLZ_PAR_SPEC32
         if (sub > 1u) hipLaunchKernelGGL(k_par_spec<true>, dim3((nchunks + 1u) / 2u, nstr), dim3(64), 0, stream, p);
         else hipLaunchKernelGGL(k_par_spec<false>, dim3((nchunks + 1u) / 2u, nstr), dim3(64), 0, stream, p);
@@ -978,8 +944,19 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         pe.tokens = pf.tokens; pe.ntok = pf.ntok;
         hipLaunchKernelGGL(k_par_emit, dim3(nchunks, nstr), dim3(64), 0, stream, pe);
         for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(nchunks, nstr), dim3(64), 0, stream, p, j);
-        hipLaunchKernelGGL(k_par_finish, dim3(1, nstr), dim3(64), 0, stream, p, passes);
         e = hipGetLastError();
+        // a stream that is not ONE fixed block (k_par_scan_top said so: C_NOTFIXED): the chain for any block types, behind this one --
+        // its kernels return at once otherwise -- in its own part of the scratch, with its own control words
+        const uint32_t* actl = nullptr;
+        uint32_t apasses = 0;
+        if (e == hipSuccess && L.any_bytes != 0u) {
+            e = launch_inflate_any(a, nstr, ws, stride, L.o_any, o_sa, p.ctl + C_NOTFIXED, (uint32_t)srcn, (uint32_t)cap64, stream, &apasses);
+            actl = reinterpret_cast<const uint32_t*>(ws + L.o_any);
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_par_finish, dim3(1, nstr), dim3(64), 0, stream, p, passes, actl, apasses);
+            e = hipGetLastError();
+        }
         // ONE stream: the serial decoder returns at once when ctl[C_OK] >= 1; several: it redoes the streams k_par_finish flagged
         if (e == hipSuccess) e = nstr == 1u ? launch_inflate_dyn(a, stream, true, p.ctl + C_OK, 1u) : launch_inflate_dyn_flagged(a, stream);
         *used = true;
@@ -989,3 +966,11 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
 }
 
 }  // namespace hdlz
+
+#ifdef HDLZ_DEBUG_EXPORTS      // (lib/libhdlz_dbg.so, tools/dev_any.py: where the control words of the two chains lie in the caller's scratch)
+extern "C" size_t hdlz_debug_par_offsets(uint32_t in_len, uint64_t nstreams, uint64_t out_pitch, uint32_t flags, size_t* o_ctl, size_t* o_any) {
+    const hdlz::par::Layout L = hdlz::par::layout_of(in_len, (uint32_t)nstreams, out_pitch, flags);
+    *o_ctl = L.o_ctl; *o_any = L.o_any;
+    return L.ok ? L.stride : 0u;
+}
+#endif

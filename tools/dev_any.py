@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""dev: the whole-GPU inflate of streams of any block types (hdlz_inflate_any.hip) on stock-zlib streams: result against zlib, time, and
+the control words of both chains (HDLZ_LIB=hdl_deflate_amd/lib/libhdlz_dbg.so, built with -DHDLZ_DEBUG_EXPORTS)"""
+import ctypes, os, random, sys, time, zlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import hdl_deflate_amd
+from hdl_deflate_amd.data import make_blocks
+
+eng = hdl_deflate_amd.Engine()
+L = eng.lib
+dbg = hasattr(L, "hdlz_debug_par_offsets")
+if dbg:
+    L.hdlz_debug_par_offsets.restype = ctypes.c_size_t
+    L.hdlz_debug_par_offsets.argtypes = [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+
+def text(n, seed):
+    r = random.Random(seed)
+    words = [bytes(r.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(r.randint(2, 9))) for _ in range(3000)]
+    out = bytearray()
+    while len(out) < n:
+        out += r.choice(words) + b" "
+    return bytes(out[:n])
+
+def run(name, z, want, reps=3):
+    n = len(want)
+    cap = (n + 64 + 15) // 16 * 16
+    zin = torch.frombuffer(bytearray(z + bytes(64)), dtype=torch.uint8).cuda().reshape(1, -1)
+    wb = L.hdlz_inflate_work_bytes(1, len(z), cap, 0, 0)
+    work = torch.zeros(wb, dtype=torch.uint8, device="cuda")
+    out = torch.zeros((1, cap), dtype=torch.uint8, device="cuda")
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.time()
+        _, ol, st = eng.inflate_batch(zin, in_len=len(z), out_pitch=cap, out=out, work=work)
+        torch.cuda.synchronize(); ts.append(time.time() - t0)
+    ok = int(st.item()) == 0 and int(ol.item()) == n and out[0, :n].cpu().numpy().tobytes() == want
+    info = ""
+    if dbg:
+        oc, oa = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        L.hdlz_debug_par_offsets(len(z), 1, cap, 0, ctypes.byref(oc), ctypes.byref(oa))
+        w32 = work.view(torch.int32)
+        cf = w32[oc.value // 4: oc.value // 4 + 64].cpu().tolist()
+        ca = w32[oa.value // 4: oa.value // 4 + 64].cpu().tolist()
+        info = " F[fallback %d notfixed %d ok %d] ANY[fallback %d ok %d total %d nused %d mark %d | ncand %d nblk %d nx %d ns %d over %d] scratch %.1f MB" % (
+            cf[0], cf[7], cf[3], ca[0], ca[3], ca[2], ca[1], ca[4], ca[40], ca[41], ca[42], ca[43], ca[44], wb / 1e6)
+    print("%-34s z %9d -> %10d  %s  %8.3f ms  %8.1f MB/s%s" % (name, len(z), n, "OK " if ok else "BAD", min(ts) * 1e3, n / min(ts) / 1e6, info), flush=True)
+    return ok
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+allok = True
+if which in ("all", "small"):
+    for n in (60000, 300000, 1 << 20):
+        d = text(n, n)
+        allok &= run("text level 6 %d" % n, zlib.compress(d, 6), d)
+    d = text(1 << 20, 5)
+    allok &= run("text level 1", zlib.compress(d, 1), d)
+    allok &= run("text level 9", zlib.compress(d, 9), d)
+    d = np.random.default_rng(1).integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    allok &= run("random level 6 (stored)", zlib.compress(d, 6), d)
+    allok &= run("random level 0", zlib.compress(d, 0), d)
+    d = make_blocks(512, 2048, "cpu", seed=3).numpy().tobytes()
+    allok &= run("families level 6", zlib.compress(d, 6), d)
+    # mixed: segments of different kinds joined at full flushes
+    parts, plain = [], []
+    for k in range(12):
+        seg = text(90000 + 1000 * k, 50 + k) if k % 3 != 1 else np.random.default_rng(k).integers(0, 256, 70000, dtype=np.uint8).tobytes()
+        co = zlib.compressobj([6, 0, 1, 9][k % 4], zlib.DEFLATED, -15, 8, zlib.Z_FIXED if k % 5 == 2 and False else zlib.Z_DEFAULT_STRATEGY)
+        parts.append(co.compress(seg) + co.flush(zlib.Z_FULL_FLUSH)); plain.append(seg)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    tail = b"the end " * 3
+    parts.append(co.compress(tail) + co.flush()); plain.append(tail)
+    want = b"".join(plain)
+    z = b"\x78\x9c" + b"".join(parts) + zlib.adler32(want).to_bytes(4, "big")
+    assert zlib.decompress(z) == want
+    allok &= run("mixed 13 segments", z, want)
+if which in ("all", "big"):
+    d = make_blocks(8192, 2048, "cpu", seed=5).numpy().tobytes()
+    allok &= run("families 16 MiB level 6", zlib.compress(d, 6), d)
+    d = text(16 << 20, 9)
+    allok &= run("text 16 MiB level 6", zlib.compress(d, 6), d)
+    allok &= run("text 16 MiB level 1", zlib.compress(d, 1), d)
+print("ALL OK" if allok else "FAILURES")
