@@ -58,7 +58,9 @@ constexpr uint32_t LB = 11, DB = 9;           // bits of the two primary look-up
 constexpr uint32_t FIX_MAX_BITS = 16 * PB;    // a fixed block behind a dynamic one is decoded by ONE lane: up to this many bits
 constexpr uint32_t NO_OWNER = 0xFFFFu;
 constexpr uint32_t N_END = 0xFFFFFFFEu, N_BAD = 0xFFFFFFFFu;      // successor of a node: the stream ends / no valid successor
-enum { A_NCAND = par::C_ANY0, A_NBLK, A_NX, A_NS, A_OVER };       // this chain's counters in its control words
+enum { A_NCAND = par::C_ANY0, A_NBLK, A_NX, A_NS, A_OVER, A_WHY, A_NREQ, A_NREQP };       // this chain's counters in its control words; A_WHY: bits of W_* (diagnostics)
+enum { W_OVER = 1, W_NODE = 2, W_NEXT = 4, W_CAP = 8, W_CYCLE = 16, W_ITEMS = 32, W_TOKEN = 64, W_TCAP = 128, W_WALK_OWNER = 256, W_WALK_MAP = 512,
+       W_WALK_HDR = 1024, W_WALK_STORED = 2048, W_WALK_FIX = 4096, W_WALK_TOK = 8192 };
 
 // decode tables of one block (global memory; a wave of k_any_spec copies its owner's into LDS)
 struct __attribute__((aligned(256))) Tab {
@@ -74,6 +76,13 @@ struct Blk { uint32_t hdr, pay, fin, nlen; };                         // a candi
 struct Node { uint32_t next, nbytes, ok, obase; };                    // result of its walk; obase: k_any_rank
 struct XItem { uint32_t start, limit, rel, node_slot; };              // an extra decode item: bits [start, limit), rel = bytes of its node in front; node | slot << 16
 struct SItem { uint32_t src, len, rel, node; };                       // a stored block: `len` bytes from stream byte `src`
+// A block whose walk meets pieces that were decoded for ANOTHER candidate -- a false positive inside it: a header-like bit pattern, ~1 per
+// 4 MB of compressed data, almost always a degenerate code of two or three symbols -- asks for those pieces to be decoded with its own
+// tables (k_any_spec2) and goes on in the next round of k_any_walk
+struct Req { uint32_t node, q0, q1, slot, round; };                   // pieces [q0, q1) for candidate `node`; maps at map2[slot ..]
+struct NState { uint32_t q, pos, nb, req; };                          // a waiting walk (Node::ok == 3)
+constexpr uint32_t WALK_ROUNDS = 3;           // rounds of k_any_walk: up to WALK_ROUNDS - 1 false positives in a row inside one block
+constexpr uint32_t REQ_MAX = 1024;            // pieces per request (more: the rest in the next round)
 
 struct Args {
     const uint8_t* z;
@@ -86,9 +95,9 @@ struct Args {
     size_t stride;                // bytes from a stream's scratch to the next stream's
     const uint32_t* gate;         // stream 0's gate word (the fixed-block chain's C_NOTFIXED)
     uint32_t* srcA;               // stream 0's marker words
-    uint32_t nchunks, candcap, maxb, maxx, maxs, tcap;
+    uint32_t nchunks, candcap, maxb, maxx, maxs, tcap, maxreq, mapcap;
     size_t o_cand, o_blk, o_blen, o_shdr, o_spay, o_sidx, o_tab, o_owner, o_map, o_pent, o_prel, o_pnode, o_node, o_xitem, o_sitem,
-           o_opos, o_ntok, o_tok, o_mext;
+           o_opos, o_ntok, o_tok, o_mext, o_req, o_map2, o_nstate;
 };
 // one stream's view
 struct View {
@@ -99,7 +108,7 @@ struct View {
     bool run;                     // the gate is open and nothing has failed so far
     uint32_t* cand; Blk* blk; uint8_t* blen; uint32_t* shdr; uint32_t* spay; uint32_t* sidx; Tab* tab; uint16_t* owner; uint32_t* map;
     uint8_t* pent; uint32_t* prel; uint16_t* pnode; Node* node; XItem* xitem; SItem* sitem; uint32_t* opos; uint32_t* ntok; uint32_t* tok;
-    uint32_t* mext; uint32_t* srcA;
+    uint32_t* mext; uint32_t* srcA; Req* req; uint32_t* map2; NState* nstate;
 };
 template <typename T> __device__ __forceinline__ T* at(uint8_t* base, size_t off) { return reinterpret_cast<T*>(base + off); }
 __device__ __forceinline__ View view(const Args& a) {
@@ -120,6 +129,7 @@ __device__ __forceinline__ View view(const Args& a) {
     v.map = at<uint32_t>(w, a.o_map); v.pent = at<uint8_t>(w, a.o_pent); v.prel = at<uint32_t>(w, a.o_prel); v.pnode = at<uint16_t>(w, a.o_pnode);
     v.node = at<Node>(w, a.o_node); v.xitem = at<XItem>(w, a.o_xitem); v.sitem = at<SItem>(w, a.o_sitem); v.opos = at<uint32_t>(w, a.o_opos);
     v.ntok = at<uint32_t>(w, a.o_ntok); v.tok = at<uint32_t>(w, a.o_tok); v.mext = at<uint32_t>(w, a.o_mext);
+    v.req = at<Req>(w, a.o_req); v.map2 = at<uint32_t>(w, a.o_map2); v.nstate = at<NState>(w, a.o_nstate);
     v.srcA = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(a.srcA) + (size_t)s * a.stride);
     return v;
 }
@@ -464,6 +474,49 @@ struct SpecLds {
     Tab t[SPEC_W];
     uint32_t win[SPEC_W][PB / 32 + 8];
 };
+__device__ __forceinline__ void load_tab(Tab* dst_, const Tab* src_, uint32_t lane) {
+    const tok::u32x4* src = reinterpret_cast<const tok::u32x4*>(src_);
+    tok::u32x4* dst = reinterpret_cast<tok::u32x4*>(dst_);
+    for (uint32_t k = lane; k < sizeof(Tab) / 16u; k += 64u) dst[k] = src[k];
+}
+// piece q with the tables at t (LDS), one wave: lane e starts at the piece's bit e -> mp[e]
+__device__ __forceinline__ void spec_piece(const View& v, const Tab* t, uint32_t* win, uint32_t q, uint32_t* mp, uint32_t lane) {
+    const uint32_t b0 = q * PB, end = b0 + PB;
+    for (uint32_t k = lane; k < PB / 32u + 8u; k += 64u) win[k] = tok::load32(v.z, (b0 >> 3) + 4u * k, v.zn);
+    wave_lds_order();
+    __builtin_amdgcn_wave_barrier();
+    uint32_t pos = b0 + lane, nbytes = 0, res = 0;
+    bool run = true;
+    while (ballot64(run) != 0ull) {
+        if (run) {
+            const uint32_t rel = pos - b0, w = rel >> 5, sh = rel & 31u;
+            const uint32_t d0 = win[w], d1 = win[w + 1u], d2 = win[w + 2u];
+            const uint64_t x = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+            uint32_t sym, len;
+            sym_of<LB, 9u, 511u>(t->ll, t->lfirst, t->lcnt, t->loff, t->lsym, (uint32_t)x, sym, len);
+            if (len == 0u) { res = 3u << 30; run = false; }
+            else if (sym < 256u) { pos += len; nbytes += 1u; }
+            else if (sym == 256u) { res = (2u << 30) | ((pos + len - b0) << 19) | nbytes; run = false; }
+            else {
+                uint32_t lbase, leb, ds, dl;
+                tok::length_info(sym - 257u, lbase, leb);
+                const uint64_t x1 = x >> len;
+                const uint32_t tl = lbase + ((uint32_t)x1 & ((1u << leb) - 1u));
+                sym_of<DB, 5u, 31u>(t->dd, t->dfirst, t->dcnt, t->doff, t->dsym, (uint32_t)(x1 >> leb), ds, dl);
+                if (dl == 0u) { res = 3u << 30; run = false; }
+                else {
+                    const uint32_t deb = ds < 4u ? 0u : (ds >> 1) - 1u;
+                    pos += len + leb + dl + deb;
+                    nbytes += tl;
+                }
+            }
+            if (run && pos >= end) { res = ((pos - end) << 19) | nbytes; run = false; }
+            if (nbytes >= (1u << 19)) { res = 3u << 30; run = false; }       // (cannot happen: 512 tokens of 258 bytes)
+        }
+    }
+    mp[lane] = res;
+    __builtin_amdgcn_wave_barrier();
+}
 __global__ __launch_bounds__(64 * SPEC_W) void k_any_spec(Args a) {
     const View v = view(a);
     __shared__ SpecLds L;
@@ -472,53 +525,31 @@ __global__ __launch_bounds__(64 * SPEC_W) void k_any_spec(Args a) {
     const uint32_t nw = gridDim.x * SPEC_W, g = blockIdx.x * SPEC_W + wv;
     const uint32_t per = (a.nchunks + nw - 1u) / nw;
     const uint32_t q0 = g * per, q1 = min(q0 + per, a.nchunks);
-    const Tab* t = &L.t[wv];
-    uint32_t* win = L.win[wv];
     uint32_t cur = NO_OWNER;
     for (uint32_t q = q0; q < q1; q++) {
         const uint32_t r = v.owner[q];
         if (r == NO_OWNER) continue;
-        if (r != cur) {
-            const tok::u32x4* src = reinterpret_cast<const tok::u32x4*>(&v.tab[r]);
-            tok::u32x4* dst = reinterpret_cast<tok::u32x4*>(&L.t[wv]);
-            for (uint32_t k = lane; k < sizeof(Tab) / 16u; k += 64u) dst[k] = src[k];
-            cur = r;
+        if (r != cur) { load_tab(&L.t[wv], &v.tab[r], lane); cur = r; }
+        spec_piece(v, &L.t[wv], L.win[wv], q, v.map + (size_t)q * 64u, lane);
+    }
+}
+// the pieces the walks of round `round` - 1 asked for, with the asking candidate's tables
+__global__ __launch_bounds__(64 * SPEC_W) void k_any_spec2(Args a, uint32_t round) {
+    const View v = view(a);
+    __shared__ SpecLds L;
+    if (!v.run) return;
+    const uint32_t nreq = min(v.ctl[A_NREQ], a.maxreq);
+    if (nreq == 0u) return;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t nw = gridDim.x * SPEC_W, g = blockIdx.x * SPEC_W + wv;
+    uint32_t cur = NO_OWNER;
+    for (uint32_t r = 0; r < nreq; r++) {
+        const Req rq = v.req[r];
+        if (rq.round + 1u != round) continue;
+        for (uint32_t k = g; k < rq.q1 - rq.q0; k += nw) {
+            if (rq.node != cur) { load_tab(&L.t[wv], &v.tab[rq.node], lane); cur = rq.node; }
+            spec_piece(v, &L.t[wv], L.win[wv], rq.q0 + k, v.map2 + (size_t)(rq.slot + k) * 64u, lane);
         }
-        const uint32_t b0 = q * PB, end = b0 + PB;
-        for (uint32_t k = lane; k < PB / 32u + 8u; k += 64u) win[k] = tok::load32(v.z, (b0 >> 3) + 4u * k, v.zn);
-        wave_lds_order();
-        __builtin_amdgcn_wave_barrier();
-        uint32_t pos = b0 + lane, nbytes = 0, res = 0;
-        bool run = true;
-        while (ballot64(run) != 0ull) {
-            if (run) {
-                const uint32_t rel = pos - b0, w = rel >> 5, sh = rel & 31u;
-                const uint32_t d0 = win[w], d1 = win[w + 1u], d2 = win[w + 2u];
-                const uint64_t x = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
-                uint32_t sym, len;
-                sym_of<LB, 9u, 511u>(t->ll, t->lfirst, t->lcnt, t->loff, t->lsym, (uint32_t)x, sym, len);
-                if (len == 0u) { res = 3u << 30; run = false; }
-                else if (sym < 256u) { pos += len; nbytes += 1u; }
-                else if (sym == 256u) { res = (2u << 30) | ((pos + len - b0) << 19) | nbytes; run = false; }
-                else {
-                    uint32_t lbase, leb, ds, dl;
-                    tok::length_info(sym - 257u, lbase, leb);
-                    const uint64_t x1 = x >> len;
-                    const uint32_t tl = lbase + ((uint32_t)x1 & ((1u << leb) - 1u));
-                    sym_of<DB, 5u, 31u>(t->dd, t->dfirst, t->dcnt, t->doff, t->dsym, (uint32_t)(x1 >> leb), ds, dl);
-                    if (dl == 0u) { res = 3u << 30; run = false; }
-                    else {
-                        const uint32_t deb = ds < 4u ? 0u : (ds >> 1) - 1u;
-                        pos += len + leb + dl + deb;
-                        nbytes += tl;
-                    }
-                }
-                if (run && pos >= end) { res = ((pos - end) << 19) | nbytes; run = false; }
-                if (nbytes >= (1u << 19)) { res = 3u << 30; run = false; }       // (cannot happen: 512 tokens of 258 bytes)
-            }
-        }
-        v.map[(size_t)q * 64u + lane] = res;
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -528,7 +559,7 @@ __device__ __forceinline__ uint32_t find_rank(const uint32_t* shdr, uint32_t n, 
     while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (shdr[m] < hdr) lo = m + 1u; else hi = m; }
     return lo < n && shdr[lo] == hdr ? lo : N_BAD;
 }
-__global__ __launch_bounds__(64) void k_any_walk(Args a) {
+__global__ __launch_bounds__(64) void k_any_walk(Args a, uint32_t round) {
     const View v = view(a);
     if (!v.run) return;
     const uint32_t n = min(v.ctl[A_NBLK], a.maxb);
@@ -538,8 +569,9 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a) {
     const int32_t isize = (int32_t)v.zn - 1;
     const uint32_t len_mask = a.obsize ? ((1u << (31u - (uint32_t)__builtin_clz(a.obsize))) - 1u) : 0xFFFFu;     // deflate.py:329,:714
     const uint32_t node_id = i < n ? i : a.maxb;
+    if (round != 0u && v.node[node_id].ok != 3u) return;              // later rounds: the walks that wait for pieces of their own
     uint64_t nb = 0;                      // bytes of this node so far
-    uint32_t ebit = 16u, fin = 0u, next = N_BAD;
+    uint32_t ebit = 16u, fin = 0u, next = N_BAD, why = 0u;
     bool ok = true;
     Bits rd;
     auto add_xitem = [&](uint32_t start, uint32_t limit, uint32_t slot) {
@@ -552,7 +584,7 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a) {
         eob = false;
         while (ok && rd.pos < limit) {
             const Token k = token_at(t, rd);
-            if (k.kind == 3u) { ok = false; break; }
+            if (k.kind == 3u) { ok = false; why |= W_WALK_TOK; break; }
             if (k.kind == 2u) { eob = true; break; }
             nb += k.kind == 0u ? 1u : k.length;
         }
@@ -560,38 +592,66 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a) {
     if (i < n) {
         const Blk b = v.blk[v.sidx[i]];
         fin = b.fin;
-        rd.init(v.z, v.zn, b.pay);
         bool eob = false;
-        uint32_t q = b.pay / PB;
-        if (b.pay % PB != 0u) {                                       // the first, partial piece: by this lane
-            const uint32_t limit = (q + 1u) * PB;
-            add_xitem(b.pay, limit, i);
-            run_to(&v.tab[i], limit, eob);
-            q++;
+        uint32_t q, pos, rq0 = 0, rq1 = 0, rslot = 0;
+        if (round == 0u) {
+            rd.init(v.z, v.zn, b.pay);
+            q = b.pay / PB;
+            if (b.pay % PB != 0u) {                                   // the first, partial piece: by this lane
+                const uint32_t limit = (q + 1u) * PB;
+                add_xitem(b.pay, limit, i);
+                run_to(&v.tab[i], limit, eob);
+                q++;
+            }
+            pos = rd.pos;
+        } else {
+            const NState st = v.nstate[i];
+            q = st.q; pos = st.pos; nb = st.nb;
+            const Req rq = v.req[st.req];
+            rq0 = rq.q0; rq1 = rq.q1; rslot = rq.slot;
         }
-        uint32_t pos = rd.pos;
         while (ok && !eob) {                                          // whole pieces: through the maps
-            if (q >= a.nchunks || v.owner[q] != i || pos - q * PB >= 64u) { ok = false; break; }
+            if (q >= a.nchunks || pos - q * PB >= 64u) { ok = false; why |= W_WALK_OWNER; break; }
             const uint32_t e = pos - q * PB;
-            const uint32_t m = v.map[(size_t)q * 64u + e], kind = m >> 30, off = (m >> 19) & 2047u;
-            v.pent[q] = (uint8_t)e; v.prel[q] = (uint32_t)nb; v.pnode[q] = (uint16_t)i;
+            uint32_t m;
+            if (v.owner[q] == i) {
+                m = v.map[(size_t)q * 64u + e];
+                v.pent[q] = (uint8_t)e; v.prel[q] = (uint32_t)nb; v.pnode[q] = (uint16_t)i;
+            } else if (q >= rq0 && q < rq1) {                         // a piece decoded for this block on request: an item of its own
+                m = v.map2[(size_t)(rslot + (q - rq0)) * 64u + e];
+                add_xitem(q * PB + e, (q + 1u) * PB, i);
+            } else {
+                // decoded for another candidate (a false positive inside this block, if this block is a true one): ask for the pieces up
+                // to the next candidate behind that one with this block's tables, go on in the next round
+                const uint32_t f = v.owner[q];
+                if (f == NO_OWNER || round + 1u >= WALK_ROUNDS) { ok = false; why |= W_WALK_OWNER; break; }
+                uint32_t qe = f + 1u < n ? min((v.spay[f + 1u] + PB - 1u) / PB, a.nchunks) : a.nchunks;
+                qe = min(qe, q + REQ_MAX);
+                const uint32_t slot = atomicAdd(&v.ctl[A_NREQP], qe - q), r = atomicAdd(&v.ctl[A_NREQ], 1u);
+                if (slot + (qe - q) > a.mapcap || r >= a.maxreq) { ok = false; why |= W_WALK_OWNER; break; }
+                v.req[r] = Req{i, q, qe, slot, round};
+                v.nstate[i] = NState{q, pos, (uint32_t)nb, r};
+                v.node[node_id] = Node{N_BAD, 0u, 3u, 0u};
+                return;
+            }
             nb += m & 0x7FFFFu;
+            const uint32_t kind = m >> 30, off = (m >> 19) & 2047u;
             if (kind == 0u) { pos = (q + 1u) * PB + off; q++; }
             else if (kind == 2u) { pos = q * PB + off; eob = true; }
-            else ok = false;
+            else { ok = false; why |= W_WALK_MAP; }
+            if (nb > 0xFFFFFFFFull) ok = false;
         }
         ebit = pos;
-        if (nb > 0xFFFFFFFFull) ok = false;
     }
     // behind the block: the blocks that cannot be found by search, up to the next dynamic header
     uint32_t guard = 0;
     while (ok) {
         if (fin) { next = N_END; break; }
-        if (ebit + 3u > nbits || ++guard > 0x100000u) { ok = false; break; }
+        if (ebit + 3u > nbits || ++guard > 0x100000u) { ok = false; why |= W_WALK_HDR; break; }
         rd.init(v.z, v.zn, ebit);
         const uint32_t f = (uint32_t)rd.bb & 1u, ty = ((uint32_t)rd.bb >> 1) & 3u;
-        if (ty == 2u) { next = find_rank(v.shdr, n, ebit); ok = next != N_BAD; break; }
-        if (ty == 3u) { ok = false; break; }
+        if (ty == 2u) { next = find_rank(v.shdr, n, ebit); ok = next != N_BAD; if (!ok) why |= W_NEXT; break; }
+        if (ty == 3u) { ok = false; why |= W_WALK_HDR; break; }
         if (ty == 0u) {
             // stored (deflate.py:709-717, :1603-1626): LEN sits `skip` bits behind the header's first bit, NLEN is not checked (D2)
             const uint32_t dio = ebit & 7u;
@@ -600,7 +660,7 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a) {
             const uint32_t length = (uint32_t)(rd.bb >> skip) & 0xFFFFu & len_mask;
             const uint32_t p0 = (ebit + skip + 32u) >> 3;
             const uint32_t i_noeof = (int32_t)p0 >= isize ? 0u : (uint32_t)isize - p0;
-            if (length > i_noeof || (int32_t)(p0 + length) >= isize) { ok = false; break; }
+            if (length > i_noeof || (int32_t)(p0 + length) >= isize) { ok = false; why |= W_WALK_STORED; break; }
             if (length) {
                 const uint32_t k = atomicAdd(&v.ctl[A_NS], 1u);
                 if (k < a.maxs) v.sitem[k] = SItem{p0, length, (uint32_t)nb, node_id};
@@ -615,7 +675,7 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a) {
             bool eob = false;
             while (ok && !eob) {
                 const uint32_t limit = (rd.pos / PB + 1u) * PB;
-                if (rd.pos >= stop) { ok = false; break; }
+                if (rd.pos >= stop) { ok = false; why |= W_WALK_FIX; break; }
                 add_xitem(rd.pos, limit, a.maxb);
                 run_to(&v.tab[a.maxb], limit, eob);
             }
@@ -624,7 +684,7 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a) {
         if (nb > 0xFFFFFFFFull) { ok = false; break; }
         fin = f;
     }
-    v.node[node_id] = Node{next, (uint32_t)nb, ok ? 1u : 0u, 0u};
+    v.node[node_id] = Node{next, (uint32_t)nb, ok ? 1u : 0u, why};        // (obase of a failed node: why its walk failed -- read by k_any_rank if it is on the chain)
 }
 
 // one thread follows the successors from the pseudo-node: the true chain, the output position of every block on it, the total
@@ -636,7 +696,7 @@ __global__ __launch_bounds__(256) void k_any_rank(Args a) {
     if (v.ctl[A_OVER] != 0u) { if (threadIdx.x == 0u) give_up(v); return; }
     for (uint32_t k = threadIdx.x; k <= n; k += 256u) {
         const Node nd = v.node[k < n ? k : a.maxb];
-        nl[2u * k] = nd.ok ? nd.next : N_BAD; nl[2u * k + 1u] = nd.nbytes;
+        nl[2u * k] = nd.ok == 1u ? nd.next : N_BAD; nl[2u * k + 1u] = nd.ok == 1u ? nd.nbytes : nd.obase;
     }
     __syncthreads();
     if (threadIdx.x != 0u) return;
@@ -645,17 +705,17 @@ __global__ __launch_bounds__(256) void k_any_rank(Args a) {
     bool good = true;
     for (;;) {
         const uint32_t nx = nl[2u * cur], by = nl[2u * cur + 1u];
-        if (nx == N_BAD) { good = false; break; }
+        if (nx == N_BAD) { good = false; atomicOr(&v.ctl[A_WHY], (uint32_t)W_NODE | by); break; }
         Node* nd = &v.node[cur < n ? cur : a.maxb];
         nd->obase = (uint32_t)acc; nd->ok = 2u;
         acc += by;
-        if (acc > (uint64_t)a.cap || acc > (uint64_t)a.srcn) { good = false; break; }
+        if (acc > (uint64_t)a.cap || acc > (uint64_t)a.srcn) { good = false; atomicOr(&v.ctl[A_WHY], (uint32_t)W_CAP); break; }
         if (nx == N_END) break;
         cur = nx;
-        if (cur >= n || ++steps > n + 1u) { good = false; break; }
+        if (cur >= n || ++steps > n + 1u) { good = false; atomicOr(&v.ctl[A_WHY], (uint32_t)W_CYCLE); break; }
     }
     const uint32_t nx_items = v.ctl[A_NX], ns_items = v.ctl[A_NS];
-    if (nx_items > a.maxx || ns_items > a.maxs) good = false;
+    if (nx_items > a.maxx || ns_items > a.maxs) { good = false; atomicOr(&v.ctl[A_WHY], (uint32_t)W_ITEMS); }
     if (!good) { give_up(v); return; }
     v.ctl[C_TOTAL] = (uint32_t)acc;
     v.ctl[C_NUSED] = a.nchunks + nx_items;
@@ -702,8 +762,8 @@ __global__ __launch_bounds__(64) void k_any_tokens(Args a) {
             const uint32_t made = k.kind == 0u ? 1u : k.length;
             f |= (uint64_t)P + made > a.cap;
             f |= k.kind == 1u && (k.dist > P || k.dist > obsize || (int32_t)((p0 + k.used) >> 3) >= isize - 2);     // D8; COPY hold (:1600)
-            f |= nt >= a.tcap;
-            if (f) { bad = true; break; }
+            if (nt >= a.tcap) { f = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_TCAP); }
+            if (f) { bad = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_TOKEN); break; }
             tk[nt++] = k.kind == 0u ? (TOK_LIT | k.lit) : (k.length | (k.dist << 9));
             P += made;
         }
@@ -733,9 +793,9 @@ __global__ __launch_bounds__(64) void k_any_zero(Args a) {
 
 constexpr uint32_t ANY_MIN = 16384;           // streams below this stay with the serial decoder (the chain of launches costs ~0.1 ms)
 struct Lay {
-    uint32_t nchunks, candcap, maxb, maxx, maxs, tcap;
+    uint32_t nchunks, candcap, maxb, maxx, maxs, tcap, maxreq, mapcap;
     size_t o_cand, o_blk, o_blen, o_shdr, o_spay, o_sidx, o_tab, o_owner, o_map, o_pent, o_prel, o_pnode, o_node, o_xitem, o_sitem,
-           o_opos, o_ntok, o_tok, o_mext, bytes;
+           o_opos, o_ntok, o_tok, o_mext, o_req, o_map2, o_nstate, bytes;
 };
 static Lay lay_of(uint32_t zn) {
     Lay L;
@@ -744,7 +804,9 @@ static Lay lay_of(uint32_t zn) {
     L.nchunks = (uint32_t)((nbits + PB - 1u) / PB);
     L.candcap = (uint32_t)(nbits / 512u) + 1024u;
     L.maxb = zn / 2048u < 64u ? 64u : zn / 2048u > 4096u ? 4096u : zn / 2048u;
-    L.maxx = 4u * L.maxb + 256u;
+    L.maxreq = 2u * L.maxb;
+    L.mapcap = L.nchunks / 4u + 1024u;                              // pieces decoded a second time, on request (false positives: ~one per 4 MB)
+    L.maxx = 4u * L.maxb + 256u + L.mapcap;                         // (every such piece is an extra item)
     L.maxs = zn / 4096u + 256u;
     L.tcap = 256u;
     size_t off = 256;                                               // the control words in front
@@ -756,6 +818,7 @@ static Lay lay_of(uint32_t zn) {
     L.o_pent = take(L.nchunks); L.o_prel = take(4u * (size_t)L.nchunks); L.o_pnode = take(2u * (size_t)L.nchunks);
     L.o_node = take(sizeof(Node) * ((size_t)L.maxb + 1u)); L.o_xitem = take(sizeof(XItem) * L.maxx); L.o_sitem = take(sizeof(SItem) * L.maxs);
     L.o_opos = take(4u * items); L.o_ntok = take(4u * items); L.o_tok = take(4u * (size_t)L.tcap * items); L.o_mext = take(4u * items);
+    L.o_req = take(sizeof(Req) * L.maxreq); L.o_map2 = take(256u * (size_t)L.mapcap); L.o_nstate = take(sizeof(NState) * L.maxb);
     L.bytes = off;
     return L;
 }
@@ -778,6 +841,7 @@ hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, 
     g.in_pitch = a.in_pitch; g.out_pitch = a.out_pitch; g.in_off = a.in_off;
     g.ws = ws + ws_off; g.stride = ws_stride; g.gate = gate; g.srcA = reinterpret_cast<uint32_t*>(ws + sa_off);
     g.nchunks = L.nchunks; g.candcap = L.candcap; g.maxb = L.maxb; g.maxx = L.maxx; g.maxs = L.maxs; g.tcap = L.tcap;
+    g.maxreq = L.maxreq; g.mapcap = L.mapcap; g.o_req = L.o_req; g.o_map2 = L.o_map2; g.o_nstate = L.o_nstate;
     g.o_cand = L.o_cand; g.o_blk = L.o_blk; g.o_blen = L.o_blen; g.o_shdr = L.o_shdr; g.o_spay = L.o_spay; g.o_sidx = L.o_sidx; g.o_tab = L.o_tab;
     g.o_owner = L.o_owner; g.o_map = L.o_map; g.o_pent = L.o_pent; g.o_prel = L.o_prel; g.o_pnode = L.o_pnode; g.o_node = L.o_node;
     g.o_xitem = L.o_xitem; g.o_sitem = L.o_sitem; g.o_opos = L.o_opos; g.o_ntok = L.o_ntok; g.o_tok = L.o_tok; g.o_mext = L.o_mext;
@@ -790,7 +854,11 @@ hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, 
     hipLaunchKernelGGL(k_any_tables, dim3(gx(L.maxb + 1u, 1024u), nstr), dim3(TAB_T), 0, stream, g);
     hipLaunchKernelGGL(k_any_owner, dim3(gx(L.maxb, 1024u), nstr), dim3(64), 0, stream, g);
     hipLaunchKernelGGL(k_any_spec, dim3(gx((L.nchunks + SPEC_W - 1u) / SPEC_W, 1536u), nstr), dim3(64 * SPEC_W), 0, stream, g);
-    hipLaunchKernelGGL(k_any_walk, dim3((L.maxb + 1u + 63u) / 64u, nstr), dim3(64), 0, stream, g);
+    hipLaunchKernelGGL(k_any_walk, dim3((L.maxb + 1u + 63u) / 64u, nstr), dim3(64), 0, stream, g, 0u);
+    for (uint32_t round = 1; round < WALK_ROUNDS; round++) {        // (return at once when no walk met a false positive)
+        hipLaunchKernelGGL(k_any_spec2, dim3(256, nstr), dim3(64 * SPEC_W), 0, stream, g, round);
+        hipLaunchKernelGGL(k_any_walk, dim3((L.maxb + 1u + 63u) / 64u, nstr), dim3(64), 0, stream, g, round);
+    }
     hipLaunchKernelGGL(k_any_rank, dim3(1, nstr), dim3(256), 8u * (L.maxb + 1u), stream, g);
     hipLaunchKernelGGL(k_any_tokens, dim3(gx((nitems + 63u) / 64u, 8192u), nstr), dim3(64), 0, stream, g);
     hipLaunchKernelGGL(k_any_stored, dim3(gx(L.maxs, 1024u), nstr), dim3(256), 0, stream, g);
