@@ -266,7 +266,7 @@ TOP_KEEP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "input_MBps", "length_allgather_ms_avg", "lengths_digest", "T1_ms", "T1_kernel_ms_median", "speedup_vs_T1",
             "T1_lengths_digest", "scaling_curve", "error", "visible_devices", "secondary", "detail")
 SEC_KEEP = ("name", "metric", "value", "unit", "ms_per_step", "compression_ratio_out_over_in", "input_MBps", "roofline",
-            "compress_roofline", "inflate_MBps", "compress_MBps", "wave_per_stream_ms", "status")
+            "compress_roofline", "inflate_MBps", "compress_MBps", "wave_per_stream_ms", "one_wave_ms", "status")
 
 
 def _numbers_only(d, depth=2):
@@ -509,6 +509,7 @@ def main_single(a):
         # -- the reference's own use: ONE stream at a time.  STARTC then STARTD on one 16 MiB stream (the most a port with LMAX = 24
         #    holds), each on the whole GPU (k_stream_*, k_par_*)
         sec.append(bench_single_stream(torch, eng, dev, a))
+        sec.append(bench_zlib_stream(torch, eng, dev, a))
         sec.append(bench_few_large(torch, eng, dev, a))
         res["secondary"] = sec
     emit(res, a)
@@ -582,6 +583,43 @@ def bench_single_stream(torch, eng, dev, a, n=1 << 24):
             "compress_roofline": roofline("k_stream_* (STARTC: all kernels of hdlz_compress_stream)", algo, kc, "k_stream|stream=%d" % n),
             "note": "one wave (every single stream before hdlz_inflate_par.hip): 9 MB/s; timed with HIP events around whole calls "
                     "(all kernels of the path)"}
+
+
+def bench_zlib_stream(torch, eng, dev, a, n=1 << 24, level=6):
+    """STARTD of ONE stock-zlib stream (level 6: dynamic-tree blocks, 32 KiB distances) -- what the reference's default build
+    (DYNAMIC=True, deflate.py:32) is fed -- on the whole GPU (hdlz_inflate_any.hip, round 6; one wave up to round 5: 11 MB/s)"""
+    import zlib
+    from hdl_deflate_amd.data import make_blocks
+    plain = make_blocks(n // 2048, 2048, "cpu", seed=7).numpy().tobytes()
+    z = zlib.compress(plain, level)
+    zn = len(z)
+    zin = torch.frombuffer(bytearray(z + bytes(64)), dtype=torch.uint8).to(dev).reshape(1, -1)
+    want = torch.frombuffer(bytearray(plain), dtype=torch.uint8).to(dev)
+    back = torch.empty((1, n), dtype=torch.uint8, device=dev)
+    work = torch.empty(eng.lib.hdlz_inflate_work_bytes(1, zn, n, 0, 0), dtype=torch.uint8, device=dev)
+
+    def step():
+        return eng.inflate_batch(zin, in_len=zn, out_pitch=n, out=back, work=work)
+
+    def step_wave():
+        return eng.inflate_batch(zin, in_len=zn, out_pitch=n, out=back, flags=4)
+
+    _, bl, bs = step()
+    torch.cuda.synchronize()
+    assert int(bs.item()) == 0 and int(bl.item()) == n and torch.equal(back.reshape(-1), want), "zlib stream: inflated bytes differ"
+    kd = kernel_ms(torch, step, max(3, a.steps))
+    kw = kernel_ms(torch, step_wave, 1)
+    ms_d = sum(kd) / len(kd)
+    return {"name": "one 16 MiB zlib level-%d stream" % level, "metric": "single-stream inflate throughput (stock zlib stream, any block types, whole GPU)",
+            "value": round(n / ms_d / 1e3, 1), "unit": "MB/s", "ms_per_step": round(ms_d, 4), "higher_is_better": True,
+            "config": {"workload": "zlib.compress(level %d) of %d bytes (families 1-4): dynamic-tree blocks, distances up to 32 KiB; inflated by "
+                                   "hdlz_inflate_batch_ws(nstreams = 1), bytes compared with the input" % (level, n),
+                       "stream_bytes": n, "compressed_bytes": zn, "scratch_bytes": int(work.numel())},
+            "input_MBps": round(zn / ms_d / 1e3, 1), "one_wave_ms": round(kw[0], 2),
+            "roofline": roofline("k_any_* + k_par_emit/jump (STARTD: all kernels of hdlz_inflate_batch(nstreams = 1))", n + zn + 4, kd,
+                                 "k_any|stream=%d|level=%d" % (n, level)),
+            "note": "HIP events around whole calls (all kernels of the path); one_wave_ms: the same stream through k_inflate_dyn (flag 4), "
+                    "what every such stream cost up to round 5"}
 
 
 def bench_few_large(torch, eng, dev, a, nstreams=256, n=1 << 20, with_wave=True):
@@ -973,7 +1011,7 @@ def main():
                          "(exercises the second pass k_inflate_tok<true> / k_inflate_dyn, SURVEY 8(f) rank 1)")
     ap.add_argument("--inflate-kernel", default="default", choices=["default", "lane", "wave", "group"],
                     help="inflate: mapping hint (lane = k_inflate_tok, wave = k_inflate_dyn, group = k_inflate_grp)")
-    ap.add_argument("--mode", default="compress", choices=["compress", "inflate", "roundtrip", "single", "few"],
+    ap.add_argument("--mode", default="compress", choices=["compress", "inflate", "roundtrip", "single", "few", "zlib"],
                     help="compress = BASELINE metric (default); inflate = only the configs[3] side metric (1 GPU)")
     ap.add_argument("--no-archive", dest="archive", action="store_false",
                     help="N=1: skip the archive figure (compress + scan + hdlz_compact_batch) of the headline job")
@@ -1000,6 +1038,11 @@ def main():
         import hdl_deflate_amd
         torch.cuda.set_device(0)
         emit(bench_single_stream(torch, hdl_deflate_amd.Engine(torch.device("cuda", 0)), torch.device("cuda", 0), a), a)
+    elif a.mode == "zlib":                                    # only the stock-zlib single-stream entry (profiling)
+        import torch
+        import hdl_deflate_amd
+        torch.cuda.set_device(0)
+        emit(bench_zlib_stream(torch, hdl_deflate_amd.Engine(torch.device("cuda", 0)), torch.device("cuda", 0), a), a)
     elif a.mode == "few":                                     # only the few-large-streams entry (profiling)
         import torch
         import hdl_deflate_amd

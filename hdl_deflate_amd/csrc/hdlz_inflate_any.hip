@@ -93,7 +93,6 @@ struct Args {
     const uint64_t* in_off;
     uint8_t* ws;                  // this chain's scratch of stream 0
     size_t stride;                // bytes from a stream's scratch to the next stream's
-    const uint32_t* gate;         // stream 0's gate word (the fixed-block chain's C_NOTFIXED)
     uint32_t* srcA;               // stream 0's marker words
     uint32_t nchunks, candcap, maxb, maxx, maxs, tcap, maxreq, mapcap;
     size_t o_cand, o_blk, o_blen, o_shdr, o_spay, o_sidx, o_tab, o_owner, o_map, o_pent, o_prel, o_pnode, o_node, o_xitem, o_sitem,
@@ -122,8 +121,10 @@ __device__ __forceinline__ View view(const Args& a) {
     v.out = a.out + (uint64_t)s * a.out_pitch;
     uint8_t* w = a.ws + (size_t)s * a.stride;
     v.ctl = reinterpret_cast<uint32_t*>(w);
-    const uint32_t* gate = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(a.gate) + (size_t)s * a.stride);
-    v.run = *gate != 0u && v.ctl[C_FALLBACK] == 0u;
+    // the gate: a stream that is ONE fixed block is the other chain's (hdlz_inflate_par.hip: one_fixed_block -- the same test on the same
+    // byte, so the two chains need nothing from each other and run side by side); this one is only launched for the default build's flags
+    const uint32_t hdr = v.zn >= 5u ? (uint32_t)v.z[2] : 0u;
+    v.run = v.zn >= 5u && !((hdr & 1u) != 0u && ((hdr >> 1) & 3u) == 1u) && v.ctl[C_FALLBACK] == 0u;
     v.cand = at<uint32_t>(w, a.o_cand); v.blk = at<Blk>(w, a.o_blk); v.blen = at<uint8_t>(w, a.o_blen); v.shdr = at<uint32_t>(w, a.o_shdr);
     v.spay = at<uint32_t>(w, a.o_spay); v.sidx = at<uint32_t>(w, a.o_sidx); v.tab = at<Tab>(w, a.o_tab); v.owner = at<uint16_t>(w, a.o_owner);
     v.map = at<uint32_t>(w, a.o_map); v.pent = at<uint8_t>(w, a.o_pent); v.prel = at<uint32_t>(w, a.o_prel); v.pnode = at<uint16_t>(w, a.o_pnode);
@@ -138,18 +139,22 @@ __device__ __forceinline__ void give_up(const View& v) { atomicExch(&v.ctl[C_FAL
 // ---- bit reader of one lane, straight from the stream (bytes at or beyond zn read as zero)
 struct Bits {
     const uint8_t* z;
-    uint32_t zn, ip, bc, nxt, pos;
+    uint32_t zn, ip, bc, pos;
+    uint32_t n0, n1, n2, n3;      // the four dwords behind the buffer, requested that far ahead: a lane's refill does not wait for memory
     uint64_t bb;
     __device__ __forceinline__ void init(const uint8_t* z_, uint32_t zn_, uint32_t pos_) {
         z = z_; zn = zn_; pos = pos_;
         ip = (pos >> 3) & ~3u;
         bc = 64u - (pos - 8u * ip);
         bb = (((uint64_t)tok::load32(z, ip + 4u, zn) << 32) | tok::load32(z, ip, zn)) >> (pos - 8u * ip);
-        ip += 8u;
-        nxt = tok::load32(z, ip, zn);
+        n0 = tok::load32(z, ip + 8u, zn); n1 = tok::load32(z, ip + 12u, zn); n2 = tok::load32(z, ip + 16u, zn); n3 = tok::load32(z, ip + 20u, zn);
+        ip += 8u;                  // n0 = the dword at ip
     }
     __device__ __forceinline__ void refill() {          // >= 33 valid bits afterwards
-        if (bc <= 32u) { bb |= (uint64_t)nxt << bc; bc += 32u; ip += 4u; nxt = tok::load32(z, ip, zn); }
+        if (bc <= 32u) {
+            bb |= (uint64_t)n0 << bc; bc += 32u; ip += 4u;
+            n0 = n1; n1 = n2; n2 = n3; n3 = tok::load32(z, ip + 12u, zn);
+        }
     }
     __device__ __forceinline__ void take(uint32_t n) { bb >>= n; bc -= n; pos += n; }
 };
@@ -202,15 +207,15 @@ __device__ __forceinline__ Token token_at(const Tab* t, Bits& r) {
 }
 
 // ================================================================================================ 1. the candidates
-// the first 17 + 3 n bits of a dynamic block header (lo = the next 64 stream bits, hi = the 32 behind them; LSB first): BTYPE, HLIT,
-// HDIST, and a COMPLETE code-length code (hdlz_inflate_dyn.hip: `left[0] != 0` is HDLZ_E_BAD_TREE)
-__device__ __forceinline__ bool header_start_ok(uint64_t lo, uint32_t hi) {
-    const uint32_t x = (uint32_t)lo;
-    if (((x >> 1) & 3u) != 2u) return false;
-    const uint32_t hlit = (x >> 3) & 31u, hdist = (x >> 8) & 31u, n = ((x >> 13) & 15u) + 4u;
-    if (hlit > 29u || hdist > 29u) return false;
-    uint64_t f = (lo >> 17) | ((uint64_t)hi << 47);                 // 47 + 32 bits behind the 17: 57 needed
-    int32_t left = 128;                                             // Kraft sum in units of 1/128
+// the cheap part of the test: BTYPE = 10, HLIT <= 29, HDIST <= 29 (22 % of all positions pass)
+__device__ __forceinline__ bool header_fields_ok(uint32_t x) {
+    return ((x >> 1) & 3u) == 2u && ((x >> 3) & 31u) <= 29u && ((x >> 8) & 31u) <= 29u;
+}
+// ... and the rest: a COMPLETE code-length code (lo: the 64 stream bits from the header's first bit on, hi: the 32 behind them)
+__device__ __forceinline__ bool header_precode_ok(uint64_t lo, uint32_t hi) {
+    const uint32_t n = (((uint32_t)lo >> 13) & 15u) + 4u;
+    uint64_t f = (lo >> 17) | ((uint64_t)hi << 47);
+    int32_t left = 128;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t l = (uint32_t)f & 7u;
         f >>= 3;
@@ -218,13 +223,14 @@ __device__ __forceinline__ bool header_start_ok(uint64_t lo, uint32_t hi) {
     }
     return left == 0;
 }
-constexpr uint32_t FIND_T = 256, FIND_CAP = 2048;
+constexpr uint32_t FIND_T = 256, FIND_CAP = 2048, FIND_Q = 640;
 __global__ __launch_bounds__(FIND_T) void k_any_find(Args a) {
     const View v = view(a);
     __shared__ uint32_t lst[FIND_CAP];
+    __shared__ uint32_t wq[FIND_T / 64][FIND_Q];        // per wave: the positions that passed the cheap part
     __shared__ uint32_t ln, gbase;
     if (!v.run) return;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     // (this kernel also presets the per-piece and per-item words the later ones only write where something is: no owner, no node, no tokens)
     for (uint32_t i = blockIdx.x * FIND_T + tid; i < a.nchunks + a.maxx; i += gridDim.x * FIND_T) {
         v.ntok[i] = 0u; v.mext[i] = 0u; v.opos[i] = 0u;
@@ -243,21 +249,37 @@ __global__ __launch_bounds__(FIND_T) void k_any_find(Args a) {
         if (tid == 0u) ln = 0u;
         __syncthreads();
     };
-    // a thread takes the 8 bit positions of one stream byte: 12 bytes cover the 7 + 17 + 57 bits behind its first bit
+    // a thread takes the 8 bit positions of one stream byte (12 bytes cover the 7 + 17 + 57 bits behind its first bit).  Two steps per
+    // wave: the cheap fields for all 512 positions, then the code-length code for the ones that passed -- packed, so that the loop over
+    // up to 19 lengths runs on full waves (one step: 8 x that loop per thread for the 22 % that get there -- 224 us at 7 MB)
     for (uint32_t base = blockIdx.x * FIND_T; base < v.zn; base += gridDim.x * FIND_T) {
         const uint32_t B = base + tid;
+        uint32_t mask = 0;
         if (B >= 2u && B < v.zn) {
-            const uint32_t d0 = tok::load32(v.z, B, v.zn), d1 = tok::load32(v.z, B + 4u, v.zn), d2 = tok::load32(v.z, B + 8u, v.zn);
+            const uint32_t d0 = tok::load32(v.z, B, v.zn), d1 = tok::load32(v.z, B + 4u, v.zn);
             const uint64_t w01 = ((uint64_t)d1 << 32) | d0;
-#pragma unroll 1
-            for (uint32_t j = 0; j < 8u; j++) {
-                const uint64_t lo = j ? ((w01 >> j) | ((uint64_t)d2 << (64u - j))) : w01;
-                const uint32_t hi = d2 >> j;
-                const uint32_t p = 8u * B + j;
-                if (p + 17u + 12u <= nbits && header_start_ok(lo, hi)) {
-                    const uint32_t k = atomicAdd(&ln, 1u);
-                    if (k < FIND_CAP) lst[k] = p;
-                }
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++)
+                mask |= (8u * B + j + 29u <= nbits && header_fields_ok((uint32_t)(w01 >> j))) ? 1u << j : 0u;
+        }
+        // the wave's queue: thread's entries behind those of the lanes below it
+        uint32_t cntm = __builtin_popcount(mask), incl = cntm;
+#pragma unroll
+        for (int ofs = 1; ofs < 64; ofs <<= 1) { const uint32_t o = __shfl_up(incl, ofs, 64); if (lane >= (uint32_t)ofs) incl += o; }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t at_ = incl - cntm;
+        for (uint32_t m = mask; m; m &= m - 1u) { if (at_ < FIND_Q) wq[wv][at_] = 8u * B + (uint32_t)__builtin_ctz(m); at_++; }
+        wave_lds_order();
+        __builtin_amdgcn_wave_barrier();
+        if (total > FIND_Q && lane == 0u) v.ctl[A_OVER] = 1u;              // (cannot happen on 22 %: 512 positions, 640 slots)
+        for (uint32_t k = lane; k < min(total, FIND_Q); k += 64u) {
+            const uint32_t p = wq[wv][k], Bp = p >> 3, j = p & 7u;
+            const uint32_t d0 = tok::load32(v.z, Bp, v.zn), d1 = tok::load32(v.z, Bp + 4u, v.zn), d2 = tok::load32(v.z, Bp + 8u, v.zn);
+            const uint64_t w01 = ((uint64_t)d1 << 32) | d0;
+            const uint64_t lo = j ? ((w01 >> j) | ((uint64_t)d2 << (64u - j))) : w01;
+            if (header_precode_ok(lo, d2 >> j)) {
+                const uint32_t kk = atomicAdd(&ln, 1u);
+                if (kk < FIND_CAP) lst[kk] = p;
             }
         }
         __syncthreads();
@@ -270,11 +292,58 @@ __global__ __launch_bounds__(FIND_T) void k_any_find(Args a) {
 // one LANE per listed position: the code lengths, and the rest of the serial decoder's acceptance rules (hdlz_inflate_dyn.hip, "BL" ..
 // "canon_build": over-subscribed sets rejected, incomplete ones only with a single code -- for the distance code also with none --,
 // an end-of-block code must exist, the header must leave room for the reference's end-of-input margin)
+// the code-length code of the header at bit p into a 7-bit table (symbol << 3 | length by the next 7 stream bits; stride: elements between
+// entries -- the lanes of k_any_headers interleave theirs); -> the reader behind the 3-bit lengths, HLIT + 257, HDIST + 1, BFINAL
+static __device__ const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+__device__ __forceinline__ void read_precode(Bits& r, uint8_t* clut, uint8_t* cl, uint32_t stride, uint32_t& nlen, uint32_t& ndist, uint32_t& fin) {
+    fin = (uint32_t)r.bb & 1u;
+    r.take(3u);
+    r.refill();
+    nlen = ((uint32_t)r.bb & 31u) + 257u; ndist = (((uint32_t)r.bb >> 5) & 31u) + 1u;
+    const uint32_t ncode = (((uint32_t)r.bb >> 10) & 15u) + 4u;
+    r.take(14u);
+    for (uint32_t k = 0; k < 19u; k++) cl[k * stride] = 0;
+    uint64_t cnt8 = 0;                                              // counts of the lengths 1..7, 8 bits each
+    for (uint32_t k = 0; k < 19u; k++) {
+        if (k < ncode) {
+            r.refill();
+            const uint32_t l = (uint32_t)r.bb & 7u;
+            r.take(3u);
+            cl[CL_ORDER[k] * stride] = (uint8_t)l;
+            cnt8 += l ? (1ull << (8u * l)) : 0ull;
+        }
+    }
+    // canonical codes (the code is complete: k_any_find checked), spread over the 7-bit table
+    uint64_t next8 = 0;                                             // next code of each length, 8 bits each
+    uint32_t code = 0;
+    for (uint32_t l = 1; l < 8u; l++) {
+        code = (code + (uint32_t)((cnt8 >> (8u * (l - 1u))) & 255u)) << 1;            // (byte 0 of cnt8 is 0)
+        next8 |= (uint64_t)(code & 255u) << (8u * l);
+    }
+    for (uint32_t s = 0; s < 19u; s++) {
+        const uint32_t l = cl[s * stride];
+        if (l) {
+            const uint32_t c = (uint32_t)(next8 >> (8u * l)) & 255u;
+            next8 += 1ull << (8u * l);
+            const uint32_t rv = __builtin_bitreverse32(c) >> (32u - l);
+            for (uint32_t k = rv; k < 128u; k += 1u << l) clut[k * stride] = (uint8_t)((s << 3) | l);
+        }
+    }
+}
+// one code-length symbol (READBL / REPEAT, deflate.py:1116-1164, :1190-1202): -> value, repeat count
+__device__ __forceinline__ void read_length(Bits& r, const uint8_t* clut, uint32_t stride, uint32_t prev, uint32_t& val, uint32_t& rep, uint32_t& sy) {
+    r.refill();
+    const uint32_t e = clut[((uint32_t)r.bb & 127u) * stride], l = e & 7u;
+    sy = e >> 3;
+    r.take(l);
+    rep = 1u; val = sy;
+    if (sy == 16u) { rep = 3u + ((uint32_t)r.bb & 3u); r.take(2u); val = prev; }
+    else if (sy == 17u) { rep = 3u + ((uint32_t)r.bb & 7u); r.take(3u); val = 0u; }
+    else if (sy == 18u) { rep = 11u + ((uint32_t)r.bb & 127u); r.take(7u); val = 0u; }
+}
 struct HdrLds {
-    uint8_t clut[128][64];        // the code-length code by the next 7 bits: symbol << 3 | length, per lane
+    uint8_t clut[128][64];        // the code-length code by the next 7 bits, per lane
     uint8_t cl[19][64];
-    uint8_t lens[320][64];
-    uint16_t cnt[32][64];         // code counts per length: [0, 16) literal/length, [16, 32) distance
 };
 __global__ __launch_bounds__(64) void k_any_headers(Args a) {
     const View v = view(a);
@@ -290,77 +359,34 @@ __global__ __launch_bounds__(64) void k_any_headers(Args a) {
         const uint32_t p = ok ? v.cand[i] : 16u;
         Bits r;
         r.init(v.z, v.zn, p);
-        const uint32_t fin = (uint32_t)r.bb & 1u;
-        r.take(3u);
-        r.refill();
-        const uint32_t nlen = ((uint32_t)r.bb & 31u) + 257u, ndist = (((uint32_t)r.bb >> 5) & 31u) + 1u, ncode = (((uint32_t)r.bb >> 10) & 15u) + 4u;
-        r.take(14u);
+        uint32_t nlen, ndist, fin;
+        read_precode(r, &L.clut[0][lane], &L.cl[0][lane], 64u, nlen, ndist, fin);
         const uint32_t total = nlen + ndist;
-        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-        for (uint32_t k = 0; k < 19u; k++) L.cl[k][lane] = 0;
-        uint64_t cnt8 = 0;                                          // counts of the lengths 1..7, 8 bits each
-        for (uint32_t k = 0; k < 19u; k++) {
-            if (ok && k < ncode) {
-                r.refill();
-                const uint32_t l = (uint32_t)r.bb & 7u;
-                r.take(3u);
-                L.cl[order[k]][lane] = (uint8_t)l;
-                cnt8 += l ? (1ull << (8u * l)) : 0ull;
-            }
-        }
-        // canonical codes of the code-length code (complete: k_any_find checked), spread over the 7-bit table
-        uint64_t next8 = 0;                                         // next code of each length, 8 bits each
-        {
-            uint32_t code = 0;
-            for (uint32_t l = 1; l < 8u; l++) {
-                code = (code + (uint32_t)((cnt8 >> (8u * (l - 1u))) & 255u) * (l > 1u ? 1u : 0u)) << 1;
-                next8 |= (uint64_t)(code & 255u) << (8u * l);
-            }
-        }
-        for (uint32_t s = 0; s < 19u; s++) {
-            const uint32_t l = ok ? L.cl[s][lane] : 0u;
-            if (l) {
-                const uint32_t code = (uint32_t)(next8 >> (8u * l)) & 255u;
-                next8 += 1ull << (8u * l);
-                const uint32_t rv = __builtin_bitreverse32(code) >> (32u - l);
-                for (uint32_t k = rv; k < 128u; k += 1u << l) L.clut[k][lane] = (uint8_t)((s << 3) | l);
-            }
-        }
-        // READBL / REPEAT (deflate.py:1116-1164, :1190-1202)
-        uint32_t idx = 0, prev = 0;
+        // the length list, counted and checked only -- registers: the Kraft sums of the two codes in units of 2^-15, their numbers of
+        // codes, the length of the end-of-block code.  Most positions fail within a few symbols (a set that is over-subscribed
+        // already is dropped at once); the lists of the few that ARE headers are decoded again where they are needed (k_any_tables)
+        uint32_t idx = 0, prev = 0, kr1 = 0, kr2 = 0, nz1 = 0, nz2 = 0, eob_len = 0;
         while (ballot64(ok && idx < total) != 0ull) {
             if (ok && idx < total) {
-                r.refill();
-                const uint32_t e = L.clut[(uint32_t)r.bb & 127u][lane], l = e & 7u, sy = e >> 3;
-                r.take(l);
-                uint32_t rep = 1, val = sy;
-                if (sy == 16u) { if (idx == 0u) ok = false; rep = 3u + ((uint32_t)r.bb & 3u); r.take(2u); val = prev; }
-                else if (sy == 17u) { rep = 3u + ((uint32_t)r.bb & 7u); r.take(3u); val = 0u; }
-                else if (sy == 18u) { rep = 11u + ((uint32_t)r.bb & 127u); r.take(7u); val = 0u; }
-                if (idx + rep > total || r.pos > nbits) ok = false;
-                if (ok) for (uint32_t k = 0; k < rep; k++) L.lens[idx + k][lane] = (uint8_t)val;
+                uint32_t val, rep, sy;
+                read_length(r, &L.clut[0][lane], 64u, prev, val, rep, sy);
+                if ((sy == 16u && idx == 0u) || idx + rep > total || r.pos > nbits) ok = false;
+                const uint32_t n1 = idx < nlen ? min(rep, nlen - idx) : 0u, n2 = rep - n1;
+                if (val) { kr1 += n1 << (15u - val); kr2 += n2 << (15u - val); nz1 += n1; nz2 += n2; }
+                if (kr1 > 32768u || kr2 > 32768u) ok = false;                                // over-subscribed
+                if (idx <= 256u && 256u < idx + rep) eob_len = val;
                 prev = val;
                 idx += rep;
             }
         }
-        if (ok) {
-            for (uint32_t k = 0; k < 32u; k++) L.cnt[k][lane] = 0;
-            for (uint32_t k = 0; k < total; k++) { const uint32_t l = L.lens[k][lane]; L.cnt[(k < nlen ? 0u : 16u) + l][lane]++; }
-            if (L.lens[256][lane] == 0) ok = false;                                         // no end-of-block code
-            int32_t l1 = 1, l2 = 1;
-            for (uint32_t l = 1; l < 16u; l++) { l1 = (l1 << 1) - (int32_t)L.cnt[l][lane]; if (l1 < 0) break; }
-            for (uint32_t l = 1; l < 16u; l++) { l2 = (l2 << 1) - (int32_t)L.cnt[16u + l][lane]; if (l2 < 0) break; }
-            if (l1 < 0 || (l1 > 0 && (int32_t)nlen - (int32_t)L.cnt[0][lane] != 1)) ok = false;
-            if (l2 < 0 || (l2 > 0 && (int32_t)ndist - (int32_t)L.cnt[16][lane] > 1)) ok = false;
-            if ((int32_t)(r.pos >> 3) > isize - 3) ok = false;                              // (the serial decoder's NO EOF at the end of a header)
-        }
+        if (eob_len == 0u) ok = false;                                                        // no end-of-block code
+        if (kr1 < 32768u && nz1 != 1u) ok = false;                                            // incomplete: only with a single code
+        if (kr2 < 32768u && nz2 > 1u) ok = false;                                             // ... the distance code also with none
+        if ((int32_t)(r.pos >> 3) > isize - 3) ok = false;                                    // (the serial decoder's NO EOF at the end of a header)
         if (ok) {
             const uint32_t slot = atomicAdd(&v.ctl[A_NBLK], 1u);
-            if (slot < a.maxb) {
-                v.blk[slot] = Blk{p, r.pos, fin, nlen};
-                uint8_t* bl = v.blen + (size_t)slot * 320u;
-                for (uint32_t k = 0; k < 320u; k++) bl[k] = k < total ? L.lens[k][lane] : (uint8_t)0;
-            } else v.ctl[A_OVER] = 1u;
+            if (slot < a.maxb) v.blk[slot] = Blk{p, r.pos, fin, nlen};
+            else v.ctl[A_OVER] = 1u;
         }
     }
 }
@@ -387,6 +413,7 @@ __global__ __launch_bounds__(SORT_T) void k_any_sort(Args a) {
 struct TabLds {
     Tab t;
     uint8_t len[320];
+    uint8_t clut[128], cl[19];
     uint32_t cnt[32], first[32], off[32];
 };
 constexpr uint32_t TAB_T = 256;
@@ -400,10 +427,24 @@ __global__ __launch_bounds__(TAB_T) void k_any_tables(Args a) {
         uint32_t nlen = 288u;
         __syncthreads();
         if (r < n) {
-            const uint32_t bi = v.sidx[r];
-            nlen = v.blk[bi].nlen;
-            const uint8_t* bl = v.blen + (size_t)bi * 320u;
-            for (uint32_t k = tid; k < 320u; k += TAB_T) L.len[k] = bl[k];
+            // the block's length list, by one thread (k_any_headers only checked it): ~300 dependent steps
+            nlen = v.blk[v.sidx[r]].nlen;
+            for (uint32_t k = tid; k < 320u; k += TAB_T) L.len[k] = 0;
+            __syncthreads();
+            if (tid == 0u) {
+                Bits rd;
+                rd.init(v.z, v.zn, v.shdr[r]);
+                uint32_t nl, nd, fin;
+                read_precode(rd, L.clut, L.cl, 1u, nl, nd, fin);
+                uint32_t idx = 0, prev = 0;
+                while (idx < nl + nd) {
+                    uint32_t val, rep, sy;
+                    read_length(rd, L.clut, 1u, prev, val, rep, sy);
+                    for (uint32_t k = 0; k < rep && idx + k < 320u; k++) L.len[idx + k] = (uint8_t)val;
+                    prev = val;
+                    idx += rep;
+                }
+            }
         } else {
             for (uint32_t k = tid; k < 320u; k += TAB_T) L.len[k] = (uint8_t)(k < 144u ? 8 : k < 256u ? 9 : k < 280u ? 7 : k < 288u ? 8 : 5);
         }
@@ -477,7 +518,12 @@ struct SpecLds {
 __device__ __forceinline__ void load_tab(Tab* dst_, const Tab* src_, uint32_t lane) {
     const tok::u32x4* src = reinterpret_cast<const tok::u32x4*>(src_);
     tok::u32x4* dst = reinterpret_cast<tok::u32x4*>(dst_);
-    for (uint32_t k = lane; k < sizeof(Tab) / 16u; k += 64u) dst[k] = src[k];
+    static_assert(sizeof(Tab) % 1024 == 0, "whole rounds of 64 lanes x 16 bytes");
+    tok::u32x4 t[sizeof(Tab) / 1024];                               // all the loads first: ONE memory latency, not one per round
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(Tab) / 1024u; k++) t[k] = src[k * 64u + lane];
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(Tab) / 1024u; k++) dst[k * 64u + lane] = t[k];
 }
 // piece q with the tables at t (LDS), one wave: lane e starts at the piece's bit e -> mp[e]
 __device__ __forceinline__ void spec_piece(const View& v, const Tab* t, uint32_t* win, uint32_t q, uint32_t* mp, uint32_t lane) {
@@ -559,11 +605,21 @@ __device__ __forceinline__ uint32_t find_rank(const uint32_t* shdr, uint32_t n, 
     while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (shdr[m] < hdr) lo = m + 1u; else hi = m; }
     return lo < n && shdr[lo] == hdr ? lo : N_BAD;
 }
+// ONE WAVE per node.  The walk is one serial chain, kept identical in all 64 lanes (every lane computes the same values from the same
+// addresses; what has a side effect -- a counter, a list entry, the node's result -- is done by lane 0 and broadcast); what the other
+// lanes are for: the maps of 64 pieces at a time are staged in LDS by the whole wave (16 KB, coalesced), so a step of the chain costs
+// an LDS round trip instead of two dependent global loads (one lane per node straight from memory: 260 us for the ~235 pieces of a
+// 16 K-symbol block)
+constexpr uint32_t WALK_STAGE = 64;           // pieces staged at a time
 __global__ __launch_bounds__(64) void k_any_walk(Args a, uint32_t round) {
     const View v = view(a);
+    __shared__ uint32_t smap[WALK_STAGE * 64];
+    __shared__ uint32_t sown[WALK_STAGE];
+    __shared__ Tab lt;                       // the tables the lane-serial parts decode with (the block's; later the fixed code's)
     if (!v.run) return;
     const uint32_t n = min(v.ctl[A_NBLK], a.maxb);
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;                // node: candidate rank i < n, or the pseudo-node i == n (stored at index maxb)
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = blockIdx.x;                                    // node: candidate rank i < n, or the pseudo-node i == n (stored at index maxb)
     if (i > n) return;
     const uint32_t nbits = 8u * v.zn;
     const int32_t isize = (int32_t)v.zn - 1;
@@ -574,10 +630,15 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a, uint32_t round) {
     uint32_t ebit = 16u, fin = 0u, next = N_BAD, why = 0u;
     bool ok = true;
     Bits rd;
+    auto bump = [&](uint32_t* ctr, uint32_t by) -> uint32_t {        // atomicAdd by lane 0, the old value in every lane
+        uint32_t k = 0;
+        if (lane == 0u) k = atomicAdd(ctr, by);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    };
     auto add_xitem = [&](uint32_t start, uint32_t limit, uint32_t slot) {
-        const uint32_t k = atomicAdd(&v.ctl[A_NX], 1u);
-        if (k < a.maxx) v.xitem[k] = XItem{start, limit, (uint32_t)nb, node_id | (slot << 16)};
-        else { v.ctl[A_OVER] = 1u; ok = false; }
+        const uint32_t k = bump(&v.ctl[A_NX], 1u);
+        if (k < a.maxx) { if (lane == 0u) v.xitem[k] = XItem{start, limit, (uint32_t)nb, node_id | (slot << 16)}; }
+        else { if (lane == 0u) v.ctl[A_OVER] = 1u; ok = false; }
     };
     // bits [rd.pos, limit) with the tables of `slot`, counting bytes; -> true at the end-of-block code (consumed)
     auto run_to = [&](const Tab* t, uint32_t limit, bool& eob) {
@@ -597,10 +658,13 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a, uint32_t round) {
         if (round == 0u) {
             rd.init(v.z, v.zn, b.pay);
             q = b.pay / PB;
-            if (b.pay % PB != 0u) {                                   // the first, partial piece: by this lane
+            if (b.pay % PB != 0u) {                                   // the first, partial piece: decoded here
                 const uint32_t limit = (q + 1u) * PB;
                 add_xitem(b.pay, limit, i);
-                run_to(&v.tab[i], limit, eob);
+                load_tab(&lt, &v.tab[i], lane);
+                wave_lds_order();
+                __builtin_amdgcn_wave_barrier();
+                run_to(&lt, limit, eob);
                 q++;
             }
             pos = rd.pos;
@@ -610,28 +674,48 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a, uint32_t round) {
             const Req rq = v.req[st.req];
             rq0 = rq.q0; rq1 = rq.q1; rslot = rq.slot;
         }
+        uint32_t sq0 = 0;                                             // first staged piece
+        bool staged = false;
         while (ok && !eob) {                                          // whole pieces: through the maps
             if (q >= a.nchunks || pos - q * PB >= 64u) { ok = false; why |= W_WALK_OWNER; break; }
             const uint32_t e = pos - q * PB;
+            if (!staged || q - sq0 >= WALK_STAGE) {
+                sq0 = q; staged = true;
+                const uint32_t cnt = min(WALK_STAGE, a.nchunks - sq0);
+                __builtin_amdgcn_wave_barrier();
+                const tok::u32x4* src = reinterpret_cast<const tok::u32x4*>(v.map + (size_t)sq0 * 64u);
+                tok::u32x4* dst = reinterpret_cast<tok::u32x4*>(smap);
+                tok::u32x4 t[WALK_STAGE / 4];                         // (all 16 loads in flight at once; the rows behind the last piece: re-read of the last one)
+#pragma unroll
+                for (uint32_t k = 0; k < WALK_STAGE / 4u; k++) t[k] = src[min(k * 64u + lane, cnt * 16u - 1u)];
+#pragma unroll
+                for (uint32_t k = 0; k < WALK_STAGE / 4u; k++) dst[k * 64u + lane] = t[k];
+                if (lane < cnt) sown[lane] = v.owner[sq0 + lane];
+                wave_lds_order();
+                __builtin_amdgcn_wave_barrier();
+            }
             uint32_t m;
-            if (v.owner[q] == i) {
-                m = v.map[(size_t)q * 64u + e];
-                v.pent[q] = (uint8_t)e; v.prel[q] = (uint32_t)nb; v.pnode[q] = (uint16_t)i;
+            const uint32_t own = sown[q - sq0];
+            if (own == i) {
+                m = smap[(q - sq0) * 64u + e];
+                if (lane == 0u) { v.pent[q] = (uint8_t)e; v.prel[q] = (uint32_t)nb; v.pnode[q] = (uint16_t)i; }
             } else if (q >= rq0 && q < rq1) {                         // a piece decoded for this block on request: an item of its own
                 m = v.map2[(size_t)(rslot + (q - rq0)) * 64u + e];
                 add_xitem(q * PB + e, (q + 1u) * PB, i);
             } else {
                 // decoded for another candidate (a false positive inside this block, if this block is a true one): ask for the pieces up
                 // to the next candidate behind that one with this block's tables, go on in the next round
-                const uint32_t f = v.owner[q];
+                const uint32_t f = own;
                 if (f == NO_OWNER || round + 1u >= WALK_ROUNDS) { ok = false; why |= W_WALK_OWNER; break; }
                 uint32_t qe = f + 1u < n ? min((v.spay[f + 1u] + PB - 1u) / PB, a.nchunks) : a.nchunks;
                 qe = min(qe, q + REQ_MAX);
-                const uint32_t slot = atomicAdd(&v.ctl[A_NREQP], qe - q), r = atomicAdd(&v.ctl[A_NREQ], 1u);
+                const uint32_t slot = bump(&v.ctl[A_NREQP], qe - q), r = bump(&v.ctl[A_NREQ], 1u);
                 if (slot + (qe - q) > a.mapcap || r >= a.maxreq) { ok = false; why |= W_WALK_OWNER; break; }
-                v.req[r] = Req{i, q, qe, slot, round};
-                v.nstate[i] = NState{q, pos, (uint32_t)nb, r};
-                v.node[node_id] = Node{N_BAD, 0u, 3u, 0u};
+                if (lane == 0u) {
+                    v.req[r] = Req{i, q, qe, slot, round};
+                    v.nstate[i] = NState{q, pos, (uint32_t)nb, r};
+                    v.node[node_id] = Node{N_BAD, 0u, 3u, 0u};
+                }
                 return;
             }
             nb += m & 0x7FFFFu;
@@ -662,9 +746,9 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a, uint32_t round) {
             const uint32_t i_noeof = (int32_t)p0 >= isize ? 0u : (uint32_t)isize - p0;
             if (length > i_noeof || (int32_t)(p0 + length) >= isize) { ok = false; why |= W_WALK_STORED; break; }
             if (length) {
-                const uint32_t k = atomicAdd(&v.ctl[A_NS], 1u);
-                if (k < a.maxs) v.sitem[k] = SItem{p0, length, (uint32_t)nb, node_id};
-                else { v.ctl[A_OVER] = 1u; ok = false; break; }
+                const uint32_t k = bump(&v.ctl[A_NS], 1u);
+                if (k < a.maxs) { if (lane == 0u) v.sitem[k] = SItem{p0, length, (uint32_t)nb, node_id}; }
+                else { if (lane == 0u) v.ctl[A_OVER] = 1u; ok = false; break; }
             }
             nb += length;
             ebit = 8u * (p0 + length);
@@ -673,18 +757,22 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a, uint32_t round) {
             rd.take(3u);
             const uint32_t stop = rd.pos + FIX_MAX_BITS;
             bool eob = false;
+            __builtin_amdgcn_wave_barrier();
+            load_tab(&lt, &v.tab[a.maxb], lane);
+            wave_lds_order();
+            __builtin_amdgcn_wave_barrier();
             while (ok && !eob) {
                 const uint32_t limit = (rd.pos / PB + 1u) * PB;
                 if (rd.pos >= stop) { ok = false; why |= W_WALK_FIX; break; }
                 add_xitem(rd.pos, limit, a.maxb);
-                run_to(&v.tab[a.maxb], limit, eob);
+                run_to(&lt, limit, eob);
             }
             ebit = rd.pos;
         }
         if (nb > 0xFFFFFFFFull) { ok = false; break; }
         fin = f;
     }
-    v.node[node_id] = Node{next, (uint32_t)nb, ok ? 1u : 0u, why};        // (obase of a failed node: why its walk failed -- read by k_any_rank if it is on the chain)
+    if (lane == 0u) v.node[node_id] = Node{next, (uint32_t)nb, ok ? 1u : 0u, why};        // (obase of a failed node: why its walk failed -- read by k_any_rank if it is on the chain)
 }
 
 // one thread follows the successors from the pseudo-node: the true chain, the output position of every block on it, the total
@@ -729,47 +817,66 @@ __global__ __launch_bounds__(256) void k_any_rank(Args a) {
 // hands the stream to the serial decoder, which reports the reference's status in the reference's order
 __global__ __launch_bounds__(64) void k_any_tokens(Args a) {
     const View v = view(a);
+    __shared__ Tab lt;                       // the tables of the wave's items when they all belong to one block (most waves: 64 consecutive pieces)
     if (!v.run || v.ctl[C_OK] == 0u) return;
     const uint32_t nitems = v.ctl[C_NUSED];
     const int32_t isize = (int32_t)v.zn - 1;
     const uint32_t obsize = a.obsize ? a.obsize : 32768u;
+    const uint32_t lane = threadIdx.x;
     bool bad = false;
+    uint32_t cur = 0xFFFFFFFFu;
     for (uint32_t i0 = blockIdx.x * 64u; i0 < nitems; i0 += gridDim.x * 64u) {
-        const uint32_t i = i0 + threadIdx.x;
-        if (i >= nitems) continue;
-        uint32_t start, limit, rel, nid, slot;
-        if (i < a.nchunks) {
-            nid = v.pnode[i];
-            if (nid == NO_OWNER) continue;
-            start = i * PB + v.pent[i]; limit = (i + 1u) * PB; rel = v.prel[i]; slot = nid;
-        } else {
-            const XItem x = v.xitem[i - a.nchunks];
-            start = x.start; limit = x.limit; rel = x.rel; nid = x.node_slot & 0xFFFFu; slot = x.node_slot >> 16;
+        const uint32_t i = i0 + lane;
+        uint32_t start = 0, limit = 0, rel = 0, nid = NO_OWNER, slot = 0;
+        bool have = i < nitems;
+        if (have) {
+            if (i < a.nchunks) {
+                nid = v.pnode[i];
+                if (nid != NO_OWNER) { start = i * PB + v.pent[i]; limit = (i + 1u) * PB; rel = v.prel[i]; slot = nid; }
+            } else {
+                const XItem x = v.xitem[i - a.nchunks];
+                start = x.start; limit = x.limit; rel = x.rel; nid = x.node_slot & 0xFFFFu; slot = x.node_slot >> 16;
+            }
         }
-        const Node nd = v.node[nid];
-        if (nd.ok != 2u) continue;                                   // not on the chain
-        const Tab* t = &v.tab[slot];
+        Node nd = Node{0u, 0u, 0u, 0u};
+        if (have && nid != NO_OWNER) nd = v.node[nid];
+        have = have && nid != NO_OWNER && nd.ok == 2u;                // (not on the chain: nothing to do)
+        const uint64_t hm = ballot64(have);
+        if (hm == 0ull) continue;
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)slot, (int)__builtin_ctzll(hm));
+        const bool uniform = ballot64(have && slot != s0) == 0ull;
+        if (uniform && s0 != cur) {
+            __builtin_amdgcn_wave_barrier();
+            load_tab(&lt, &v.tab[s0], lane);
+            wave_lds_order();
+            __builtin_amdgcn_wave_barrier();
+            cur = s0;
+        }
         uint32_t P = nd.obase + rel, nt = 0;
         uint32_t* tk = v.tok + (size_t)i * a.tcap;
-        v.opos[i] = P;
+        if (have) v.opos[i] = P;
         Bits rd;
-        rd.init(v.z, v.zn, start);
-        while (rd.pos < limit) {
-            const uint32_t p0 = rd.pos;
-            const Token k = token_at(t, rd);
-            bool f = k.kind == 3u || (int32_t)((p0 + k.nb) >> 3) > isize - 3;                      // no code; NO EOF (deflate.py:1535-1539)
-            if (k.kind == 2u) { bad |= f; break; }
-            const uint32_t made = k.kind == 0u ? 1u : k.length;
-            f |= (uint64_t)P + made > a.cap;
-            f |= k.kind == 1u && (k.dist > P || k.dist > obsize || (int32_t)((p0 + k.used) >> 3) >= isize - 2);     // D8; COPY hold (:1600)
-            if (nt >= a.tcap) { f = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_TCAP); }
-            if (f) { bad = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_TOKEN); break; }
-            tk[nt++] = k.kind == 0u ? (TOK_LIT | k.lit) : (k.length | (k.dist << 9));
-            P += made;
-        }
-        v.ntok[i] = nt;
+        rd.init(v.z, v.zn, have ? start : 16u);
+        auto decode = [&](const Tab* t) {
+            while (have && rd.pos < limit) {
+                const uint32_t p0 = rd.pos;
+                const Token k = token_at(t, rd);
+                bool f = k.kind == 3u || (int32_t)((p0 + k.nb) >> 3) > isize - 3;                  // no code; NO EOF (deflate.py:1535-1539)
+                if (k.kind == 2u) { bad |= f; break; }
+                const uint32_t made = k.kind == 0u ? 1u : k.length;
+                f |= (uint64_t)P + made > a.cap;
+                f |= k.kind == 1u && (k.dist > P || k.dist > obsize || (int32_t)((p0 + k.used) >> 3) >= isize - 2);     // D8; COPY hold (:1600)
+                if (nt >= a.tcap) { f = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_TCAP); }
+                if (f) { bad = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_TOKEN); break; }
+                tk[nt++] = k.kind == 0u ? (TOK_LIT | k.lit) : (k.length | (k.dist << 9));
+                P += made;
+            }
+        };
+        if (uniform) decode(&lt);
+        else decode(&v.tab[slot]);
+        if (have) v.ntok[i] = nt;
     }
-    if (ballot64(bad) != 0ull && (threadIdx.x & 63u) == 0u) give_up(v);
+    if (ballot64(bad) != 0ull && lane == 0u) give_up(v);
 }
 
 // the stored blocks: straight copies; their bytes are there (no marker)
@@ -805,8 +912,8 @@ static Lay lay_of(uint32_t zn) {
     L.candcap = (uint32_t)(nbits / 512u) + 1024u;
     L.maxb = zn / 2048u < 64u ? 64u : zn / 2048u > 4096u ? 4096u : zn / 2048u;
     L.maxreq = 2u * L.maxb;
-    L.mapcap = L.nchunks / 4u + 1024u;                              // pieces decoded a second time, on request (false positives: ~one per 4 MB)
-    L.maxx = 4u * L.maxb + 256u + L.mapcap;                         // (every such piece is an extra item)
+    L.mapcap = L.nchunks / 16u + 1024u;                             // pieces decoded a second time, on request (false positives: ~one per 4 MB, ~120 pieces each)
+    L.maxx = 2u * L.maxb + 256u + L.mapcap;                         // (every such piece is an extra item; + a partial piece per block, + the fixed blocks' pieces)
     L.maxs = zn / 4096u + 256u;
     L.tcap = 256u;
     size_t off = 256;                                               // the control words in front
@@ -832,14 +939,14 @@ size_t any_work_bytes(uint32_t in_len, uint64_t out_pitch, uint32_t flags) {
 }
 
 hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, size_t ws_stride, size_t ws_off, size_t sa_off,
-                              const uint32_t* gate, uint32_t srcn, uint32_t cap, hipStream_t stream, uint32_t* passes_out) {
+                              uint32_t srcn, uint32_t cap, hipStream_t stream, uint32_t* passes_out) {
     using namespace any;
     const Lay L = lay_of(a.in_len);
     Args g;
     memset(&g, 0, sizeof(g));
     g.z = a.in; g.zn = a.in_len; g.flags = a.flags; g.obsize = a.obsize; g.out = a.out; g.cap = cap; g.srcn = srcn;
     g.in_pitch = a.in_pitch; g.out_pitch = a.out_pitch; g.in_off = a.in_off;
-    g.ws = ws + ws_off; g.stride = ws_stride; g.gate = gate; g.srcA = reinterpret_cast<uint32_t*>(ws + sa_off);
+    g.ws = ws + ws_off; g.stride = ws_stride; g.srcA = reinterpret_cast<uint32_t*>(ws + sa_off);
     g.nchunks = L.nchunks; g.candcap = L.candcap; g.maxb = L.maxb; g.maxx = L.maxx; g.maxs = L.maxs; g.tcap = L.tcap;
     g.maxreq = L.maxreq; g.mapcap = L.mapcap; g.o_req = L.o_req; g.o_map2 = L.o_map2; g.o_nstate = L.o_nstate;
     g.o_cand = L.o_cand; g.o_blk = L.o_blk; g.o_blen = L.o_blen; g.o_shdr = L.o_shdr; g.o_spay = L.o_spay; g.o_sidx = L.o_sidx; g.o_tab = L.o_tab;
@@ -854,10 +961,10 @@ hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, 
     hipLaunchKernelGGL(k_any_tables, dim3(gx(L.maxb + 1u, 1024u), nstr), dim3(TAB_T), 0, stream, g);
     hipLaunchKernelGGL(k_any_owner, dim3(gx(L.maxb, 1024u), nstr), dim3(64), 0, stream, g);
     hipLaunchKernelGGL(k_any_spec, dim3(gx((L.nchunks + SPEC_W - 1u) / SPEC_W, 1536u), nstr), dim3(64 * SPEC_W), 0, stream, g);
-    hipLaunchKernelGGL(k_any_walk, dim3((L.maxb + 1u + 63u) / 64u, nstr), dim3(64), 0, stream, g, 0u);
+    hipLaunchKernelGGL(k_any_walk, dim3(L.maxb + 1u, nstr), dim3(64), 0, stream, g, 0u);
     for (uint32_t round = 1; round < WALK_ROUNDS; round++) {        // (return at once when no walk met a false positive)
         hipLaunchKernelGGL(k_any_spec2, dim3(256, nstr), dim3(64 * SPEC_W), 0, stream, g, round);
-        hipLaunchKernelGGL(k_any_walk, dim3((L.maxb + 1u + 63u) / 64u, nstr), dim3(64), 0, stream, g, round);
+        hipLaunchKernelGGL(k_any_walk, dim3(L.maxb + 1u, nstr), dim3(64), 0, stream, g, round);
     }
     hipLaunchKernelGGL(k_any_rank, dim3(1, nstr), dim3(256), 8u * (L.maxb + 1u), stream, g);
     hipLaunchKernelGGL(k_any_tokens, dim3(gx((nitems + 63u) / 64u, 8192u), nstr), dim3(64), 0, stream, g);

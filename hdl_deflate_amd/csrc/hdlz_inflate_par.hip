@@ -703,24 +703,29 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a_) {
 // in the launch it runs in (that store may not be visible yet): a resolved position keeps ROOT | r, r = the byte of the emit its chain
 // ends in -- final since the emit -- and a chain that arrives there takes out[r], not out[p].
 // (HOPS, hdlz_inflate_par.h: 8 in round 2 -- a pass that finds nothing left still costs a launch, 4.5 us; three passes of 256 cover 65536 pieces)
+constexpr uint32_t JUMP_GRID = 8192;          // workgroups of the passes behind the first one (they mostly find nothing left)
 constexpr uint32_t ROOT = 0x80000000u;        // src word: ROOT | r = resolved, the byte is out[r] (NONE: a byte of the emit, its own root); positions are < 2^30
 __global__ __launch_bounds__(64) void k_par_jump(ParArgs a_, uint32_t pass) {
     const ParArgs a = of_stream(a_);
     if (a.ctl[C_FALLBACK] != 0u) return;
     if (a.ctl[pass == 0u ? (uint32_t)C_MARK : C_PASS0 + pass - 1u] == 0u) return;            // nothing left
-    const uint32_t c = blockIdx.x;
-    if (c >= a.ctl[C_NUSED]) return;
-    const uint32_t ext = a.mext[c];
-    if (ext == 0u) return;
-    const uint32_t p0 = a.opos[c];
     uint32_t* s = a.srcA;
+    const uint32_t nused = a.ctl[C_NUSED];
+    uint32_t left = 0;
+    __shared__ unsigned long long memo[256];
+    // (a workgroup takes the pieces blockIdx.x, + gridDim.x, ..: the passes behind the first one are launched with JUMP_GRID workgroups -- a
+    //  pass that finds nothing left costs what its workgroups cost to start, 20 us for the 90 000 items of a 7 MB zlib stream; the FIRST
+    //  pass keeps one workgroup per piece: capped, it ran 665 us instead of 407)
+    for (uint32_t c = blockIdx.x; c < nused; c += gridDim.x) {
+    const uint32_t ext = a.mext[c];
+    if (ext == 0u) continue;
+    const uint32_t p0 = a.opos[c];
     // What a walk from marker m found is kept for the piece's later bytes (a direct-mapped table in LDS, key and result in one 8-byte
     // entry): the markers of a piece share few targets -- the bytes in front of it --, and in a run or a short period (zeros: EVERY
     // byte of every piece is a marker of the byte in front of the piece) they all share one to `period` of them: 64 MiB of zeros
     // 10.1 -> 1.6 ms, 256 MiB 36.5 -> 4.1 ms (profiles/r05_single_stream_inflate.txt).  (One wave per piece: its LDS accesses are in program order.)
-    __shared__ unsigned long long memo[256];
     for (uint32_t k = threadIdx.x; k < 256u; k += 64u) memo[k] = ~0ull;          // (no marker is NONE)
-    uint32_t left = 0;
+    wave_lds_order();
     for (uint32_t q = p0; q < p0 + ext; q += 64u) {
         const uint32_t p = q + threadIdx.x;
         uint32_t m = p < p0 + ext ? s[p] : NONE;
@@ -742,6 +747,8 @@ __global__ __launch_bounds__(64) void k_par_jump(ParArgs a_, uint32_t pass) {
         if (r & ROOT) a.out[p] = a.out[r & ~ROOT];                            // (a byte of the emit: nobody writes it now)
         else left++;
         s[p] = r;
+    }
+    wave_lds_order();
     }
 #pragma unroll
     for (int ofs = 32; ofs > 0; ofs >>= 1) left += (uint32_t)__shfl_xor((int)left, ofs, 64);
@@ -784,7 +791,7 @@ __global__ __launch_bounds__(64) void k_par_flag_rest(uint32_t* out_len, uint32_
 
 hipError_t par::par_launch_emit_jump(const ParArgs& p, uint32_t nitems, uint32_t passes, uint32_t nstr, hipStream_t stream) {
     hipLaunchKernelGGL(k_par_emit, dim3(nitems, nstr), dim3(64), 0, stream, p);
-    for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(nitems, nstr), dim3(64), 0, stream, p, j);
+    for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(j == 0u || nitems < JUMP_GRID ? nitems : JUMP_GRID, nstr), dim3(64), 0, stream, p, j);
     return hipGetLastError();
 }
 
@@ -846,6 +853,19 @@ size_t inflate_par_work_bytes(uint32_t in_len, uint64_t nstreams, uint64_t out_p
     constexpr size_t BUDGET = (size_t)4 << 30;
     const size_t all = L.stride * (size_t)nstreams;
     return all > BUDGET && nstreams > 1 ? (BUDGET / L.stride ? (BUDGET / L.stride) * L.stride : L.stride) : all;
+}
+
+// The two chains need nothing from each other (each looks at the stream's first block header itself), and for any given stream one of
+// them is a dozen launches that return at once -- 40 .. 90 us of launch spacing if they queue up behind each other.  So the chain for any
+// block types runs on a SIDE stream of the library's (one per host thread and device, created on first use): forked from the caller's
+// stream behind everything that is queued there (the scratch may still be in use by the call before), joined in front of k_par_finish.
+// Events are per call.  The pattern is capturable (the side stream joins the capture at the fork and leaves it at the join).
+static hipStream_t side_stream() {
+    static thread_local hipStream_t side[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+    if (!side[dev] && hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); side[dev] = nullptr; }
+    return side[dev];
 }
 
 hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used, const Work& w) {
@@ -918,6 +938,24 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                   reinterpret_cast<uint32_t*>(ws + o_nt), reinterpret_cast<uint32_t*>(ws + o_sa), sub, ws + o_mx,
                   reinterpret_cast<uint32_t*>(ws + o_mn), (uint32_t)C_NUSED, reinterpret_cast<uint32_t*>(ws + o_me),
                   a.in_pitch, a.out_pitch, a.in_off, stride, nstr > 1u ? 1u : 0u};
+        // fork: the chain for any block types on the side stream, beside this one
+        const uint32_t* actl = nullptr;
+        uint32_t apasses = 0;
+        hipEvent_t ev_join = nullptr;
+        if (L.any_bytes != 0u) {
+            hipStream_t side = side_stream();
+            hipEvent_t ev_fork = nullptr;
+            bool forked = side && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess &&
+                          hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) == hipSuccess &&
+                          hipEventRecord(ev_fork, stream) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess;
+            if (!forked) { (void)hipGetLastError(); side = stream; }
+            e = launch_inflate_any(a, nstr, ws, stride, L.o_any, o_sa, (uint32_t)srcn, (uint32_t)cap64, side, &apasses);
+            actl = reinterpret_cast<const uint32_t*>(ws + L.o_any);
+            if (forked && e == hipSuccess) e = hipEventRecord(ev_join, side);
+            if (!forked && ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
+            if (ev_fork) (void)hipEventDestroy(ev_fork);
+            if (e != hipSuccess) { if (ev_join) (void)hipEventDestroy(ev_join); const hipError_t e2 = w.put(ws, stream); (void)e2; return e; }
+        }
         hipLaunchKernelGGL(k_par_zero, dim3(1, nstr), dim3(64), 0, stream, p);
         // the same arguments at sub-piece granularity: what the real decode and the emit work on
         ParArgs pf = p;
@@ -943,15 +981,12 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         ParArgs pe = p;                                                 // the emit: pieces, reading the sub-pieces' token lists
         pe.tokens = pf.tokens; pe.ntok = pf.ntok;
         hipLaunchKernelGGL(k_par_emit, dim3(nchunks, nstr), dim3(64), 0, stream, pe);
-        for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(nchunks, nstr), dim3(64), 0, stream, p, j);
+        for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(j == 0u || nchunks < JUMP_GRID ? nchunks : JUMP_GRID, nstr), dim3(64), 0, stream, p, j);
         e = hipGetLastError();
-        // a stream that is not ONE fixed block (k_par_scan_top said so: C_NOTFIXED): the chain for any block types, behind this one --
-        // its kernels return at once otherwise -- in its own part of the scratch, with its own control words
-        const uint32_t* actl = nullptr;
-        uint32_t apasses = 0;
-        if (e == hipSuccess && L.any_bytes != 0u) {
-            e = launch_inflate_any(a, nstr, ws, stride, L.o_any, o_sa, p.ctl + C_NOTFIXED, (uint32_t)srcn, (uint32_t)cap64, stream, &apasses);
-            actl = reinterpret_cast<const uint32_t*>(ws + L.o_any);
+        // join: the verdict looks at both chains' control words
+        if (ev_join) {
+            if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev_join, 0);
+            (void)hipEventDestroy(ev_join);
         }
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_par_finish, dim3(1, nstr), dim3(64), 0, stream, p, passes, actl, apasses);
