@@ -611,6 +611,7 @@ __device__ __forceinline__ uint32_t find_rank(const uint32_t* shdr, uint32_t n, 
 // an LDS round trip instead of two dependent global loads (one lane per node straight from memory: 260 us for the ~235 pieces of a
 // 16 K-symbol block)
 constexpr uint32_t WALK_STAGE = 64;           // pieces staged at a time
+__device__ __forceinline__ void walk_node(const Args& a, const View& v, uint32_t round, uint32_t n, uint32_t i, uint32_t lane, uint32_t* smap, uint32_t* sown, Tab* ltp);
 __global__ __launch_bounds__(64) void k_any_walk(Args a, uint32_t round) {
     const View v = view(a);
     __shared__ uint32_t smap[WALK_STAGE * 64];
@@ -619,8 +620,11 @@ __global__ __launch_bounds__(64) void k_any_walk(Args a, uint32_t round) {
     if (!v.run) return;
     const uint32_t n = min(v.ctl[A_NBLK], a.maxb);
     const uint32_t lane = threadIdx.x;
-    const uint32_t i = blockIdx.x;                                    // node: candidate rank i < n, or the pseudo-node i == n (stored at index maxb)
-    if (i > n) return;
+    for (uint32_t i = blockIdx.x; i <= n; i += gridDim.x) walk_node(a, v, round, n, i, lane, smap, sown, &lt);
+}
+// node i: candidate rank i < n, or the pseudo-node i == n (stored at index maxb)
+__device__ __forceinline__ void walk_node(const Args& a, const View& v, uint32_t round, uint32_t n, uint32_t i, uint32_t lane, uint32_t* smap, uint32_t* sown, Tab* ltp) {
+    Tab& lt = *ltp;
     const uint32_t nbits = 8u * v.zn;
     const int32_t isize = (int32_t)v.zn - 1;
     const uint32_t len_mask = a.obsize ? ((1u << (31u - (uint32_t)__builtin_clz(a.obsize))) - 1u) : 0xFFFFu;     // deflate.py:329,:714
@@ -953,7 +957,7 @@ hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, 
     g.o_owner = L.o_owner; g.o_map = L.o_map; g.o_pent = L.o_pent; g.o_prel = L.o_prel; g.o_pnode = L.o_pnode; g.o_node = L.o_node;
     g.o_xitem = L.o_xitem; g.o_sitem = L.o_sitem; g.o_opos = L.o_opos; g.o_ntok = L.o_ntok; g.o_tok = L.o_tok; g.o_mext = L.o_mext;
     const uint32_t nitems = L.nchunks + L.maxx;
-    auto gx = [](uint64_t work, uint32_t cap_) { return (unsigned)(work < 1u ? 1u : work > cap_ ? cap_ : work); };
+    auto gx = [&](uint64_t work, uint32_t cap_) { const uint32_t c = par::grid_cap(work, nstr); return (unsigned)(c > cap_ ? cap_ : c); };
     hipLaunchKernelGGL(k_any_zero, dim3(1, nstr), dim3(64), 0, stream, g);
     hipLaunchKernelGGL(k_any_find, dim3(gx((a.in_len + FIND_T - 1u) / FIND_T, 4096u), nstr), dim3(FIND_T), 0, stream, g);
     hipLaunchKernelGGL(k_any_headers, dim3(gx((L.candcap + 63u) / 64u, 1280u), nstr), dim3(64), 0, stream, g);
@@ -961,10 +965,10 @@ hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, 
     hipLaunchKernelGGL(k_any_tables, dim3(gx(L.maxb + 1u, 1024u), nstr), dim3(TAB_T), 0, stream, g);
     hipLaunchKernelGGL(k_any_owner, dim3(gx(L.maxb, 1024u), nstr), dim3(64), 0, stream, g);
     hipLaunchKernelGGL(k_any_spec, dim3(gx((L.nchunks + SPEC_W - 1u) / SPEC_W, 1536u), nstr), dim3(64 * SPEC_W), 0, stream, g);
-    hipLaunchKernelGGL(k_any_walk, dim3(L.maxb + 1u, nstr), dim3(64), 0, stream, g, 0u);
+    hipLaunchKernelGGL(k_any_walk, dim3(gx(L.maxb + 1u, 8192u), nstr), dim3(64), 0, stream, g, 0u);
     for (uint32_t round = 1; round < WALK_ROUNDS; round++) {        // (return at once when no walk met a false positive)
-        hipLaunchKernelGGL(k_any_spec2, dim3(256, nstr), dim3(64 * SPEC_W), 0, stream, g, round);
-        hipLaunchKernelGGL(k_any_walk, dim3(L.maxb + 1u, nstr), dim3(64), 0, stream, g, round);
+        hipLaunchKernelGGL(k_any_spec2, dim3(gx(256u, 256u), nstr), dim3(64 * SPEC_W), 0, stream, g, round);
+        hipLaunchKernelGGL(k_any_walk, dim3(gx(L.maxb + 1u, 8192u), nstr), dim3(64), 0, stream, g, round);
     }
     hipLaunchKernelGGL(k_any_rank, dim3(1, nstr), dim3(256), 8u * (L.maxb + 1u), stream, g);
     hipLaunchKernelGGL(k_any_tokens, dim3(gx((nitems + 63u) / 64u, 8192u), nstr), dim3(64), 0, stream, g);

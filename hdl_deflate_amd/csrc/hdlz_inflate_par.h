@@ -65,6 +65,13 @@ constexpr uint32_t HOPS = 256;                // marker chain steps per pass of 
 
 // the last kernels of either chain, for the items (pieces) the arguments describe: bytes + markers, the marker passes
 hipError_t par_launch_emit_jump(const ParArgs& p, uint32_t nitems, uint32_t passes, uint32_t nstr, hipStream_t stream);
+// workgroups per stream of a grid-stride launch over `work` units: all of them for one stream, fewer per stream the more streams there are
+// (>= 32, ~2^14 workgroups per launch in all: they fill the GPU twice over, and a launch whose workgroups all turn away at the door --
+// the chain that is not the streams' -- stays cheap beside the other chain's real work)
+__host__ inline uint32_t grid_cap(uint64_t work, uint32_t nstr) {
+    const uint64_t cap = nstr <= 1u ? work : ((1u << 14) / nstr < 32u ? 32u : (1u << 14) / nstr);
+    return (uint32_t)(work < 1u ? 1u : work < cap ? work : cap);
+}
 __host__ inline uint32_t passes_for(uint32_t nitems) {                 // chains of up to `nitems` hops, HOPS-fold shorter per pass
     uint32_t passes = 1;
     for (uint64_t reach = 1; reach < (uint64_t)nitems + 1u; reach *= HOPS) passes++;

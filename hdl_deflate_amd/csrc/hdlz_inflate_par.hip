@@ -579,6 +579,7 @@ constexpr uint32_t HRING = 1024;              // (2048 with a pointer array besi
 constexpr uint32_t SPAN = 768;                // a batch ends with the token that takes its output beyond this many bytes
 constexpr uint32_t HREACH = HRING - 128u;     // distances served from the ring (it is written a 64-byte slice at a time)
 constexpr uint32_t P_RES = 0xFFu;             // in-slice pointer: the byte / marker is there
+template <bool STRIDED>
 __global__ __launch_bounds__(64) void k_par_emit(ParArgs a_) {
     const ParArgs a = of_stream(a_);
     __shared__ uint8_t hb[HRING];             // ring over the piece's output positions: byte ...
@@ -586,8 +587,13 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a_) {
     __shared__ uint32_t tI[64];               // the batch's token words
     __shared__ uint64_t bmw[17];              // token starts, one bit per byte of the batch
     __shared__ uint32_t bpre[17];             // token starts in front of each 64-byte slice
-    const uint32_t lane = threadIdx.x, c = blockIdx.x;
-    if (a.ctl[C_FALLBACK] != 0u || c >= a.ctl[C_NUSED]) return;
+    const uint32_t lane = threadIdx.x;
+    if (a.ctl[C_FALLBACK] != 0u) return;
+    const uint32_t nused_ = a.ctl[C_NUSED];
+    // (a workgroup takes the pieces blockIdx.x, + gridDim.x, ..: batches of many streams are launched with fewer workgroups per stream than
+    //  pieces -- a chain that is NOT a stream's turns every workgroup away at the door, and 1.7 million of those cost 0.7 ms beside the
+    //  other chain's real work)
+    for (uint32_t c = blockIdx.x; c < nused_; c += gridDim.x) {
     // a piece's tokens are the lists of its sub-pieces, one behind the other (the decode runs on sub-pieces; the emit does not:
     // the history in front of a wave's own output becomes markers, and with four times shorter pieces the marker passes doubled)
     const uint32_t nsub = a.sub, fnused = a.ctl[C_FNUSED];
@@ -692,6 +698,9 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a_) {
     for (int ofs = 32; ofs > 0; ofs >>= 1) mlast = max(mlast, (uint32_t)__shfl_xor((int)mlast, ofs, 64));
     if (lane == 0u) a.mext[c] = mlast > cstart ? mlast - cstart : 0u;
     if (nmark) atomicAdd(&a.ctl[C_MARK], nmark);
+    if constexpr (!STRIDED) break;                       // (one workgroup per piece: the form of single streams -- the loop cost it 60 % there)
+    __syncthreads();
+    }
 }
 
 // ---- 4. one pass of pointer jumping over the markers, IN PLACE (round 5: one marker word per output byte instead of two buffers -- half
@@ -790,8 +799,10 @@ __global__ __launch_bounds__(64) void k_par_flag_rest(uint32_t* out_len, uint32_
 }  // namespace par
 
 hipError_t par::par_launch_emit_jump(const ParArgs& p, uint32_t nitems, uint32_t passes, uint32_t nstr, hipStream_t stream) {
-    hipLaunchKernelGGL(k_par_emit, dim3(nitems, nstr), dim3(64), 0, stream, p);
-    for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(j == 0u || nitems < JUMP_GRID ? nitems : JUMP_GRID, nstr), dim3(64), 0, stream, p, j);
+    const uint32_t gx = grid_cap(nitems, nstr);
+    if (gx < nitems) hipLaunchKernelGGL(k_par_emit<true>, dim3(gx, nstr), dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL(k_par_emit<false>, dim3(gx, nstr), dim3(64), 0, stream, p);
+    for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(j == 0u || gx < JUMP_GRID ? gx : JUMP_GRID, nstr), dim3(64), 0, stream, p, j);
     return hipGetLastError();
 }
 
@@ -850,7 +861,7 @@ size_t inflate_par_work_bytes(uint32_t in_len, uint64_t nstreams, uint64_t out_p
     if (nstreams == 0 || nstreams > 65535u || in_len < HDLZ_INFLATE_PAR_MIN) return 0;
     const par::Layout L = par::layout_of(in_len, (uint32_t)nstreams, out_pitch, flags);
     if (!L.ok) return 0;
-    constexpr size_t BUDGET = (size_t)4 << 30;
+    constexpr size_t BUDGET = (size_t)8 << 30;
     const size_t all = L.stride * (size_t)nstreams;
     return all > BUDGET && nstreams > 1 ? (BUDGET / L.stride ? (BUDGET / L.stride) * L.stride : L.stride) : all;
 }
@@ -886,7 +897,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     // more scratch than the budget (4 GiB from the library's pool; the caller's buffer otherwise): the batch goes through in groups of
     // streams, one chain of launches each (its scratch is the one the group in front of it used: the launches are stream-ordered).
     // NOTE the piece size follows the group's bytes, so a group is laid out again by the recursive call.
-    const size_t BUDGET = w.caller ? w.bytes : (size_t)4 << 30;
+    const size_t BUDGET = w.caller ? w.bytes : (size_t)8 << 30;
     if (stride > BUDGET) return hipSuccess;                     // not even one stream: the caller's other paths
     if (nstr > 1u && stride * (size_t)nstr > BUDGET) {
         uint32_t gs = (uint32_t)(BUDGET / stride);
@@ -980,7 +991,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         else hipLaunchKernelGGL(k_par_tokens<false>, dim3((pf.nchunks + 63u) / 64u, nstr), dim3(64), 0, stream, pf);
         ParArgs pe = p;                                                 // the emit: pieces, reading the sub-pieces' token lists
         pe.tokens = pf.tokens; pe.ntok = pf.ntok;
-        hipLaunchKernelGGL(k_par_emit, dim3(nchunks, nstr), dim3(64), 0, stream, pe);
+        hipLaunchKernelGGL(k_par_emit<false>, dim3(nchunks, nstr), dim3(64), 0, stream, pe);
         for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(j == 0u || nchunks < JUMP_GRID ? nchunks : JUMP_GRID, nstr), dim3(64), 0, stream, p, j);
         e = hipGetLastError();
         // join: the verdict looks at both chains' control words

@@ -58,7 +58,7 @@ def test_no_cpu_fallback_without_gpu():
     assert 8 << 20 <= lanes <= 9 << 20
     one = L.hdlz_inflate_work_bytes(1, 1 << 24, 1 << 26, 0, 0)            # ONE 16 MiB stream: the whole-GPU path's markers and lists
     assert one >= 1 << 26 and L.hdlz_inflate_work_bytes(1, 1 << 24, 1 << 26, 2, 0) < 1 << 16      # (a mapping hint keeps the batch kernels)
-    assert L.hdlz_inflate_work_bytes(4096, 1 << 20, 1 << 22, 0, 0) <= (4 << 30) + (1 << 20)         # a batch: bounded by the 4 GiB budget
+    assert L.hdlz_inflate_work_bytes(4096, 1 << 20, 1 << 22, 0, 0) <= (8 << 30) + (1 << 20)         # a batch: bounded by the 8 GiB budget
     assert L.hdlz_inflate_batch_ws(buf, None, 64, 64, 1, 0, 0, buf, 64, buf, buf, None, 0, None) == E_HIP
     assert L.hdlz_inflate_batch_ws(buf, None, 64, 64, 1, 16, 0, buf, 64, buf, buf, None, 0, None) == E_BAD_PARAM      # flags 16 / 32 left with round 6
     try:
