@@ -377,6 +377,14 @@ def main_single(a):
         d_in = make_text_blocks(B, n, dev, seed=0)
     else:
         d_in = make_blocks(B, n, dev, seed=0)
+    if a.shuffle:
+        # (VERDICT r5 #6b) the same blocks in a seeded random ORDER: the families no longer alternate with period 4, so a wave's blocks
+        # -- it strides over the batch -- are a mix of families instead of one
+        g = torch.Generator(device="cpu")
+        g.manual_seed(a.shuffle)
+        perm = torch.randperm(B, generator=g).to(dev)
+        d_in = d_in[perm].contiguous()
+        del perm
     torch.cuda.synchronize()
     r = run_compress(torch, eng, d_in, a.cwindow, a.maxmatch, a.steps, a.warmup, a.verify)
 
@@ -403,7 +411,7 @@ def main_single(a):
         "ms_per_step": round(r["dt"] / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[1]: %d x %d B blocks, families 1-4 (test_deflate.py:38-66), "
-                                "distinct blocks, HBM-resident" % (B, n)) if a.data == "families" else
+                                "distinct blocks, HBM-resident%s" % (B, n, ", block order shuffled (seed %d)" % a.shuffle if a.shuffle else "")) if a.data == "families" else
                                ("%d x %d B blocks of Zipf pseudo-English (enwik8 stand-in), HBM-resident" % (B, n)),
                    "cwindow": a.cwindow, "maxmatch": a.maxmatch, "blocks_per_gpu": B, "block_bytes": n,
                    "parallelism": "single GPU; --gpus N block-shards BASELINE configs[4] (8 GiB of 64 KiB blocks) over N ranks"},
@@ -1019,6 +1027,7 @@ def main():
                     help="N=1: skip the PCIe-inclusive measurement of the headline job (SURVEY 8(d) Timing)")
     ap.add_argument("--no-t1", dest="t1", action="store_false",
                     help="N>1: do not run the whole job on rank 0 first (T1_ms / speedup_vs_T1 are then absent)")
+    ap.add_argument("--shuffle", type=int, default=0, help="N=1 headline: the blocks in a seeded random order (0 = the order of BASELINE configs[1])")
     ap.add_argument("--detail", default=DETAIL_DEFAULT,
                     help="file that receives the FULL result (notes, configs, every sub-measurement); the printed line names it ('' = none)")
     a = ap.parse_args()

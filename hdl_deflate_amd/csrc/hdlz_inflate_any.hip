@@ -60,7 +60,7 @@ constexpr uint32_t NO_OWNER = 0xFFFFu;
 constexpr uint32_t N_END = 0xFFFFFFFEu, N_BAD = 0xFFFFFFFFu;      // successor of a node: the stream ends / no valid successor
 enum { A_NCAND = par::C_ANY0, A_NBLK, A_NX, A_NS, A_OVER, A_WHY, A_NREQ, A_NREQP };       // this chain's counters in its control words; A_WHY: bits of W_* (diagnostics)
 enum { W_OVER = 1, W_NODE = 2, W_NEXT = 4, W_CAP = 8, W_CYCLE = 16, W_ITEMS = 32, W_TOKEN = 64, W_TCAP = 128, W_WALK_OWNER = 256, W_WALK_MAP = 512,
-       W_WALK_HDR = 1024, W_WALK_STORED = 2048, W_WALK_FIX = 4096, W_WALK_TOK = 8192 };
+       W_WALK_HDR = 1024, W_WALK_STORED = 2048, W_WALK_FIX = 4096, W_WALK_TOK = 8192, W_VERIFY = 16384 };
 
 // decode tables of one block (global memory; a wave of k_any_spec copies its owner's into LDS)
 struct __attribute__((aligned(256))) Tab {
@@ -74,7 +74,8 @@ static_assert(sizeof(Tab) % 256 == 0, "tables are copied in 16-byte words");
 
 struct Blk { uint32_t hdr, pay, fin, nlen; };                         // a candidate: header bit, first payload bit, BFINAL, HLIT + 257
 struct Node { uint32_t next, nbytes, ok, obase; };                    // result of its walk; obase: k_any_rank
-struct XItem { uint32_t start, limit, rel, node_slot; };              // an extra decode item: bits [start, limit), rel = bytes of its node in front; node | slot << 16
+struct XItem { uint32_t start, limit, rel, node_slot, endpos, nbytes; };      // an extra decode item: bits [start, limit), rel = bytes of its node in front; node | slot << 16;
+                                                                      // endpos / nbytes: where the walk says it ends and what it makes (k_any_tokens checks both)
 struct SItem { uint32_t src, len, rel, node; };                       // a stored block: `len` bytes from stream byte `src`
 // A block whose walk meets pieces that were decoded for ANOTHER candidate -- a false positive inside it: a header-like bit pattern, ~1 per
 // 4 MB of compressed data, almost always a degenerate code of two or three symbols -- asks for those pieces to be decoded with its own
@@ -96,7 +97,7 @@ struct Args {
     uint32_t* srcA;               // stream 0's marker words
     uint32_t nchunks, candcap, maxb, maxx, maxs, tcap, maxreq, mapcap;
     size_t o_cand, o_blk, o_blen, o_shdr, o_spay, o_sidx, o_tab, o_owner, o_map, o_pent, o_prel, o_pnode, o_node, o_xitem, o_sitem,
-           o_opos, o_ntok, o_tok, o_mext, o_req, o_map2, o_nstate;
+           o_opos, o_ntok, o_tok, o_mext, o_req, o_map2, o_nstate, o_cpos, o_cres, o_nch, o_pmap;
 };
 // one stream's view
 struct View {
@@ -107,7 +108,7 @@ struct View {
     bool run;                     // the gate is open and nothing has failed so far
     uint32_t* cand; Blk* blk; uint8_t* blen; uint32_t* shdr; uint32_t* spay; uint32_t* sidx; Tab* tab; uint16_t* owner; uint32_t* map;
     uint8_t* pent; uint32_t* prel; uint16_t* pnode; Node* node; XItem* xitem; SItem* sitem; uint32_t* opos; uint32_t* ntok; uint32_t* tok;
-    uint32_t* mext; uint32_t* srcA; Req* req; uint32_t* map2; NState* nstate;
+    uint32_t* mext; uint32_t* srcA; Req* req; uint32_t* map2; NState* nstate; uint32_t* cpos; uint32_t* cres; uint8_t* nch; uint32_t* pmap;
 };
 template <typename T> __device__ __forceinline__ T* at(uint8_t* base, size_t off) { return reinterpret_cast<T*>(base + off); }
 __device__ __forceinline__ View view(const Args& a) {
@@ -131,6 +132,7 @@ __device__ __forceinline__ View view(const Args& a) {
     v.node = at<Node>(w, a.o_node); v.xitem = at<XItem>(w, a.o_xitem); v.sitem = at<SItem>(w, a.o_sitem); v.opos = at<uint32_t>(w, a.o_opos);
     v.ntok = at<uint32_t>(w, a.o_ntok); v.tok = at<uint32_t>(w, a.o_tok); v.mext = at<uint32_t>(w, a.o_mext);
     v.req = at<Req>(w, a.o_req); v.map2 = at<uint32_t>(w, a.o_map2); v.nstate = at<NState>(w, a.o_nstate);
+    v.cpos = at<uint32_t>(w, a.o_cpos); v.cres = at<uint32_t>(w, a.o_cres); v.nch = at<uint8_t>(w, a.o_nch); v.pmap = at<uint32_t>(w, a.o_pmap);
     v.srcA = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(a.srcA) + (size_t)s * a.stride);
     return v;
 }
@@ -525,47 +527,67 @@ __device__ __forceinline__ void load_tab(Tab* dst_, const Tab* src_, uint32_t la
 #pragma unroll
     for (uint32_t k = 0; k < sizeof(Tab) / 1024u; k++) dst[k * 64u + lane] = t[k];
 }
-// piece q with the tables at t (LDS), one wave: lane e starts at the piece's bit e -> mp[e]
-__device__ __forceinline__ void spec_piece(const View& v, const Tab* t, uint32_t* win, uint32_t q, uint32_t* mp, uint32_t lane) {
-    const uint32_t b0 = q * PB, end = b0 + PB;
-    for (uint32_t k = lane; k < PB / 32u + 8u; k += 64u) win[k] = tok::load32(v.z, (b0 >> 3) + 4u * k, v.zn);
+// one token of a chain, lengths and byte counts only (x: the next 64 stream bits).  -> false when the chain ends here: res = the map
+// entry (end-of-block: kind 2, the bit behind the code relative to b0; no code: kind 3)
+__device__ __forceinline__ bool spec_step(const Tab* t, uint64_t x, uint32_t b0, uint32_t& pos, uint32_t& nbytes, uint32_t& res) {
+    uint32_t sym, len;
+    sym_of<LB, 9u, 511u>(t->ll, t->lfirst, t->lcnt, t->loff, t->lsym, (uint32_t)x, sym, len);
+    if (len == 0u) { res = 3u << 30; return false; }
+    if (sym < 256u) { pos += len; nbytes += 1u; return true; }
+    if (sym == 256u) { res = (2u << 30) | ((pos + len - b0) << 19) | nbytes; return false; }
+    uint32_t lbase, leb, ds, dl;
+    tok::length_info(sym - 257u, lbase, leb);
+    const uint64_t x1 = x >> len;
+    const uint32_t tl = lbase + ((uint32_t)x1 & ((1u << leb) - 1u));
+    sym_of<DB, 5u, 31u>(t->dd, t->dfirst, t->dcnt, t->doff, t->dsym, (uint32_t)(x1 >> leb), ds, dl);
+    if (dl == 0u) { res = 3u << 30; return false; }
+    const uint32_t deb = ds < 4u ? 0u : (ds >> 1) - 1u;
+    pos += len + leb + dl + deb;
+    nbytes += tl;
+    if (nbytes >= (1u << 19)) { res = 3u << 30; return false; }       // (cannot happen: 512 tokens of 258 bytes)
+    return true;
+}
+__device__ __forceinline__ void stage_piece(const View& v, uint32_t* win, uint32_t q, uint32_t lane) {
+    for (uint32_t k = lane; k < PB / 32u + 8u; k += 64u) win[k] = tok::load32(v.z, ((q * PB) >> 3) + 4u * k, v.zn);
     wave_lds_order();
     __builtin_amdgcn_wave_barrier();
-    uint32_t pos = b0 + lane, nbytes = 0, res = 0;
-    bool run = true;
+}
+__device__ __forceinline__ uint64_t win_bits(const uint32_t* win, uint32_t rel) {
+    const uint32_t w = rel >> 5, sh = rel & 31u;
+    const uint32_t d0 = win[w], d1 = win[w + 1u], d2 = win[w + 2u];
+    return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+}
+// the chains of all lanes from where they stand to the end of the piece -> res
+__device__ __forceinline__ void spec_finish(const Tab* t, const uint32_t* win, uint32_t b0, uint32_t& pos, uint32_t& nbytes, uint32_t& res, bool& run) {
+    const uint32_t end = b0 + PB;
     while (ballot64(run) != 0ull) {
         if (run) {
-            const uint32_t rel = pos - b0, w = rel >> 5, sh = rel & 31u;
-            const uint32_t d0 = win[w], d1 = win[w + 1u], d2 = win[w + 2u];
-            const uint64_t x = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
-            uint32_t sym, len;
-            sym_of<LB, 9u, 511u>(t->ll, t->lfirst, t->lcnt, t->loff, t->lsym, (uint32_t)x, sym, len);
-            if (len == 0u) { res = 3u << 30; run = false; }
-            else if (sym < 256u) { pos += len; nbytes += 1u; }
-            else if (sym == 256u) { res = (2u << 30) | ((pos + len - b0) << 19) | nbytes; run = false; }
-            else {
-                uint32_t lbase, leb, ds, dl;
-                tok::length_info(sym - 257u, lbase, leb);
-                const uint64_t x1 = x >> len;
-                const uint32_t tl = lbase + ((uint32_t)x1 & ((1u << leb) - 1u));
-                sym_of<DB, 5u, 31u>(t->dd, t->dfirst, t->dcnt, t->doff, t->dsym, (uint32_t)(x1 >> leb), ds, dl);
-                if (dl == 0u) { res = 3u << 30; run = false; }
-                else {
-                    const uint32_t deb = ds < 4u ? 0u : (ds >> 1) - 1u;
-                    pos += len + leb + dl + deb;
-                    nbytes += tl;
-                }
-            }
+            run = spec_step(t, win_bits(win, pos - b0), b0, pos, nbytes, res);
             if (run && pos >= end) { res = ((pos - end) << 19) | nbytes; run = false; }
-            if (nbytes >= (1u << 19)) { res = 3u << 30; run = false; }       // (cannot happen: 512 tokens of 258 bytes)
         }
     }
+}
+// piece q with the tables at t (LDS), one wave: lane e starts at the piece's bit e -> mp[e]
+__device__ __forceinline__ void spec_piece(const View& v, const Tab* t, uint32_t* win, uint32_t q, uint32_t* mp, uint32_t lane) {
+    const uint32_t b0 = q * PB;
+    stage_piece(v, win, q, lane);
+    uint32_t pos = b0 + lane, nbytes = 0, res = 0;
+    bool run = true;
+    spec_finish(t, win, b0, pos, nbytes, res, run);
     mp[lane] = res;
     __builtin_amdgcn_wave_barrier();
 }
+// ---- the maps with the 64-fold work only where it is needed (as k_par_head / _tail / _resolve do for the fixed code): chains that start
+// at different offsets of a piece fall into step at the first token boundary they share and are ONE chain from there on.
+//   k_any_spec     all 64 offsets of a piece decode its first HEAD bits only; the lanes that stand at the same bit afterwards are one
+//                  chain: up to CH_MAX of them per piece are listed (more -- a period of a few tokens -- : the wave decodes the piece
+//                  to its end right here);  a lane's entry: final, or kind 1 = pending: chain rank << 19 | bytes of the head
+//   k_any_tail     one LANE per listed chain decodes the rest of its piece;   k_any_resolve: pending entries take their chain's result
+constexpr uint32_t HEAD = 256, CH_MAX = 8;
 __global__ __launch_bounds__(64 * SPEC_W) void k_any_spec(Args a) {
     const View v = view(a);
     __shared__ SpecLds L;
+    __shared__ uint32_t first[SPEC_W][64], slotof[SPEC_W][64];
     if (!v.run) return;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t nw = gridDim.x * SPEC_W, g = blockIdx.x * SPEC_W + wv;
@@ -574,9 +596,101 @@ __global__ __launch_bounds__(64 * SPEC_W) void k_any_spec(Args a) {
     uint32_t cur = NO_OWNER;
     for (uint32_t q = q0; q < q1; q++) {
         const uint32_t r = v.owner[q];
-        if (r == NO_OWNER) continue;
+        if (r == NO_OWNER) { if (lane == 0u) v.nch[q] = 0; continue; }
         if (r != cur) { load_tab(&L.t[wv], &v.tab[r], lane); cur = r; }
-        spec_piece(v, &L.t[wv], L.win[wv], q, v.map + (size_t)q * 64u, lane);
+        const Tab* t = &L.t[wv];
+        const uint32_t* win = L.win[wv];
+        const uint32_t b0 = q * PB, hb = b0 + HEAD;
+        stage_piece(v, L.win[wv], q, lane);
+        first[wv][lane] = 0xFFFFFFFFu;
+        uint32_t pos = b0 + lane, nbytes = 0, res = 0;
+        bool run = true;
+        while (ballot64(run && pos < hb) != 0ull) {
+            if (run && pos < hb) run = spec_step(t, win_bits(win, pos - b0), b0, pos, nbytes, res);
+        }
+        wave_lds_order();
+        const uint32_t key = (pos - hb) & 63u;                   // (a token is at most 48 bits long)
+        if (run) atomicMin(&first[wv][key], lane);
+        wave_lds_order();
+        __builtin_amdgcn_wave_barrier();
+        const bool leader = run && first[wv][key] == lane;
+        const uint64_t lm = ballot64(leader);
+        const uint32_t nlead = (uint32_t)__popcll(lm);
+        if (nlead > CH_MAX) {                                    // (rare) too many distinct chains: to the end, here
+            spec_finish(t, win, b0, pos, nbytes, res, run);
+            if (lane == 0u) v.nch[q] = 0;
+        } else {
+            if (leader) {
+                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                slotof[wv][key] = rk;
+                v.cpos[(size_t)q * CH_MAX + rk] = pos;
+            }
+            wave_lds_order();
+            __builtin_amdgcn_wave_barrier();
+            if (run) res = (1u << 30) | (slotof[wv][key] << 19) | nbytes;
+            if (lane == 0u) v.nch[q] = (uint8_t)nlead;
+        }
+        v.map[(size_t)q * 64u + lane] = res;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+__global__ __launch_bounds__(64) void k_any_tail(Args a) {
+    const View v = view(a);
+    __shared__ Tab lt;
+    if (!v.run) return;
+    const uint32_t lane = threadIdx.x;
+    uint32_t cur = NO_OWNER;
+    for (uint32_t c0 = blockIdx.x * 64u; c0 < a.nchunks * CH_MAX; c0 += gridDim.x * 64u) {
+        const uint32_t c = c0 + lane, q = c / CH_MAX, rk = c % CH_MAX;
+        const bool have = q < a.nchunks && rk < v.nch[q];
+        const uint32_t r = have ? (uint32_t)v.owner[q] : NO_OWNER;
+        const uint64_t hm = ballot64(have);
+        if (hm == 0ull) continue;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)__builtin_ctzll(hm));
+        const bool uniform = ballot64(have && r != r0) == 0ull;       // (8 consecutive pieces: almost always one block)
+        if (uniform && r0 != cur) {
+            __builtin_amdgcn_wave_barrier();
+            load_tab(&lt, &v.tab[r0], lane);
+            wave_lds_order();
+            __builtin_amdgcn_wave_barrier();
+            cur = r0;
+        }
+        const uint32_t b0 = q * PB, end = b0 + PB;
+        Bits rd;
+        rd.init(v.z, v.zn, have ? v.cpos[c] : 16u);
+        uint32_t pos = rd.pos, nbytes = 0, res = 0;
+        bool run = have;
+        auto go = [&](const Tab* t) {
+            while (run) {
+                // (a token is at most 48 bits: the buffer's >= 33 bits + the dword behind it make the 64-bit window whole)
+                rd.refill();
+                const uint64_t x = rd.bc < 64u ? (rd.bb | ((uint64_t)rd.n0 << rd.bc)) : rd.bb;
+                const uint32_t p0 = pos;
+                run = spec_step(t, x, b0, pos, nbytes, res);
+                if (run) {
+                    uint32_t used = pos - p0;                    // (up to 48 bits, the buffer holds >= 33: in two steps)
+                    rd.pos = p0;
+                    if (used > 32u) { rd.take(32u); rd.refill(); used -= 32u; }
+                    rd.take(used);
+                    if (pos >= end) { res = ((pos - end) << 19) | nbytes; run = false; }
+                }
+            }
+        };
+        if (uniform) go(&lt);
+        else if (have) go(&v.tab[r]);
+        if (have) v.cres[c] = res;
+    }
+}
+__global__ __launch_bounds__(256) void k_any_resolve(Args a) {
+    const View v = view(a);
+    if (!v.run) return;
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < a.nchunks * 64u; t += gridDim.x * 256u) {
+        const uint32_t q = t >> 6;
+        if (v.owner[q] == NO_OWNER) continue;
+        const uint32_t m = v.map[t];
+        if ((m >> 30) != 1u) continue;
+        const uint32_t c = v.cres[(size_t)q * CH_MAX + ((m >> 19) & 7u)], nb = (m & 0x7FFFFu) + (c & 0x7FFFFu);
+        v.map[t] = nb >= (1u << 19) ? (3u << 30) : ((c & 0xFFF80000u) | nb);
     }
 }
 // the pieces the walks of round `round` - 1 asked for, with the asking candidate's tables
@@ -639,9 +753,10 @@ __device__ __forceinline__ void walk_node(const Args& a, const View& v, uint32_t
         if (lane == 0u) k = atomicAdd(ctr, by);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
     };
-    auto add_xitem = [&](uint32_t start, uint32_t limit, uint32_t slot) {
+    // (endpos / made: where the item ends and the bytes it makes, as the walk knows them)
+    auto add_xitem = [&](uint32_t start, uint32_t limit, uint32_t slot, uint64_t nb0, uint32_t endpos, uint32_t made) {
         const uint32_t k = bump(&v.ctl[A_NX], 1u);
-        if (k < a.maxx) { if (lane == 0u) v.xitem[k] = XItem{start, limit, (uint32_t)nb, node_id | (slot << 16)}; }
+        if (k < a.maxx) { if (lane == 0u) v.xitem[k] = XItem{start, limit, (uint32_t)nb0, node_id | (slot << 16), endpos, made}; }
         else { if (lane == 0u) v.ctl[A_OVER] = 1u; ok = false; }
     };
     // bits [rd.pos, limit) with the tables of `slot`, counting bytes; -> true at the end-of-block code (consumed)
@@ -664,11 +779,11 @@ __device__ __forceinline__ void walk_node(const Args& a, const View& v, uint32_t
             q = b.pay / PB;
             if (b.pay % PB != 0u) {                                   // the first, partial piece: decoded here
                 const uint32_t limit = (q + 1u) * PB;
-                add_xitem(b.pay, limit, i);
                 load_tab(&lt, &v.tab[i], lane);
                 wave_lds_order();
                 __builtin_amdgcn_wave_barrier();
                 run_to(&lt, limit, eob);
+                add_xitem(b.pay, limit, i, 0u, rd.pos, (uint32_t)nb);
                 q++;
             }
             pos = rd.pos;
@@ -702,10 +817,11 @@ __device__ __forceinline__ void walk_node(const Args& a, const View& v, uint32_t
             const uint32_t own = sown[q - sq0];
             if (own == i) {
                 m = smap[(q - sq0) * 64u + e];
-                if (lane == 0u) { v.pent[q] = (uint8_t)e; v.prel[q] = (uint32_t)nb; v.pnode[q] = (uint16_t)i; }
+                if (lane == 0u) { v.pent[q] = (uint8_t)e; v.prel[q] = (uint32_t)nb; v.pnode[q] = (uint16_t)i; v.pmap[q] = m; }
             } else if (q >= rq0 && q < rq1) {                         // a piece decoded for this block on request: an item of its own
                 m = v.map2[(size_t)(rslot + (q - rq0)) * 64u + e];
-                add_xitem(q * PB + e, (q + 1u) * PB, i);
+                const uint32_t k_ = m >> 30, o_ = (m >> 19) & 2047u;
+                add_xitem(q * PB + e, (q + 1u) * PB, i, nb, k_ == 0u ? (q + 1u) * PB + o_ : q * PB + o_, m & 0x7FFFFu);
             } else {
                 // decoded for another candidate (a false positive inside this block, if this block is a true one): ask for the pieces up
                 // to the next candidate behind that one with this block's tables, go on in the next round
@@ -766,10 +882,11 @@ __device__ __forceinline__ void walk_node(const Args& a, const View& v, uint32_t
             wave_lds_order();
             __builtin_amdgcn_wave_barrier();
             while (ok && !eob) {
-                const uint32_t limit = (rd.pos / PB + 1u) * PB;
+                const uint32_t limit = (rd.pos / PB + 1u) * PB, st0 = rd.pos;
                 if (rd.pos >= stop) { ok = false; why |= W_WALK_FIX; break; }
-                add_xitem(rd.pos, limit, a.maxb);
+                const uint64_t nb0 = nb;
                 run_to(&lt, limit, eob);
+                add_xitem(st0, limit, a.maxb, nb0, rd.pos, (uint32_t)(nb - nb0));
             }
             ebit = rd.pos;
         }
@@ -801,7 +918,11 @@ __global__ __launch_bounds__(256) void k_any_rank(Args a) {
         Node* nd = &v.node[cur < n ? cur : a.maxb];
         nd->obase = (uint32_t)acc; nd->ok = 2u;
         acc += by;
-        if (acc > (uint64_t)a.cap || acc > (uint64_t)a.srcn) { good = false; atomicOr(&v.ctl[A_WHY], (uint32_t)W_CAP); break; }
+        if (acc > (uint64_t)a.cap || acc > (uint64_t)a.srcn) {
+            good = false; atomicOr(&v.ctl[A_WHY], (uint32_t)W_CAP);
+            v.ctl[A_NREQP + 1] = cur; v.ctl[A_NREQP + 2] = (uint32_t)acc; v.ctl[A_NREQP + 3] = by; v.ctl[A_NREQP + 4] = steps; v.ctl[A_NREQP + 5] = a.cap; v.ctl[A_NREQP + 6] = a.srcn;
+            break;
+        }
         if (nx == N_END) break;
         cur = nx;
         if (cur >= n || ++steps > n + 1u) { good = false; atomicOr(&v.ctl[A_WHY], (uint32_t)W_CYCLE); break; }
@@ -831,15 +952,21 @@ __global__ __launch_bounds__(64) void k_any_tokens(Args a) {
     uint32_t cur = 0xFFFFFFFFu;
     for (uint32_t i0 = blockIdx.x * 64u; i0 < nitems; i0 += gridDim.x * 64u) {
         const uint32_t i = i0 + lane;
-        uint32_t start = 0, limit = 0, rel = 0, nid = NO_OWNER, slot = 0;
+        uint32_t start = 0, limit = 0, rel = 0, nid = NO_OWNER, slot = 0, want_end = 0, want_made = 0;
         bool have = i < nitems;
         if (have) {
             if (i < a.nchunks) {
                 nid = v.pnode[i];
-                if (nid != NO_OWNER) { start = i * PB + v.pent[i]; limit = (i + 1u) * PB; rel = v.prel[i]; slot = nid; }
+                if (nid != NO_OWNER) {
+                    start = i * PB + v.pent[i]; limit = (i + 1u) * PB; rel = v.prel[i]; slot = nid;
+                    const uint32_t m = v.pmap[i];
+                    want_made = m & 0x7FFFFu;
+                    want_end = (m >> 30) == 0u ? limit + ((m >> 19) & 2047u) : i * PB + ((m >> 19) & 2047u);
+                }
             } else {
                 const XItem x = v.xitem[i - a.nchunks];
                 start = x.start; limit = x.limit; rel = x.rel; nid = x.node_slot & 0xFFFFu; slot = x.node_slot >> 16;
+                want_end = x.endpos; want_made = x.nbytes;
             }
         }
         Node nd = Node{0u, 0u, 0u, 0u};
@@ -856,7 +983,7 @@ __global__ __launch_bounds__(64) void k_any_tokens(Args a) {
             __builtin_amdgcn_wave_barrier();
             cur = s0;
         }
-        uint32_t P = nd.obase + rel, nt = 0;
+        uint32_t P = nd.obase + rel, nt = 0, icur = i;
         uint32_t* tk = v.tok + (size_t)i * a.tcap;
         if (have) v.opos[i] = P;
         Bits rd;
@@ -870,7 +997,19 @@ __global__ __launch_bounds__(64) void k_any_tokens(Args a) {
                 const uint32_t made = k.kind == 0u ? 1u : k.length;
                 f |= (uint64_t)P + made > a.cap;
                 f |= k.kind == 1u && (k.dist > P || k.dist > obsize || (int32_t)((p0 + k.used) >> 3) >= isize - 2);     // D8; COPY hold (:1600)
-                if (nt >= a.tcap) { f = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_TCAP); }
+                if (!f && nt >= a.tcap) {
+                    // the list is full (tokens of two or three bits: long runs): the rest of the item goes on as an item of its own -- the
+                    // emit takes items in any order, each with its own position
+                    const uint32_t k2 = atomicAdd(&v.ctl[A_NX], 1u);
+                    if (k2 >= a.maxx) { f = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_TCAP); }
+                    else {
+                        v.ntok[icur] = nt;
+                        icur = a.nchunks + k2; nt = 0;
+                        tk = v.tok + (size_t)icur * a.tcap;
+                        v.opos[icur] = P;
+                        atomicMax(&v.ctl[C_NUSED], icur + 1u); atomicMax(&v.ctl[C_FNUSED], icur + 1u);
+                    }
+                }
                 if (f) { bad = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_TOKEN); break; }
                 tk[nt++] = k.kind == 0u ? (TOK_LIT | k.lit) : (k.length | (k.dist << 9));
                 P += made;
@@ -878,7 +1017,10 @@ __global__ __launch_bounds__(64) void k_any_tokens(Args a) {
         };
         if (uniform) decode(&lt);
         else decode(&v.tab[slot]);
-        if (have) v.ntok[i] = nt;
+        // the item must end where the walk -- the speculative maps -- said it would, with the bytes it said: whatever goes wrong in the
+        // speculation can cost the fallback, never a wrong byte
+        if (have && !bad && (rd.pos != want_end || P - (nd.obase + rel) != want_made)) { bad = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_VERIFY); }
+        if (have) v.ntok[icur] = nt;
     }
     if (ballot64(bad) != 0ull && lane == 0u) give_up(v);
 }
@@ -906,19 +1048,19 @@ constexpr uint32_t ANY_MIN = 16384;           // streams below this stay with th
 struct Lay {
     uint32_t nchunks, candcap, maxb, maxx, maxs, tcap, maxreq, mapcap;
     size_t o_cand, o_blk, o_blen, o_shdr, o_spay, o_sidx, o_tab, o_owner, o_map, o_pent, o_prel, o_pnode, o_node, o_xitem, o_sitem,
-           o_opos, o_ntok, o_tok, o_mext, o_req, o_map2, o_nstate, bytes;
+           o_opos, o_ntok, o_tok, o_mext, o_req, o_map2, o_nstate, o_cpos, o_cres, o_nch, o_pmap, bytes;
 };
 static Lay lay_of(uint32_t zn) {
     Lay L;
     memset(&L, 0, sizeof(L));
     const uint64_t nbits = 8ull * zn;
     L.nchunks = (uint32_t)((nbits + PB - 1u) / PB);
-    L.candcap = (uint32_t)(nbits / 512u) + 1024u;
-    L.maxb = zn / 2048u < 64u ? 64u : zn / 2048u > 4096u ? 4096u : zn / 2048u;
+    L.candcap = (uint32_t)(nbits / 128u) + 1024u;                   // (0.085 % of arbitrary bit positions pass k_any_find; periodic streams far more)
+    L.maxb = zn / 1024u < 64u ? 64u : zn / 1024u > 8000u ? 8000u : zn / 1024u;      // (zlib's blocks hold 16 K symbols, ~20 KB; small memLevels and flushes make many small ones)
     L.maxreq = 2u * L.maxb;
     L.mapcap = L.nchunks / 16u + 1024u;                             // pieces decoded a second time, on request (false positives: ~one per 4 MB, ~120 pieces each)
     L.maxx = 2u * L.maxb + 256u + L.mapcap;                         // (every such piece is an extra item; + a partial piece per block, + the fixed blocks' pieces)
-    L.maxs = zn / 4096u + 256u;
+    L.maxs = zn / 512u + 256u;
     L.tcap = 256u;
     size_t off = 256;                                               // the control words in front
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
@@ -930,6 +1072,7 @@ static Lay lay_of(uint32_t zn) {
     L.o_node = take(sizeof(Node) * ((size_t)L.maxb + 1u)); L.o_xitem = take(sizeof(XItem) * L.maxx); L.o_sitem = take(sizeof(SItem) * L.maxs);
     L.o_opos = take(4u * items); L.o_ntok = take(4u * items); L.o_tok = take(4u * (size_t)L.tcap * items); L.o_mext = take(4u * items);
     L.o_req = take(sizeof(Req) * L.maxreq); L.o_map2 = take(256u * (size_t)L.mapcap); L.o_nstate = take(sizeof(NState) * L.maxb);
+    L.o_cpos = take(4u * 8u * (size_t)L.nchunks); L.o_cres = take(4u * 8u * (size_t)L.nchunks); L.o_nch = take(L.nchunks); L.o_pmap = take(4u * (size_t)L.nchunks);
     L.bytes = off;
     return L;
 }
@@ -953,6 +1096,7 @@ hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, 
     g.ws = ws + ws_off; g.stride = ws_stride; g.srcA = reinterpret_cast<uint32_t*>(ws + sa_off);
     g.nchunks = L.nchunks; g.candcap = L.candcap; g.maxb = L.maxb; g.maxx = L.maxx; g.maxs = L.maxs; g.tcap = L.tcap;
     g.maxreq = L.maxreq; g.mapcap = L.mapcap; g.o_req = L.o_req; g.o_map2 = L.o_map2; g.o_nstate = L.o_nstate;
+    g.o_cpos = L.o_cpos; g.o_cres = L.o_cres; g.o_nch = L.o_nch; g.o_pmap = L.o_pmap;
     g.o_cand = L.o_cand; g.o_blk = L.o_blk; g.o_blen = L.o_blen; g.o_shdr = L.o_shdr; g.o_spay = L.o_spay; g.o_sidx = L.o_sidx; g.o_tab = L.o_tab;
     g.o_owner = L.o_owner; g.o_map = L.o_map; g.o_pent = L.o_pent; g.o_prel = L.o_prel; g.o_pnode = L.o_pnode; g.o_node = L.o_node;
     g.o_xitem = L.o_xitem; g.o_sitem = L.o_sitem; g.o_opos = L.o_opos; g.o_ntok = L.o_ntok; g.o_tok = L.o_tok; g.o_mext = L.o_mext;
@@ -965,6 +1109,8 @@ hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, 
     hipLaunchKernelGGL(k_any_tables, dim3(gx(L.maxb + 1u, 1024u), nstr), dim3(TAB_T), 0, stream, g);
     hipLaunchKernelGGL(k_any_owner, dim3(gx(L.maxb, 1024u), nstr), dim3(64), 0, stream, g);
     hipLaunchKernelGGL(k_any_spec, dim3(gx((L.nchunks + SPEC_W - 1u) / SPEC_W, 1536u), nstr), dim3(64 * SPEC_W), 0, stream, g);
+    hipLaunchKernelGGL(k_any_tail, dim3(gx(((size_t)L.nchunks * CH_MAX + 63u) / 64u, 8192u), nstr), dim3(64), 0, stream, g);
+    hipLaunchKernelGGL(k_any_resolve, dim3(gx(((size_t)L.nchunks * 64u + 255u) / 256u, 4096u), nstr), dim3(256), 0, stream, g);
     hipLaunchKernelGGL(k_any_walk, dim3(gx(L.maxb + 1u, 8192u), nstr), dim3(64), 0, stream, g, 0u);
     for (uint32_t round = 1; round < WALK_ROUNDS; round++) {        // (return at once when no walk met a false positive)
         hipLaunchKernelGGL(k_any_spec2, dim3(gx(256u, 256u), nstr), dim3(64 * SPEC_W), 0, stream, g, round);

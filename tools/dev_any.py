@@ -43,8 +43,8 @@ def run(name, z, want, reps=3):
         w32 = work.view(torch.int32)
         cf = w32[oc.value // 4: oc.value // 4 + 64].cpu().tolist()
         ca = w32[oa.value // 4: oa.value // 4 + 64].cpu().tolist()
-        info = " F[fallback %d notfixed %d ok %d] ANY[fallback %d ok %d total %d nused %d mark %d | ncand %d nblk %d nx %d ns %d over %d why %#x nreq %d reqp %d] scratch %.1f MB" % (
-            cf[0], cf[7], cf[3], ca[0], ca[3], ca[2], ca[1], ca[4], ca[40], ca[41], ca[42], ca[43], ca[44], ca[45], ca[46], ca[47], wb / 1e6)
+        info = " F[fallback %d notfixed %d ok %d] ANY[fallback %d ok %d total %d nused %d mark %d | ncand %d nblk %d nx %d ns %d over %d why %#x nreq %d reqp %d dbg %s] scratch %.1f MB" % (
+            cf[0], cf[7], cf[3], ca[0], ca[3], ca[2], ca[1], ca[4], ca[40], ca[41], ca[42], ca[43], ca[44], ca[45], ca[46], ca[47], ca[48:54], wb / 1e6)
     print("%-34s z %9d -> %10d  %s  %8.3f ms  %8.1f MB/s%s" % (name, len(z), n, "OK " if ok else "BAD", min(ts) * 1e3, n / min(ts) / 1e6, info), flush=True)
     return ok
 

@@ -1,10 +1,10 @@
 """Condense the rocprofv3 CSVs of tools/prof_single.sh: the one-stream paths are CHAINS of kernels, so every counter is summed over
-all dispatches of a kernel family (k_stream_* = hdlz_compress_stream, k_par_* + k_inflate_dyn = hdlz_inflate_batch(nstreams = 1)) and
+all dispatches of a kernel family (k_stream_* = hdlz_compress_stream, k_par_* + k_any_* + k_inflate_dyn = hdlz_inflate_batch(nstreams = 1)) and
 divided by the number of calls (= the dispatch count of a kernel that runs exactly once per call)."""
 import csv, glob, os, sys
 from collections import defaultdict
 root = sys.argv[1]
-FAM = (("k_stream", ("k_stream_",), "k_stream_place"), ("k_par", ("k_par_", "k_inflate_dyn", "k_zero_words"), "k_par_emit"))
+FAM = (("k_stream", ("k_stream_",), "k_stream_place"), ("k_par", ("k_par_", "k_any_", "k_inflate_dyn", "k_zero_words"), "k_par_finish"))
 
 
 def find(sub, pat):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the PMC summaries of tools/evidence_r5.sh: per bench entry the HBM bytes per launch (FETCH_SIZE x 2
+"""profiles/traffic.json from the PMC summaries of tools/evidence_r6.sh: per bench entry the HBM bytes per launch (FETCH_SIZE x 2
 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, KB -> bytes; per-dispatch means of separate --pmc passes) and the
 issue counters (SQ_INSTS_VALU / _SALU, GRBM_GUI_ACTIVE), together with WHAT was measured -- kernel symbol, launch grid, library
 version -- so that bench.py can refuse an entry that does not describe the kernel it just launched.
@@ -13,7 +13,7 @@ root = sys.argv[1]
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 hdr = open(os.path.join(REPO, "include", "hdlz.h")).read()
 VERSION = int(re.search(r"#define\s+HDLZ_VERSION\s+(0x[0-9a-fA-F]+)", hdr).group(1), 16)
-RND = "r05"
+RND = "r06"
 # summary file, traffic.json key, kernel symbol (prefix) the counters are taken from, committed copy
 # summary file, traffic.json key, kernel symbol(s) the counters are taken from, committed copy, (source file, mangled substring) for the VALU mix
 SPEC = [("pmc_cfg1.txt", "k_compress<1>|blocks=1048576|block=2048|data=families", "k_compress<1, true, true>", "cfg1", ("hdlz_compress.hip", "k_compressILi1ELb1ELb1E")),
@@ -31,8 +31,8 @@ if os.path.exists(tt):
     m_ = re.search(r"the counter runs at ([0-9.]+) GHz", open(tt).read())
     if m_:
         CLK = float(m_.group(1))
-    open(os.path.join(REPO, "profiles", "r05_tile_timing.txt"), "w").write(
-        "# tools/exp_tile_timing.py on the -DHDLZ_TILE_TIMING build, evidence run of the shipped kernels (tools/evidence_r5.sh)\n" +
+    open(os.path.join(REPO, "profiles", "r06_tile_timing.txt"), "w").write(
+        "# tools/exp_tile_timing.py on the -DHDLZ_TILE_TIMING build, evidence run of the shipped kernels (tools/evidence_r6.sh)\n" +
         "".join(l for l in open(tt) if "amdgpu.ids" not in l) +
         "# \"first prologue of the wave\": ~45 us in front of a wave's first tile in THIS instrumented build of <1,true,true> (its prologue spills SGPRs to scratch; the shipped kernel has\n"
         "# no scratch, and the wide-window instantiations of the same build show 140 cycles there): an artifact of the stamps, reported apart so that \"block prologue\" is the per-tile cost.\n")
@@ -68,7 +68,7 @@ for fn, key, kern, tag, mixsrc in SPEC:
         continue
     dest = "profiles/%s_%s_pmc_summary.txt" % (RND, tag)
     open(os.path.join(REPO, dest), "w").write(
-        "# rocprofv3 evidence (tools/evidence_r5.sh -> tools/profile*.sh: kernel stats + SQ / LDS / FETCH / WRITE (+ TA / TCP / TCC) passes, "
+        "# rocprofv3 evidence (tools/evidence_r6.sh -> tools/profile*.sh: kernel stats + SQ / LDS / FETCH / WRITE (+ TA / TCP / TCC) passes, "
         "separate --pmc passes, per-dispatch means; libhdlz 0x%06x)\n" % VERSION + txt)
     e = {"traffic_bytes": int(f * 2 * 1024 + w * 1024), "source": dest, "fetch_size_kb": f, "write_size_kb": w,
          "kernel": kern, "grid": grid[0], "hdlz_version": VERSION,
@@ -78,8 +78,8 @@ for fn, key, kern, tag, mixsrc in SPEC:
                        "instructions in its ISA (tools/valu_mix.py; 1.96 / 3.25 shader cycles per wave64 instruction measured in s_memtime ticks, "
                        "profiles/r04_ubench/ubench_valu_cycles*.txt): the time the VALU pipes are HELD, a lower bound of the time they are needed "
                        "(at 2 waves per SIMD a wave cannot issue faster than 2.4 / 4.4, alone 4.9); kernel_cycles = launch duration x the clock of "
-                       "the same counter under the headline load (%.3f GHz, profiles/r05_tile_timing.txt)" % CLK,
-         "note": "round 5, %s: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE" % kern}
+                       "the same counter under the headline load (%.3f GHz, profiles/r06_tile_timing.txt)" % CLK,
+         "note": "round 6, %s: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE" % kern}
     f_, s_ = mix(mixsrc[0], mixsrc[1])
     e["valu_fast_frac"] = f_ / float(f_ + s_)
     rd, wr = val("TCC_EA0_RDREQ"), val("TCC_EA0_WRREQ")
@@ -109,14 +109,14 @@ if os.path.exists(p):
                   "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
                   "kernel": "k_par_* (STARTD: all kernels of hdlz_inflate_batch, 256 streams)", "grid": None,
                   "hdlz_version": VERSION, "valu_insts": vals.get("SQ_INSTS_VALU"), "salu_insts": vals.get("SQ_INSTS_SALU"),
-                  "note": "round 5: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, summed over the kernels of one call"}
+                  "note": "round 6: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, summed over the kernels of one call"}
         print(key, T[key]["traffic_bytes"])
 # the one-stream paths (tools/prof_single.sh: counters summed over the kernels of one call)
 p = os.path.join(root, "pmc_single.txt")
 if os.path.exists(p):
     txt = "\n".join(l for l in open(p).read().splitlines() if "amdgpu.ids" not in l) + "\n"
     dest = "profiles/%s_single_stream_pmc_summary.txt" % RND
-    open(os.path.join(REPO, dest), "w").write("# rocprofv3 evidence (tools/evidence_r5.sh -> tools/prof_single.sh): one 16 MiB stream through hdlz_compress_stream (k_stream_*) and "
+    open(os.path.join(REPO, dest), "w").write("# rocprofv3 evidence (tools/evidence_r6.sh -> tools/prof_single.sh): one 16 MiB stream through hdlz_compress_stream (k_stream_*) and "
                                               "hdlz_inflate_batch(nstreams = 1) (k_par_* + the fall-back launch), every counter SUMMED over the kernels of one call; libhdlz 0x%06x\n" % VERSION + txt)
     for fam, key, kname in (("k_stream", "k_stream|stream=16777216", "k_stream_* (STARTC: all kernels of hdlz_compress_stream)"),
                             ("k_par", "k_par|stream=16777216", "k_par_* (STARTD: all kernels of hdlz_inflate_batch(nstreams = 1))")):
@@ -133,6 +133,29 @@ if os.path.exists(p):
             T[key] = {"traffic_bytes": int(vals["FETCH_SIZE"] * 2 * 1024 + vals["WRITE_SIZE"] * 1024), "source": dest,
                       "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"], "kernel": kname, "grid": None,
                       "hdlz_version": VERSION, "valu_insts": vals.get("SQ_INSTS_VALU"), "salu_insts": vals.get("SQ_INSTS_SALU"),
-                      "note": "round 5: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, summed over the kernels of one call"}
+                      "note": "round 6: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, summed over the kernels of one call"}
             print(key, T[key]["traffic_bytes"])
+# one stock-zlib stream (PROF_MODE=zlib tools/prof_single.sh: k_any_* + the k_par_* kernels of the same call, summed)
+p = os.path.join(root, "pmc_zlib.txt")
+if os.path.exists(p):
+    txt = "\n".join(l for l in open(p).read().splitlines() if "amdgpu.ids" not in l) + "\n"
+    dest = "profiles/%s_zlib_stream_pmc_summary.txt" % RND
+    open(os.path.join(REPO, dest), "w").write("# rocprofv3 evidence (PROF_MODE=zlib tools/prof_single.sh): one 16 MiB zlib level-6 stream through hdlz_inflate_batch_ws(nstreams = 1) "
+                                              "(k_any_* + k_par_emit / k_par_jump + the idle fixed-block chain + the fall-back launch), every counter SUMMED over the kernels of one call; libhdlz 0x%06x\n" % VERSION + txt)
+    vals, cur = {}, None
+    for ln in txt.splitlines():
+        m = re.match(r"\s*family (\w+)\s*$", ln)
+        if m:
+            cur = m.group(1)
+        m = re.search(r"(\w+)\s+n=\d+ mean=([0-9.e+]+)", ln)
+        if m and cur == "k_par":
+            vals[m.group(1)] = float(m.group(2))
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        key = "k_any|stream=16777216|level=6"
+        T[key] = {"traffic_bytes": int(vals["FETCH_SIZE"] * 2 * 1024 + vals["WRITE_SIZE"] * 1024), "source": dest,
+                  "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+                  "kernel": "k_any_* + k_par_emit/jump (STARTD: all kernels of hdlz_inflate_batch(nstreams = 1))", "grid": None,
+                  "hdlz_version": VERSION, "valu_insts": vals.get("SQ_INSTS_VALU"), "salu_insts": vals.get("SQ_INSTS_SALU"),
+                  "note": "round 6: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, summed over the kernels of one call"}
+        print(key, T[key]["traffic_bytes"])
 json.dump(T, open(tj, "w"), indent=1)
