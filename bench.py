@@ -264,9 +264,10 @@ ISSUE_KEEP = ("frac", "valu_insts_per_launch", "valu_insts_per_byte", "source")
 TOP_KEEP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
             "data", "config", "per_gpu_MBps", "compression_ratio_out_over_in", "roofline", "cpu_baseline", "archive", "end_to_end",
             "input_MBps", "length_allgather_ms_avg", "lengths_digest", "T1_ms", "T1_kernel_ms_median", "speedup_vs_T1",
-            "T1_lengths_digest", "scaling_curve", "error", "visible_devices", "secondary", "detail")
+            "T1_lengths_digest", "scaling_curve", "error", "visible_devices", "secondary", "detail", "name", "inflate_MBps", "compress_MBps",
+            "inflate_ms", "compress_ms", "inflate_ms_with_hint", "ms_with_hint", "one_wave_ms", "wave_per_stream_ms", "compress_roofline")
 SEC_KEEP = ("name", "metric", "value", "unit", "ms_per_step", "compression_ratio_out_over_in", "input_MBps", "roofline",
-            "compress_roofline", "inflate_MBps", "compress_MBps", "wave_per_stream_ms", "one_wave_ms", "status")
+            "compress_roofline", "inflate_MBps", "compress_MBps", "wave_per_stream_ms", "one_wave_ms", "inflate_ms_with_hint", "ms_with_hint", "status")
 
 
 def _numbers_only(d, depth=2):
@@ -297,7 +298,9 @@ def _short(s, n):
 def slim_line(res, detail_path=None, line_max=LINE_MAX):
     """the line the driver parses: the contract's keys, `roofline`, `cpu_baseline` and the numbers of every secondary entry; all
     prose (`note`s, long workload texts, per-entry configs) stays in the detail file named in `detail` (VERDICT r5 #1)"""
-    top = {k: res[k] for k in TOP_KEEP if k in res and k not in ("secondary", "roofline", "cpu_baseline", "archive", "end_to_end", "config")}
+    top = {k: res[k] for k in TOP_KEEP if k in res and k not in ("secondary", "roofline", "compress_roofline", "cpu_baseline", "archive", "end_to_end", "config")}
+    if isinstance(res.get("compress_roofline"), dict):
+        top["compress_roofline"] = _slim_roofline(res["compress_roofline"])
     if "config" in res:
         top["config"] = {k: (_short(v, 200) if isinstance(v, str) else v) for k, v in res["config"].items()}
     if "roofline" in res:
@@ -571,11 +574,15 @@ def bench_single_stream(torch, eng, dev, a, n=1 << 24):
     def step_d():
         return eng.inflate_batch(zin, in_len=zn, out_pitch=n, out=back)
 
+    def step_dh():                           # with the caller's hint "a single fixed block" (what STARTC writes): only that chain is launched
+        return eng.inflate_batch(zin, in_len=zn, out_pitch=n, out=back, flags=128)
+
     _, bl, bs = step_d()
     torch.cuda.synchronize()
     assert int(bs.item()) == 0 and int(bl.item()) == n and torch.equal(back.reshape(-1), d[:n]), "single-stream round trip failed"
     kc = kernel_ms(torch, step_c, max(3, a.steps))
     kd = kernel_ms(torch, step_d, max(3, a.steps))
+    kh = kernel_ms(torch, step_dh, max(3, a.steps))
     ms_c, ms_d = sum(kc) / len(kc), sum(kd) / len(kd)
     algo = n + zn + 4                         # one stream = N_in + N_out + one length word, in either direction
     return {"name": "one 16 MiB stream", "metric": "single-stream throughput (STARTC then STARTD of ONE stream, whole GPU each)",
@@ -584,6 +591,7 @@ def bench_single_stream(torch, eng, dev, a, n=1 << 24):
                                    "inflated by hdlz_inflate_batch(nstreams = 1), round trip checked" % n,
                        "stream_bytes": n, "compressed_bytes": zn},
             "inflate_MBps": round(n / ms_d / 1e3, 1), "inflate_ms": round(ms_d, 4),
+            "inflate_ms_with_hint": round(sum(kh) / len(kh), 4),       # HDLZ_INFLATE_ONE_FIXED_BLOCK: the chain for other block types is not launched beside it
             "compress_MBps": round(n / ms_c / 1e3, 1), "compress_ms": round(ms_c, 4),
             # (VERDICT r4 #3b) the path is a CHAIN of kernels: algorithmic bytes over the duration of the whole call (HIP events around it);
             # traffic = the counters summed over all kernels of one call (tools/prof_single.py -> profiles/r05_single_stream_pmc_summary.txt)
@@ -593,7 +601,7 @@ def bench_single_stream(torch, eng, dev, a, n=1 << 24):
                     "(all kernels of the path)"}
 
 
-def bench_zlib_stream(torch, eng, dev, a, n=1 << 24, level=6):
+def bench_zlib_stream(torch, eng, dev, a, n=1 << 24, level=6, with_wave=True):
     """STARTD of ONE stock-zlib stream (level 6: dynamic-tree blocks, 32 KiB distances) -- what the reference's default build
     (DYNAMIC=True, deflate.py:32) is fed -- on the whole GPU (hdlz_inflate_any.hip, round 6; one wave up to round 5: 11 MB/s)"""
     import zlib
@@ -616,7 +624,7 @@ def bench_zlib_stream(torch, eng, dev, a, n=1 << 24, level=6):
     torch.cuda.synchronize()
     assert int(bs.item()) == 0 and int(bl.item()) == n and torch.equal(back.reshape(-1), want), "zlib stream: inflated bytes differ"
     kd = kernel_ms(torch, step, max(3, a.steps))
-    kw = kernel_ms(torch, step_wave, 1)
+    kw = kernel_ms(torch, step_wave, 1) if with_wave else [0.0]      # (profiling runs leave it out: its kernel would be summed into the path's family)
     ms_d = sum(kd) / len(kd)
     return {"name": "one 16 MiB zlib level-%d stream" % level, "metric": "single-stream inflate throughput (stock zlib stream, any block types, whole GPU)",
             "value": round(n / ms_d / 1e3, 1), "unit": "MB/s", "ms_per_step": round(ms_d, 4), "higher_is_better": True,
@@ -646,11 +654,15 @@ def bench_few_large(torch, eng, dev, a, nstreams=256, n=1 << 20, with_wave=True)
     def step_wave():
         return eng.inflate_batch(zo, out_pitch=n, out=back, flags=4)
 
+    def step_hint():
+        return eng.inflate_batch(zo, out_pitch=n, out=back, flags=128)
+
     _, bl, bs = step()
     torch.cuda.synchronize()
     assert int(bs.max().item()) == 0 and int(bl.min().item()) == n and torch.equal(back, d), "few-large-streams round trip failed"
     kd = kernel_ms(torch, step, max(3, a.steps))
     kw = kernel_ms(torch, step_wave, 2) if with_wave else [0.0]      # (profiling runs leave it out: its kernel is part of the path's family)
+    kh = kernel_ms(torch, step_hint, max(3, a.steps)) if with_wave else [0.0]
     ms_d = sum(kd) / len(kd)
     total = nstreams * n
     algo = total + zsum + 4 * nstreams
@@ -659,7 +671,7 @@ def bench_few_large(torch, eng, dev, a, nstreams=256, n=1 << 20, with_wave=True)
             "config": {"workload": "%d own streams of %d bytes (families 1-4, CWINDOW=32, MATCH10) in rows of one pitch: hdlz_inflate_batch, "
                                    "no mapping hint, round trip checked" % (nstreams, n), "streams": nstreams, "stream_bytes": n,
                        "compressed_bytes": zsum},
-            "wave_per_stream_ms": round(sum(kw) / len(kw), 3),
+            "wave_per_stream_ms": round(sum(kw) / len(kw), 3), "ms_with_hint": round(sum(kh) / len(kh), 4),
             "roofline": roofline("k_par_* (STARTD: all kernels of hdlz_inflate_batch, %d streams)" % nstreams, algo, kd,
                                  "k_par|streams=%d|stream=%d" % (nstreams, n)),
             "note": "every kernel of the single-stream path launched once for all streams (blockIdx.y = the stream); timed with HIP events "
@@ -1051,7 +1063,7 @@ def main():
         import torch
         import hdl_deflate_amd
         torch.cuda.set_device(0)
-        emit(bench_zlib_stream(torch, hdl_deflate_amd.Engine(torch.device("cuda", 0)), torch.device("cuda", 0), a), a)
+        emit(bench_zlib_stream(torch, hdl_deflate_amd.Engine(torch.device("cuda", 0)), torch.device("cuda", 0), a, with_wave=False), a)
     elif a.mode == "few":                                     # only the few-large-streams entry (profiling)
         import torch
         import hdl_deflate_amd

@@ -8,7 +8,7 @@ There is NO CPU fallback: every compute entry point raises if the HIP library or
 from .errors import Error, HdlzStatusError, HdlzRangeError                         # noqa: F401
 from .constants import (IDLE, WRITE, READ, STARTC, STARTD, OK, E_SHORT_INPUT, E_OUT_CAPACITY,   # noqa: F401
                         E_BAD_BTYPE, E_BAD_DISTANCE, E_NO_EOF, E_DYNAMIC_UNSUPPORTED, E_BAD_SYMBOL,
-                        E_BAD_PARAM, E_HIP, E_BAD_TREE, INFLATE_ASSUME_FIXED, INFLATE_LANE_PER_STREAM, INFLATE_WAVE_PER_STREAM, INFLATE_GROUP_PER_STREAM, INFLATE_ONEBLOCK,
+                        E_BAD_PARAM, E_HIP, E_BAD_TREE, INFLATE_ASSUME_FIXED, INFLATE_LANE_PER_STREAM, INFLATE_WAVE_PER_STREAM, INFLATE_GROUP_PER_STREAM, INFLATE_ONEBLOCK, INFLATE_ONE_FIXED_BLOCK,
                         STATUS_NAMES, out_bound)
 from .port import Sig, DeflatePort, deflate                         # noqa: F401
 

@@ -8,6 +8,7 @@ INFLATE_ASSUME_FIXED = 1
 INFLATE_LANE_PER_STREAM = 2      # mapping hints of hdlz_inflate_batch (results are identical)
 INFLATE_WAVE_PER_STREAM = 4
 INFLATE_GROUP_PER_STREAM = 64   # 16 lanes per stream, history in LDS (hdlz_inflate_grp.hip)
+INFLATE_ONE_FIXED_BLOCK = 128   # hint: the streams are single fixed blocks (what STARTC writes): only that whole-GPU chain is launched
 INFLATE_ONEBLOCK = 8             # ONEBLOCK=True build: stop at the end of the first block (deflate.py:40-41,678,1542,1617)
 
 STATUS_NAMES = {OK: "OK", E_SHORT_INPUT: "SHORT_INPUT", E_OUT_CAPACITY: "OUT_CAPACITY", E_BAD_BTYPE: "BAD_BTYPE",

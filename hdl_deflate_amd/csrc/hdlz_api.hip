@@ -205,7 +205,7 @@ int inflate_batch_impl(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t i
     if (nstreams > 0x7FFFFFFFull * 32) return fail_param("nstreams too large for one launch");
     if (nstreams && (!d_in || !d_out || !d_out_len || !d_status)) return fail_param("null device pointer");
     if (flags & ~(HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_LANE_PER_STREAM | HDLZ_INFLATE_WAVE_PER_STREAM | HDLZ_INFLATE_ONEBLOCK |
-                  HDLZ_INFLATE_GROUP_PER_STREAM))
+                  HDLZ_INFLATE_GROUP_PER_STREAM | HDLZ_INFLATE_ONE_FIXED_BLOCK))
         return fail_param("unknown flag");
     // the kernels keep stream lengths and bit positions in 32 bits (8 * length must not wrap)
     if (!d_in_off && in_len >= 0x10000000u) return fail_param("in_len too large (streams are limited to 256 MiB - 1)");

@@ -53,9 +53,15 @@ using par::C_TOTAL;
 using par::NONE;
 using par::TOK_LIT;
 
-constexpr uint32_t PB = 1024;                 // bits per piece
+// bits per piece (Args::pb): 1024, and 2048 for streams of 4 MiB and more -- the real decode and the walks are lane-serial per piece
+// (small streams want short pieces: 60 KB .. 1 MiB 0.63 .. 0.71 ms against 0.85 .. 0.92), the emit and the marker pass pay per item
+// (large ones want fewer: 16 MiB 1.71 .. 1.89 ms against 1.73 .. 2.10)
+constexpr uint32_t PB_MAX = 2048;
+// a map entry: kind << 30 | offset << NBB | bytes -- offset up to pb + 15 (an end-of-block code ends that far behind the piece's first bit)
+constexpr uint32_t OB = 12u, NBB = 30u - OB, NBM = (1u << NBB) - 1u, OFM = (1u << OB) - 1u;
+static_assert(PB_MAX + 15u <= OFM, "map entry fields");
 constexpr uint32_t LB = 11, DB = 9;           // bits of the two primary look-up tables
-constexpr uint32_t FIX_MAX_BITS = 16 * PB;    // a fixed block behind a dynamic one is decoded by ONE lane: up to this many bits
+constexpr uint32_t FIX_MAX_BITS = 16384;      // a fixed block behind a dynamic one is decoded by ONE lane: up to this many bits
 constexpr uint32_t NO_OWNER = 0xFFFFu;
 constexpr uint32_t N_END = 0xFFFFFFFEu, N_BAD = 0xFFFFFFFFu;      // successor of a node: the stream ends / no valid successor
 enum { A_NCAND = par::C_ANY0, A_NBLK, A_NX, A_NS, A_OVER, A_WHY, A_NREQ, A_NREQP };       // this chain's counters in its control words; A_WHY: bits of W_* (diagnostics)
@@ -95,7 +101,7 @@ struct Args {
     uint8_t* ws;                  // this chain's scratch of stream 0
     size_t stride;                // bytes from a stream's scratch to the next stream's
     uint32_t* srcA;               // stream 0's marker words
-    uint32_t nchunks, candcap, maxb, maxx, maxs, tcap, maxreq, mapcap;
+    uint32_t nchunks, candcap, maxb, maxx, maxs, tcap, maxreq, mapcap, pb;
     size_t o_cand, o_blk, o_blen, o_shdr, o_spay, o_sidx, o_tab, o_owner, o_map, o_pent, o_prel, o_pnode, o_node, o_xitem, o_sitem,
            o_opos, o_ntok, o_tok, o_mext, o_req, o_map2, o_nstate, o_cpos, o_cres, o_nch, o_pmap;
 };
@@ -105,6 +111,7 @@ struct View {
     uint32_t zn;
     uint8_t* out;
     uint32_t* ctl;
+    uint32_t pb;                  // bits per piece
     bool run;                     // the gate is open and nothing has failed so far
     uint32_t* cand; Blk* blk; uint8_t* blen; uint32_t* shdr; uint32_t* spay; uint32_t* sidx; Tab* tab; uint16_t* owner; uint32_t* map;
     uint8_t* pent; uint32_t* prel; uint16_t* pnode; Node* node; XItem* xitem; SItem* sitem; uint32_t* opos; uint32_t* ntok; uint32_t* tok;
@@ -122,6 +129,7 @@ __device__ __forceinline__ View view(const Args& a) {
     v.out = a.out + (uint64_t)s * a.out_pitch;
     uint8_t* w = a.ws + (size_t)s * a.stride;
     v.ctl = reinterpret_cast<uint32_t*>(w);
+    v.pb = a.pb;
     // the gate: a stream that is ONE fixed block is the other chain's (hdlz_inflate_par.hip: one_fixed_block -- the same test on the same
     // byte, so the two chains need nothing from each other and run side by side); this one is only launched for the default build's flags
     const uint32_t hdr = v.zn >= 5u ? (uint32_t)v.z[2] : 0u;
@@ -498,14 +506,14 @@ __global__ __launch_bounds__(TAB_T) void k_any_tables(Args a) {
 }
 
 // ================================================================================================ 2. pieces and their maps
-// piece q = the stream bits [q PB, (q + 1) PB); its owner: the last candidate whose payload starts at or in front of its first bit
+// piece q = the stream bits [q v.pb, (q + 1) v.pb); its owner: the last candidate whose payload starts at or in front of its first bit
 __global__ __launch_bounds__(64) void k_any_owner(Args a) {
     const View v = view(a);
     if (!v.run) return;
     const uint32_t n = min(v.ctl[A_NBLK], a.maxb);
     for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
-        const uint32_t q0 = (v.spay[r] + PB - 1u) / PB;
-        const uint32_t q1 = r + 1u < n ? min((v.spay[r + 1u] + PB - 1u) / PB, a.nchunks) : a.nchunks;
+        const uint32_t q0 = (v.spay[r] + v.pb - 1u) / v.pb;
+        const uint32_t q1 = r + 1u < n ? min((v.spay[r + 1u] + v.pb - 1u) / v.pb, a.nchunks) : a.nchunks;
         for (uint32_t q = q0 + threadIdx.x; q < q1; q += 64u) v.owner[q] = (uint16_t)r;
     }
 }
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(64) void k_any_owner(Args a) {
 constexpr uint32_t SPEC_W = 4;                // waves per workgroup, each with its own tables
 struct SpecLds {
     Tab t[SPEC_W];
-    uint32_t win[SPEC_W][PB / 32 + 8];
+    uint32_t win[SPEC_W][PB_MAX / 32 + 8];
 };
 __device__ __forceinline__ void load_tab(Tab* dst_, const Tab* src_, uint32_t lane) {
     const tok::u32x4* src = reinterpret_cast<const tok::u32x4*>(src_);
@@ -534,7 +542,7 @@ __device__ __forceinline__ bool spec_step(const Tab* t, uint64_t x, uint32_t b0,
     sym_of<LB, 9u, 511u>(t->ll, t->lfirst, t->lcnt, t->loff, t->lsym, (uint32_t)x, sym, len);
     if (len == 0u) { res = 3u << 30; return false; }
     if (sym < 256u) { pos += len; nbytes += 1u; return true; }
-    if (sym == 256u) { res = (2u << 30) | ((pos + len - b0) << 19) | nbytes; return false; }
+    if (sym == 256u) { res = (2u << 30) | ((pos + len - b0) << NBB) | nbytes; return false; }
     uint32_t lbase, leb, ds, dl;
     tok::length_info(sym - 257u, lbase, leb);
     const uint64_t x1 = x >> len;
@@ -544,11 +552,11 @@ __device__ __forceinline__ bool spec_step(const Tab* t, uint64_t x, uint32_t b0,
     const uint32_t deb = ds < 4u ? 0u : (ds >> 1) - 1u;
     pos += len + leb + dl + deb;
     nbytes += tl;
-    if (nbytes >= (1u << 19)) { res = 3u << 30; return false; }       // (cannot happen: 512 tokens of 258 bytes)
+    if (nbytes >= (1u << NBB)) { res = 3u << 30; return false; }       // (cannot happen: 512 tokens of 258 bytes)
     return true;
 }
 __device__ __forceinline__ void stage_piece(const View& v, uint32_t* win, uint32_t q, uint32_t lane) {
-    for (uint32_t k = lane; k < PB / 32u + 8u; k += 64u) win[k] = tok::load32(v.z, ((q * PB) >> 3) + 4u * k, v.zn);
+    for (uint32_t k = lane; k < v.pb / 32u + 8u; k += 64u) win[k] = tok::load32(v.z, ((q * v.pb) >> 3) + 4u * k, v.zn);
     wave_lds_order();
     __builtin_amdgcn_wave_barrier();
 }
@@ -558,22 +566,22 @@ __device__ __forceinline__ uint64_t win_bits(const uint32_t* win, uint32_t rel) 
     return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
 }
 // the chains of all lanes from where they stand to the end of the piece -> res
-__device__ __forceinline__ void spec_finish(const Tab* t, const uint32_t* win, uint32_t b0, uint32_t& pos, uint32_t& nbytes, uint32_t& res, bool& run) {
-    const uint32_t end = b0 + PB;
+__device__ __forceinline__ void spec_finish(const Tab* t, const uint32_t* win, uint32_t b0, uint32_t pb, uint32_t& pos, uint32_t& nbytes, uint32_t& res, bool& run) {
+    const uint32_t end = b0 + pb;
     while (ballot64(run) != 0ull) {
         if (run) {
             run = spec_step(t, win_bits(win, pos - b0), b0, pos, nbytes, res);
-            if (run && pos >= end) { res = ((pos - end) << 19) | nbytes; run = false; }
+            if (run && pos >= end) { res = ((pos - end) << NBB) | nbytes; run = false; }
         }
     }
 }
 // piece q with the tables at t (LDS), one wave: lane e starts at the piece's bit e -> mp[e]
 __device__ __forceinline__ void spec_piece(const View& v, const Tab* t, uint32_t* win, uint32_t q, uint32_t* mp, uint32_t lane) {
-    const uint32_t b0 = q * PB;
+    const uint32_t b0 = q * v.pb;
     stage_piece(v, win, q, lane);
     uint32_t pos = b0 + lane, nbytes = 0, res = 0;
     bool run = true;
-    spec_finish(t, win, b0, pos, nbytes, res, run);
+    spec_finish(t, win, b0, v.pb, pos, nbytes, res, run);
     mp[lane] = res;
     __builtin_amdgcn_wave_barrier();
 }
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(64 * SPEC_W) void k_any_spec(Args a) {
         if (r != cur) { load_tab(&L.t[wv], &v.tab[r], lane); cur = r; }
         const Tab* t = &L.t[wv];
         const uint32_t* win = L.win[wv];
-        const uint32_t b0 = q * PB, hb = b0 + HEAD;
+        const uint32_t b0 = q * v.pb, hb = b0 + HEAD;
         stage_piece(v, L.win[wv], q, lane);
         first[wv][lane] = 0xFFFFFFFFu;
         uint32_t pos = b0 + lane, nbytes = 0, res = 0;
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(64 * SPEC_W) void k_any_spec(Args a) {
         const uint64_t lm = ballot64(leader);
         const uint32_t nlead = (uint32_t)__popcll(lm);
         if (nlead > CH_MAX) {                                    // (rare) too many distinct chains: to the end, here
-            spec_finish(t, win, b0, pos, nbytes, res, run);
+            spec_finish(t, win, b0, v.pb, pos, nbytes, res, run);
             if (lane == 0u) v.nch[q] = 0;
         } else {
             if (leader) {
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(64 * SPEC_W) void k_any_spec(Args a) {
             }
             wave_lds_order();
             __builtin_amdgcn_wave_barrier();
-            if (run) res = (1u << 30) | (slotof[wv][key] << 19) | nbytes;
+            if (run) res = (1u << 30) | (slotof[wv][key] << NBB) | nbytes;
             if (lane == 0u) v.nch[q] = (uint8_t)nlead;
         }
         v.map[(size_t)q * 64u + lane] = res;
@@ -655,7 +663,7 @@ __global__ __launch_bounds__(64) void k_any_tail(Args a) {
             __builtin_amdgcn_wave_barrier();
             cur = r0;
         }
-        const uint32_t b0 = q * PB, end = b0 + PB;
+        const uint32_t b0 = q * v.pb, end = b0 + v.pb;
         Bits rd;
         rd.init(v.z, v.zn, have ? v.cpos[c] : 16u);
         uint32_t pos = rd.pos, nbytes = 0, res = 0;
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(64) void k_any_tail(Args a) {
                     rd.pos = p0;
                     if (used > 32u) { rd.take(32u); rd.refill(); used -= 32u; }
                     rd.take(used);
-                    if (pos >= end) { res = ((pos - end) << 19) | nbytes; run = false; }
+                    if (pos >= end) { res = ((pos - end) << NBB) | nbytes; run = false; }
                 }
             }
         };
@@ -689,8 +697,8 @@ __global__ __launch_bounds__(256) void k_any_resolve(Args a) {
         if (v.owner[q] == NO_OWNER) continue;
         const uint32_t m = v.map[t];
         if ((m >> 30) != 1u) continue;
-        const uint32_t c = v.cres[(size_t)q * CH_MAX + ((m >> 19) & 7u)], nb = (m & 0x7FFFFu) + (c & 0x7FFFFu);
-        v.map[t] = nb >= (1u << 19) ? (3u << 30) : ((c & 0xFFF80000u) | nb);
+        const uint32_t c = v.cres[(size_t)q * CH_MAX + ((m >> NBB) & 7u)], nb = (m & NBM) + (c & NBM);
+        v.map[t] = nb >= (1u << NBB) ? (3u << 30) : ((c & ~NBM) | nb);
     }
 }
 // the pieces the walks of round `round` - 1 asked for, with the asking candidate's tables
@@ -776,9 +784,9 @@ __device__ __forceinline__ void walk_node(const Args& a, const View& v, uint32_t
         uint32_t q, pos, rq0 = 0, rq1 = 0, rslot = 0;
         if (round == 0u) {
             rd.init(v.z, v.zn, b.pay);
-            q = b.pay / PB;
-            if (b.pay % PB != 0u) {                                   // the first, partial piece: decoded here
-                const uint32_t limit = (q + 1u) * PB;
+            q = b.pay / v.pb;
+            if (b.pay % v.pb != 0u) {                                   // the first, partial piece: decoded here
+                const uint32_t limit = (q + 1u) * v.pb;
                 load_tab(&lt, &v.tab[i], lane);
                 wave_lds_order();
                 __builtin_amdgcn_wave_barrier();
@@ -796,8 +804,8 @@ __device__ __forceinline__ void walk_node(const Args& a, const View& v, uint32_t
         uint32_t sq0 = 0;                                             // first staged piece
         bool staged = false;
         while (ok && !eob) {                                          // whole pieces: through the maps
-            if (q >= a.nchunks || pos - q * PB >= 64u) { ok = false; why |= W_WALK_OWNER; break; }
-            const uint32_t e = pos - q * PB;
+            if (q >= a.nchunks || pos - q * v.pb >= 64u) { ok = false; why |= W_WALK_OWNER; break; }
+            const uint32_t e = pos - q * v.pb;
             if (!staged || q - sq0 >= WALK_STAGE) {
                 sq0 = q; staged = true;
                 const uint32_t cnt = min(WALK_STAGE, a.nchunks - sq0);
@@ -820,14 +828,14 @@ __device__ __forceinline__ void walk_node(const Args& a, const View& v, uint32_t
                 if (lane == 0u) { v.pent[q] = (uint8_t)e; v.prel[q] = (uint32_t)nb; v.pnode[q] = (uint16_t)i; v.pmap[q] = m; }
             } else if (q >= rq0 && q < rq1) {                         // a piece decoded for this block on request: an item of its own
                 m = v.map2[(size_t)(rslot + (q - rq0)) * 64u + e];
-                const uint32_t k_ = m >> 30, o_ = (m >> 19) & 2047u;
-                add_xitem(q * PB + e, (q + 1u) * PB, i, nb, k_ == 0u ? (q + 1u) * PB + o_ : q * PB + o_, m & 0x7FFFFu);
+                const uint32_t k_ = m >> 30, o_ = (m >> NBB) & OFM;
+                add_xitem(q * v.pb + e, (q + 1u) * v.pb, i, nb, k_ == 0u ? (q + 1u) * v.pb + o_ : q * v.pb + o_, m & NBM);
             } else {
                 // decoded for another candidate (a false positive inside this block, if this block is a true one): ask for the pieces up
                 // to the next candidate behind that one with this block's tables, go on in the next round
                 const uint32_t f = own;
                 if (f == NO_OWNER || round + 1u >= WALK_ROUNDS) { ok = false; why |= W_WALK_OWNER; break; }
-                uint32_t qe = f + 1u < n ? min((v.spay[f + 1u] + PB - 1u) / PB, a.nchunks) : a.nchunks;
+                uint32_t qe = f + 1u < n ? min((v.spay[f + 1u] + v.pb - 1u) / v.pb, a.nchunks) : a.nchunks;
                 qe = min(qe, q + REQ_MAX);
                 const uint32_t slot = bump(&v.ctl[A_NREQP], qe - q), r = bump(&v.ctl[A_NREQ], 1u);
                 if (slot + (qe - q) > a.mapcap || r >= a.maxreq) { ok = false; why |= W_WALK_OWNER; break; }
@@ -838,10 +846,10 @@ __device__ __forceinline__ void walk_node(const Args& a, const View& v, uint32_t
                 }
                 return;
             }
-            nb += m & 0x7FFFFu;
-            const uint32_t kind = m >> 30, off = (m >> 19) & 2047u;
-            if (kind == 0u) { pos = (q + 1u) * PB + off; q++; }
-            else if (kind == 2u) { pos = q * PB + off; eob = true; }
+            nb += m & NBM;
+            const uint32_t kind = m >> 30, off = (m >> NBB) & OFM;
+            if (kind == 0u) { pos = (q + 1u) * v.pb + off; q++; }
+            else if (kind == 2u) { pos = q * v.pb + off; eob = true; }
             else { ok = false; why |= W_WALK_MAP; }
             if (nb > 0xFFFFFFFFull) ok = false;
         }
@@ -882,7 +890,7 @@ __device__ __forceinline__ void walk_node(const Args& a, const View& v, uint32_t
             wave_lds_order();
             __builtin_amdgcn_wave_barrier();
             while (ok && !eob) {
-                const uint32_t limit = (rd.pos / PB + 1u) * PB, st0 = rd.pos;
+                const uint32_t limit = (rd.pos / v.pb + 1u) * v.pb, st0 = rd.pos;
                 if (rd.pos >= stop) { ok = false; why |= W_WALK_FIX; break; }
                 const uint64_t nb0 = nb;
                 run_to(&lt, limit, eob);
@@ -958,10 +966,10 @@ __global__ __launch_bounds__(64) void k_any_tokens(Args a) {
             if (i < a.nchunks) {
                 nid = v.pnode[i];
                 if (nid != NO_OWNER) {
-                    start = i * PB + v.pent[i]; limit = (i + 1u) * PB; rel = v.prel[i]; slot = nid;
+                    start = i * v.pb + v.pent[i]; limit = (i + 1u) * v.pb; rel = v.prel[i]; slot = nid;
                     const uint32_t m = v.pmap[i];
-                    want_made = m & 0x7FFFFu;
-                    want_end = (m >> 30) == 0u ? limit + ((m >> 19) & 2047u) : i * PB + ((m >> 19) & 2047u);
+                    want_made = m & NBM;
+                    want_end = (m >> 30) == 0u ? limit + ((m >> NBB) & OFM) : i * v.pb + ((m >> NBB) & OFM);
                 }
             } else {
                 const XItem x = v.xitem[i - a.nchunks];
@@ -1046,7 +1054,7 @@ __global__ __launch_bounds__(64) void k_any_zero(Args a) {
 
 constexpr uint32_t ANY_MIN = 16384;           // streams below this stay with the serial decoder (the chain of launches costs ~0.1 ms)
 struct Lay {
-    uint32_t nchunks, candcap, maxb, maxx, maxs, tcap, maxreq, mapcap;
+    uint32_t nchunks, candcap, maxb, maxx, maxs, tcap, maxreq, mapcap, pb;
     size_t o_cand, o_blk, o_blen, o_shdr, o_spay, o_sidx, o_tab, o_owner, o_map, o_pent, o_prel, o_pnode, o_node, o_xitem, o_sitem,
            o_opos, o_ntok, o_tok, o_mext, o_req, o_map2, o_nstate, o_cpos, o_cres, o_nch, o_pmap, bytes;
 };
@@ -1054,7 +1062,8 @@ static Lay lay_of(uint32_t zn) {
     Lay L;
     memset(&L, 0, sizeof(L));
     const uint64_t nbits = 8ull * zn;
-    L.nchunks = (uint32_t)((nbits + PB - 1u) / PB);
+    L.pb = zn >= (4u << 20) ? 2048u : 1024u;
+    L.nchunks = (uint32_t)((nbits + L.pb - 1u) / L.pb);
     L.candcap = (uint32_t)(nbits / 128u) + 1024u;                   // (0.085 % of arbitrary bit positions pass k_any_find; periodic streams far more)
     L.maxb = zn / 1024u < 64u ? 64u : zn / 1024u > 8000u ? 8000u : zn / 1024u;      // (zlib's blocks hold 16 K symbols, ~20 KB; small memLevels and flushes make many small ones)
     L.maxreq = 2u * L.maxb;
@@ -1081,7 +1090,11 @@ static Lay lay_of(uint32_t zn) {
 
 size_t any_work_bytes(uint32_t in_len, uint64_t out_pitch, uint32_t flags) {
     (void)out_pitch;
-    if (in_len < any::ANY_MIN || (flags & (HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_ONEBLOCK))) return 0;     // (those builds read every block as fixed / stop at the first one)
+#ifdef HDLZ_ANY_OFF                            // (A/B build: what the chain costs a stream that is not its)
+    return 0;
+#endif
+    // (those builds read every block as fixed / stop at the first one; the hint: the caller knows the streams are single fixed blocks)
+    if (in_len < any::ANY_MIN || (flags & (HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_ONEBLOCK | HDLZ_INFLATE_ONE_FIXED_BLOCK))) return 0;
     return any::lay_of(in_len).bytes;
 }
 
@@ -1095,7 +1108,7 @@ hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, 
     g.in_pitch = a.in_pitch; g.out_pitch = a.out_pitch; g.in_off = a.in_off;
     g.ws = ws + ws_off; g.stride = ws_stride; g.srcA = reinterpret_cast<uint32_t*>(ws + sa_off);
     g.nchunks = L.nchunks; g.candcap = L.candcap; g.maxb = L.maxb; g.maxx = L.maxx; g.maxs = L.maxs; g.tcap = L.tcap;
-    g.maxreq = L.maxreq; g.mapcap = L.mapcap; g.o_req = L.o_req; g.o_map2 = L.o_map2; g.o_nstate = L.o_nstate;
+    g.maxreq = L.maxreq; g.mapcap = L.mapcap; g.pb = L.pb; g.o_req = L.o_req; g.o_map2 = L.o_map2; g.o_nstate = L.o_nstate;
     g.o_cpos = L.o_cpos; g.o_cres = L.o_cres; g.o_nch = L.o_nch; g.o_pmap = L.o_pmap;
     g.o_cand = L.o_cand; g.o_blk = L.o_blk; g.o_blen = L.o_blen; g.o_shdr = L.o_shdr; g.o_spay = L.o_spay; g.o_sidx = L.o_sidx; g.o_tab = L.o_tab;
     g.o_owner = L.o_owner; g.o_map = L.o_map; g.o_pent = L.o_pent; g.o_prel = L.o_prel; g.o_pnode = L.o_pnode; g.o_node = L.o_node;
@@ -1125,7 +1138,7 @@ hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, 
     par::ParArgs p;
     memset(&p, 0, sizeof(p));
     p.z = a.in; p.zn = a.in_len; p.flags = a.flags; p.obsize = a.obsize; p.out = a.out; p.cap = cap; p.srcn = srcn;
-    p.out_len = a.out_len; p.status = a.status; p.nchunks = nitems; p.chbits = PB;
+    p.out_len = a.out_len; p.status = a.status; p.nchunks = nitems; p.chbits = L.pb;
     p.ctl = reinterpret_cast<uint32_t*>(g.ws);
     p.opos = reinterpret_cast<uint32_t*>(g.ws + L.o_opos); p.tokens = reinterpret_cast<uint32_t*>(g.ws + L.o_tok); p.tcap = L.tcap;
     p.ntok = reinterpret_cast<uint32_t*>(g.ws + L.o_ntok); p.srcA = g.srcA; p.sub = 1u; p.cnu = par::C_NUSED;

@@ -42,6 +42,17 @@ using tok::T_LEN;
 
 // (pointer arithmetic, NOT a round trip through an integer: that makes the pointer generic and every access through it a flat_load /
 //  flat_store, which waits on the LDS counter as well -- k_par_emit ran 7.7 ms instead of 0.15 that way)
+// XCD-aware item order (MI355X_MICROARCH.md: block b runs on XCD b % 8, each XCD has its own L2): workgroup b of n takes item
+// xcd_item(b, n) -- XCD x works through ONE contiguous eighth of the items, so the history its copies and marker chains read (the bytes
+// and marker words of the items just in front) is in ITS L2 instead of being fetched by all eight (measured on a 16 MiB zlib stream:
+// profiles/r06_xcd_order_ab.txt).  A bijection of [0, n); speed only, no correctness depends on it.
+__device__ __forceinline__ uint32_t xcd_item(uint32_t b, uint32_t n) {
+#ifdef HDLZ_NO_XCD_ORDER                       // (A/B build)
+    return b;
+#endif
+    const uint32_t q = n >> 3, r = n & 7u, x = b & 7u;
+    return x * q + min(x, r) + (b >> 3);
+}
 template <typename T> __device__ __forceinline__ void shift_ptr(T*& p, size_t bytes) {
     p = reinterpret_cast<T*>(reinterpret_cast<uint8_t*>(p) + bytes);
 }
@@ -593,7 +604,9 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a_) {
     // (a workgroup takes the pieces blockIdx.x, + gridDim.x, ..: batches of many streams are launched with fewer workgroups per stream than
     //  pieces -- a chain that is NOT a stream's turns every workgroup away at the door, and 1.7 million of those cost 0.7 ms beside the
     //  other chain's real work)
-    for (uint32_t c = blockIdx.x; c < nused_; c += gridDim.x) {
+    for (uint32_t c0_ = blockIdx.x; c0_ < (STRIDED ? nused_ : gridDim.x); c0_ += gridDim.x) {
+    const uint32_t c = STRIDED ? c0_ : xcd_item(c0_, gridDim.x);      // (one workgroup per item: the XCD-aware order)
+    if (c >= nused_) { if constexpr (!STRIDED) break; else continue; }
     // a piece's tokens are the lists of its sub-pieces, one behind the other (the decode runs on sub-pieces; the emit does not:
     // the history in front of a wave's own output becomes markers, and with four times shorter pieces the marker passes doubled)
     const uint32_t nsub = a.sub, fnused = a.ctl[C_FNUSED];
@@ -725,7 +738,7 @@ __global__ __launch_bounds__(64) void k_par_jump(ParArgs a_, uint32_t pass) {
     // (a workgroup takes the pieces blockIdx.x, + gridDim.x, ..: the passes behind the first one are launched with JUMP_GRID workgroups -- a
     //  pass that finds nothing left costs what its workgroups cost to start, 20 us for the 90 000 items of a 7 MB zlib stream; the FIRST
     //  pass keeps one workgroup per piece: capped, it ran 665 us instead of 407)
-    for (uint32_t c = blockIdx.x; c < nused; c += gridDim.x) {
+    for (uint32_t c = xcd_item(blockIdx.x, gridDim.x); c < nused; c += gridDim.x) {      // (XCD-aware order within every stride of the grid)
     const uint32_t ext = a.mext[c];
     if (ext == 0u) continue;
     const uint32_t p0 = a.opos[c];

@@ -5,7 +5,7 @@ import functools
 import torch
 
 from . import _lib
-from .constants import OK, LMAX, pitch_for
+from .constants import OK, LMAX, INFLATE_ONE_FIXED_BLOCK, pitch_for
 from .errors import Error
 
 
@@ -440,6 +440,8 @@ class Engine(object):
         d = host.to(self.device).view(1, pad)
         cap = out_cap if out_cap is not None else min(1 << LMAX, max(1 << 16, 1032 * n + 258))
         cap = (cap + 15) // 16 * 16
+        if n >= 5 and (z[2] & 7) == 3:           # the bytes are here: BFINAL = 1, BTYPE = 01 -- a single fixed block takes that chain only
+            flags |= INFLATE_ONE_FIXED_BLOCK
         out, ol, st = self.inflate_batch(d, in_len=n, out_pitch=cap, flags=flags, obsize=obsize)
         st = int(st.item())
         return st, bytes(out[0, :int(ol.item())].cpu().numpy().tobytes())

@@ -70,6 +70,11 @@ enum {
 #define HDLZ_INFLATE_LANE_PER_STREAM 2u  /* 64 streams per wave (k_inflate_tok) + a second pass for streams with dynamic-tree blocks */
 #define HDLZ_INFLATE_WAVE_PER_STREAM 4u  /* one wave per stream (k_inflate_dyn), any block type */
 #define HDLZ_INFLATE_GROUP_PER_STREAM 64u /* 16 lanes per stream, history in LDS (k_inflate_grp) + the second pass */
+/* hint for the whole-GPU path of large streams (results are identical): the streams are single fixed-Huffman blocks -- what STARTC
+ * writes --, so only that chain of kernels is launched; without it the chain for any block types is launched beside it (a stream takes
+ * one of the two, decided on the device; the other one's launches return at once and cost a stream of STARTC ~8 %).  A stream of
+ * other block types given with this hint is decoded by the serial pass. */
+#define HDLZ_INFLATE_ONE_FIXED_BLOCK 128u
 /* ---- the shapes the default mapping switches at (measured crossovers; provenance: INTEGRATION.md 4) */
 #define HDLZ_INFLATE_WAVE_THRESHOLD 22528u   /* up to this many streams: a wave per stream */
 #define HDLZ_INFLATE_DYN_LANE_MIN 28672u     /* second pass: a lane per stream from this many flagged streams on, else a wave each */

@@ -345,6 +345,24 @@ def test_any_block_types_whole_gpu(engine, oracle):
         assert t_par * 5 < t_wave, (name, len(z), t_par, t_wave)
 
 
+def test_one_fixed_block_hint(engine, oracle):
+    """HDLZ_INFLATE_ONE_FIXED_BLOCK (128): only the fixed-block chain is launched -- same results for what STARTC writes, and a stream of
+    other block types given with the hint is still decoded (by the serial pass)"""
+    import torch
+    from hdl_deflate_amd.data import make_blocks
+    d = make_blocks(512, 2048, "cuda", seed=9).reshape(-1)
+    out, ol, st = engine.compress_stream(d, d.numel() - 16)
+    z = out[:int(ol.item())].cpu().numpy().tobytes()
+    for zz in (z, zlib.compress(_text(200000, 90), 6), _zfixed(_text(300000, 91))):
+        cap = 1 << 21
+        zin = torch.frombuffer(bytearray(zz + bytes(64)), dtype=torch.uint8).cuda().reshape(1, -1)
+        rc, ref = oracle.inflate(zz, out_cap=cap)
+        for flags in (0, 128):
+            o, l, s_ = engine.inflate_batch(zin, in_len=len(zz), out_pitch=cap, flags=flags)
+            assert int(s_.item()) == rc and o[0, :int(l.item())].cpu().numpy().tobytes() == ref, (len(zz), flags)
+    assert engine.inflate_bytes(z, out_cap=1 << 21) == (0, d[: d.numel() - 16].cpu().numpy().tobytes())      # (inflate_bytes sets the hint itself: it holds the bytes)
+
+
 def test_any_block_types_give_ups_and_bad_streams(engine, oracle):
     """what the chain for any block types hands to the serial decoder, and what is wrong with a stream: a LONG fixed block behind a
     dynamic one (followed serially only up to 16 pieces), a stream that starts with a fixed block and goes on with dynamic ones, damaged
