@@ -130,10 +130,12 @@ __device__ __forceinline__ View view(const Args& a) {
     uint8_t* w = a.ws + (size_t)s * a.stride;
     v.ctl = reinterpret_cast<uint32_t*>(w);
     v.pb = a.pb;
-    // the gate: a stream that is ONE fixed block is the other chain's (hdlz_inflate_par.hip: one_fixed_block -- the same test on the same
-    // byte, so the two chains need nothing from each other and run side by side); this one is only launched for the default build's flags
+    // the gate: a stream that STARTS with a fixed block is the other chain's (hdlz_inflate_par.hip: one_fixed_block -- the same test on
+    // the same byte, so the two chains need nothing from each other and run side by side; it also takes streams of SEVERAL fixed blocks,
+    // and gives a fixed block followed by blocks of other types to the serial decoder); this one is only launched for the default
+    // build's flags
     const uint32_t hdr = v.zn >= 5u ? (uint32_t)v.z[2] : 0u;
-    v.run = v.zn >= 5u && !((hdr & 1u) != 0u && ((hdr >> 1) & 3u) == 1u) && v.ctl[C_FALLBACK] == 0u;
+    v.run = v.zn >= 5u && ((hdr >> 1) & 3u) != 1u && v.ctl[C_FALLBACK] == 0u;
     v.cand = at<uint32_t>(w, a.o_cand); v.blk = at<Blk>(w, a.o_blk); v.blen = at<uint8_t>(w, a.o_blen); v.shdr = at<uint32_t>(w, a.o_shdr);
     v.spay = at<uint32_t>(w, a.o_spay); v.sidx = at<uint32_t>(w, a.o_sidx); v.tab = at<Tab>(w, a.o_tab); v.owner = at<uint16_t>(w, a.o_owner);
     v.map = at<uint32_t>(w, a.o_map); v.pent = at<uint8_t>(w, a.o_pent); v.prel = at<uint32_t>(w, a.o_prel); v.pnode = at<uint16_t>(w, a.o_pnode);

@@ -17,7 +17,7 @@ constexpr uint32_t FIRST_BIT = 19;            // 2 zlib header bytes, BFINAL, BT
 constexpr uint32_t X_EOB = 0x40, X_BAD = 0x80;
 constexpr uint32_t SUB = 4;                   // sub-pieces per piece: the granularity of the real decode and the emit (k_par_spec)
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-enum { C_FALLBACK = 0, C_NUSED = 1, C_TOTAL = 2, C_OK = 3, C_MARK = 4, C_FNUSED = 5, C_NCHAIN = 6,
+enum { C_FALLBACK = 0, C_NUSED = 1, C_TOTAL = 2, C_OK = 3, C_MARK = 4, C_FNUSED = 5, C_NCHAIN = 6, C_NCROSS = 36, C_FAILF = 37,
        C_NOTFIXED = 7,         // the stream is not ONE fixed block: the gate of the chain for any block types (hdlz_inflate_any.hip)
        C_PASS0 = 8, C_ANY0 = 40 /* .. 63: that chain's own counters */, C_WORDS = 64 };
 
@@ -51,6 +51,8 @@ struct ParArgs {
     uint32_t* mnb32;            // [nchunks][SUB-1][32]  bytes of the tokens that start in front of that boundary
     uint32_t cnu;               // the control word that holds the number of pieces in use at THIS granularity (C_NUSED / C_FNUSED)
     uint32_t* mext;             // [nchunks]  bytes from a piece's first output byte to behind its LAST marker (0: it has none)
+    uint32_t* cross;            // [MAXCROSS][4]  the end-of-block codes the real decode passed: bit, output position, sub-piece, token index | header << 24 | goes on << 27
+    uint32_t* nfail;            // [nchunks * sub]  token index of a sub-piece's first failed check (NONE: none)
     // SEVERAL streams in the same launches (round 5): blockIdx.y is the stream; stream s reads z + s * in_pitch, writes out + s * out_pitch,
     // out_len[s], status[s], and owns the scratch ws_stride bytes behind stream s - 1's (every array above, same layout)
     uint64_t in_pitch, out_pitch;
@@ -59,6 +61,7 @@ struct ParArgs {
     size_t ws_stride;
     uint32_t batch;             // != 0: a stream the path gives up on is FLAGGED for the serial pass (status HDLZ_E_DYNAMIC_UNSUPPORTED)
 };
+constexpr uint32_t MAXCROSS = 4096;           // end-of-block codes (blocks) of a stream of fixed blocks the chain can list
 constexpr uint32_t TOK_LIT = 0x80000000u;     // a token: TOK_LIT | byte, or length | distance << 9
 __host__ __device__ inline uint32_t tmax_of(uint32_t chbits) { return chbits / 8u + 2u; }      // fixed blocks: the shortest token is 8 bits long
 constexpr uint32_t HOPS = 256;                // marker chain steps per pass of k_par_jump

@@ -20,7 +20,10 @@
 //                    (markers are copied like bytes);
 //   4. k_par_jump    pointer jumping over the markers IN PLACE: src[p] <- up to HOPS steps along its chain, until the source is a byte
 //                    (one launch per pass, log_HOPS(pieces) + 1 passes at most; a pass with nothing left returns at once).
-// Anything else -- another block type, more than one block, a failed check (NO EOF, bad symbol, bad distance, capacity) -- sets
+//   3'. k_par_ends   (round 6) streams of SEVERAL fixed blocks: the chains pass "end-of-block + next fixed header" like a token; the
+//                    true end is the first listed end-of-block code of a block whose BFINAL was set (see one_fixed_block below);
+// Anything else -- a block of another type (a stream that does not even start with a fixed block: hdlz_inflate_any.hip), a failed check
+// (NO EOF, bad symbol, bad distance, capacity) -- sets
 // a fallback flag on the device and k_inflate_dyn redoes the stream from its first byte (it is launched behind the chain and
 // returns at once otherwise): status words and bytes are those of the serial decoder by construction, the parallel path
 // only ever reports HDLZ_OK.  Scratch (stream-ordered, from the library's own pool): ~1.6 KB per piece (the maps of the 32 offsets, of the sub-boundaries and of the
@@ -72,6 +75,7 @@ __device__ __forceinline__ ParArgs of_stream(ParArgs a) {
     shift_ptr(a.ctl, d); shift_ptr(a.exit8, d); shift_ptr(a.nb32, d); shift_ptr(a.entry8, d); shift_ptr(a.opos, d);
     shift_ptr(a.gexit8, d); shift_ptr(a.gstop8, d); shift_ptr(a.gnb32, d); shift_ptr(a.gentry8, d); shift_ptr(a.gopos, d);
     shift_ptr(a.tokens, d); shift_ptr(a.ntok, d); shift_ptr(a.srcA, d); shift_ptr(a.mexit8, d); shift_ptr(a.mnb32, d); shift_ptr(a.mext, d);
+    shift_ptr(a.cross, d); shift_ptr(a.nfail, d);
     return a;
 }
 
@@ -93,15 +97,26 @@ __device__ __forceinline__ uint64_t bits_at(const uint32_t* win, uint32_t b_c, u
     return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
 }
 
-// the stream must be one fixed block (or be read as one: the DYNAMIC=False / ONEBLOCK builds).  k_par_scan_top gives the verdict (the
-// fallback flag); the kernels in front of it only SKIP such a stream -- a batch of small dynamic-tree streams must not pay a speculative
-// fixed-Huffman decode of every stream before the serial pass takes them
-__device__ __forceinline__ bool one_fixed_block(const ParArgs& a) {
+// The stream must START with a fixed block (or be read as fixed blocks: the DYNAMIC=False build) for this chain of kernels; round 6: it
+// may go on with MORE fixed blocks -- what zlib's Z_FIXED strategy writes for anything beyond ~16 K symbols, what the DYNAMIC=False build
+// makes of every stream (deflate.py:1540-1548 EOB -> HEADER, :677-685, :724-732).  An end-of-block code followed by the header of another
+// fixed block is one more token of the chains -- 7 + 3 bits, no bytes -- WHATEVER the block's BFINAL was: a speculative chain does not know
+// it.  So the chain of pieces runs through the true end of the stream into the trailer bytes behind it (and ends there, "bad" or at an
+// end-of-block code that nothing fixed follows); the real decode (k_par_tokens) lists every end-of-block code it passes, and k_par_ends
+// finds the first one that ends a block whose BFINAL was set: the true end, the total length; what lies behind it is cut off.
+// k_par_scan_top gives the first verdict (not this chain's stream at all); the kernels in front of it only SKIP such a stream -- a batch
+// of small dynamic-tree streams must not pay a speculative fixed-Huffman decode of every stream before another path takes them.
+__device__ __forceinline__ bool one_fixed_block(const ParArgs& a) {           // (the name of rounds 3..5: a stream that starts with a fixed block)
     const uint32_t hdr = (a.zn >= 5u && a.zn != 0xFFFFFFFFu) ? (uint32_t)a.z[2] : 0u;
     const bool fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) || ((hdr >> 1) & 3u) == 1u;
-    const bool last = (a.flags & HDLZ_INFLATE_ONEBLOCK) || (hdr & 1u);
-    return a.zn >= 5u && a.zn != 0xFFFFFFFFu && fixed && last;
+    return a.zn >= 5u && a.zn != 0xFFFFFFFFu && fixed;
 }
+// what follows an end-of-block code: 0 = the chain ends there (the ONEBLOCK build: the stream ends with its first block), 1 = it goes on if
+// the next header says BTYPE = 01, 2 = it goes on (the DYNAMIC=False build reads every block as fixed)
+__device__ __forceinline__ uint32_t eob_mode(const ParArgs& a) {
+    return (a.flags & HDLZ_INFLATE_ONEBLOCK) ? 0u : (a.flags & HDLZ_INFLATE_ASSUME_FIXED) ? 2u : 1u;
+}
+__device__ __forceinline__ bool eob_goes_on(uint32_t mode, uint32_t hdr3) { return mode == 2u || (mode == 1u && ((hdr3 >> 1) & 3u) == 1u); }
 
 // ---- 1. speculative decode: lane (piece, offset)
 template <bool SUBMAPS>
@@ -198,7 +213,7 @@ __device__ __forceinline__ Chains of_stream(Chains ch, size_t ws_stride) {
 
 // one token of a chain, lengths and byte counts only, branch-free (see k_par_spec); x = the next 32 stream bits
 __device__ __forceinline__ void spec_token(uint32_t x, const uint32_t* lit, const uint32_t* dst, uint32_t& pos, uint32_t& nbytes,
-                                           uint32_t& exitc, bool& run, uint32_t& used_out) {
+                                           uint32_t& exitc, bool& run, uint32_t& used_out, uint32_t emode) {
     const uint32_t e0 = lit[x & 511u];
     const uint32_t nb = e0 & 15u, type = (e0 >> 13) & 3u, leb = (e0 >> 25) & 7u, lbase = (e0 >> 16) & 0x1FFu;
     const uint32_t y = x >> nb;
@@ -209,9 +224,11 @@ __device__ __forceinline__ void spec_token(uint32_t x, const uint32_t* lit, cons
     const uint32_t deb = max(dc >> 1, 1u) - 1u;
     const bool islit = type == (uint32_t)T_LIT;
     const bool bad = (nb == 0u) | (type == (uint32_t)T_BAD) | ((type == (uint32_t)T_LEN) & (dc >= 30u));
-    const bool eob = type == (uint32_t)T_EOB;
-    const uint32_t used = islit ? nb : nb + leb + 5u + deb;
-    const uint32_t made = islit ? 1u : tl;
+    const bool iseob = type == (uint32_t)T_EOB;
+    const bool on = iseob & eob_goes_on(emode, (x >> 7) & 7u);        // the end-of-block code + the next fixed block's header: 10 bits, no bytes
+    const bool eob = iseob & !on;
+    const uint32_t used = on ? 10u : islit ? nb : nb + leb + 5u + deb;
+    const uint32_t made = on ? 0u : islit ? 1u : tl;
     const bool adv = !(bad | eob);
     exitc = bad ? X_BAD : eob ? X_EOB : exitc;
     used_out = adv ? used : 0u;
@@ -226,6 +243,7 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a_, Chains
     const ParArgs a = of_stream(a_);
     const Chains ch = of_stream(ch_, a_.ws_stride);
     if (!one_fixed_block(a)) return;
+    const uint32_t emode = eob_mode(a);
     __shared__ uint32_t lit[512], dst[32], win[HEAD_WAVES][2][HEAD_BITS / 32 + 8], first[HEAD_WAVES][2][32], slotof[HEAD_WAVES][2][32];
     __shared__ uint32_t wcount[HEAD_WAVES], wbase[HEAD_WAVES];
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u, half = lane >> 5, e = lane & 31u;
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a_, Chains
     while (ballot64(run && pos < hb) != 0ull) {
         if (run && pos < hb) {
             const uint32_t rel = pos - bit0;
-            spec_token(__builtin_amdgcn_alignbit(w_[(rel >> 5) + 1u], w_[rel >> 5], rel), lit, dst, pos, nbytes, exitc, run, used);
+            spec_token(__builtin_amdgcn_alignbit(w_[(rel >> 5) + 1u], w_[rel >> 5], rel), lit, dst, pos, nbytes, exitc, run, used, emode);
         }
     }
     const uint32_t key = (pos - hb) & 31u;                 // (a token is at most 32 bits long)
@@ -285,6 +303,7 @@ __global__ __launch_bounds__(64) void k_par_tail(ParArgs a_, Chains ch_) {
     const ParArgs a = of_stream(a_);
     const Chains ch = of_stream(ch_, a_.ws_stride);
     if (!one_fixed_block(a)) return;
+    const uint32_t emode = eob_mode(a);
     __shared__ uint32_t lit[512], dst[32];
     const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
     const uint32_t nchain = a.ctl[C_NCHAIN];
@@ -308,7 +327,7 @@ __global__ __launch_bounds__(64) void k_par_tail(ParArgs a_, Chains ch_) {
         while (ballot64(run && pos < bound) != 0ull) {
             if (run && pos < bound) {
                 if (bc <= 32u) { bb |= (uint64_t)nxt << bc; bc += 32u; ip += 4u; nxt = tok::load32(a.z, ip, a.zn); }
-                spec_token((uint32_t)bb, lit, dst, pos, nbytes, exitc, run, used);
+                spec_token((uint32_t)bb, lit, dst, pos, nbytes, exitc, run, used, emode);
                 bb >>= used; bc -= used;
             }
         }
@@ -380,7 +399,7 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a_) {
     __shared__ __attribute__((aligned(16))) uint8_t stp[GROUP * 32];
     __shared__ uint8_t ent[GROUP];
     __shared__ uint32_t op[GROUP];
-    __shared__ uint32_t sh_stop, sh_e, sh_bad, sh_nused, sh_cnt;
+    __shared__ uint32_t sh_stop, sh_e, sh_bad, sh_nused, sh_cnt;          // (sh_bad: why the chain of pieces ended -- of no consequence since round 6)
     __shared__ uint64_t sh_acc;
     __shared__ uint8_t pathb[8][32][8], segmap[8][32], segstop[8][32], segent[8];
     const uint32_t lane = threadIdx.x;                     // (256 threads: staging, and 8 segments x 32 entry offsets for the walk)
@@ -447,7 +466,10 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a_) {
             const uint64_t before = sh_acc + incl - mine;
             if (lane < walked) op[lane] = (uint32_t)before;
             const bool over = lane < walked && before + mine > 0xFFFFFFFFull;
-            if (ballot64(over) != 0ull && lane == 0u) { sh_stop = 1u; sh_bad = 1u; }
+            if (ballot64(over) != 0ull && lane == 0u) {            // positions beyond 2^32 (only behind the true end, or the stream is not decodable here)
+                const uint32_t fo = (uint32_t)__builtin_ctzll(ballot64(over));
+                if (sh_stop == 0u || (base + fo) * GROUP < sh_nused) { sh_stop = 1u; sh_bad = 1u; sh_nused = (base + fo) * GROUP; }
+            }
             if (lane == 63u) sh_acc += incl;
         }
         __syncthreads();
@@ -455,10 +477,11 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a_) {
         __syncthreads();
     }
     if (lane == 0u) {
-        const bool good = sh_stop != 0u && sh_bad == 0u && sh_acc <= (uint64_t)a.cap && sh_acc <= (uint64_t)a.srcn;
-        a.ctl[C_NUSED] = sh_nused;
-        a.ctl[C_TOTAL] = (uint32_t)sh_acc;
-        if (!good) a.ctl[C_FALLBACK] = 1u;
+        // (round 6) where the chain of pieces ends is NOT where the stream ends: it runs through the true end into the trailer (see
+        // one_fixed_block); the pieces up to there are decoded, k_par_ends finds the true end among the end-of-block codes and gives the
+        // verdict.  A chain that never stopped (garbage up to the last piece): all pieces.
+        a.ctl[C_NUSED] = sh_stop != 0u ? sh_nused : a.nchunks;
+        a.ctl[C_TOTAL] = 0u;
     }
 }
 __global__ __launch_bounds__(64) void k_par_scan_pieces(ParArgs a_, uint8_t* fentry8, uint32_t* fopos) {
@@ -518,6 +541,7 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a_) {
     __syncthreads();
     const uint32_t c = c0 + lane;
     const bool have = c < nused;
+    const uint32_t emode = eob_mode(a);
     const int32_t isize = (int32_t)a.zn - 1;              // deflate.py:605
     const uint32_t obsize = a.obsize ? a.obsize : 32768u;
     const uint32_t b_c = FIRST_BIT + c * a.chbits, end = b_c + a.chbits;
@@ -543,7 +567,11 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a_) {
     // every path anyway.  The reference's checks (deflate.py:1409-1445, :1519-1591, :1600) are all evaluated; WHICH of them failed does
     // not matter here -- any failure hands the stream to the serial decoder, which reports the reference's status in the reference's
     // order.  A token is at most 32 bits long: the low dword of the bit buffer is all a step looks at.
-    bool run = have, bad = false;
+    // (round 6) an end-of-block code is LISTED -- bit, output position, sub-piece, token index, the three header bits behind it -- and, when
+    // another fixed block follows, passed like a token of 10 bits; a failed check is recorded per sub-piece (nfail: the token index), not
+    // as the stream's verdict: this lane may be decoding the trailer behind the true end.  k_par_ends sorts it out.
+    bool run = have;
+    uint32_t nfail = NONE;
     while (ballot64(run) != 0ull) {
         if (run) {
             if (bc <= 32u) {
@@ -567,14 +595,67 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a_) {
             f |= !iseob & ((uint64_t)P + made > a.cap);                                           // capacity
             f |= islen & ((code - 257u >= 29u) | (dc >= 30u) | (D > P) | (D > obsize) |           // BAD_SYMBOL, BAD_DISTANCE, D8
                           ((int32_t)((pos + used) >> 3) >= isize - 2));                           // COPY hold (deflate.py:1600)
-            const bool go = !(f | iseob);                                                         // (D6: EOB ends the stream)
+            const bool go = !(f | iseob);
+            bool stop = f;
             if (go) { tk[n] = islit ? (TOK_LIT | code) : (tl | (D << 9)); n++; P += made; pos += used; bb >>= used; bc -= used; }
-            bad |= f;
-            run = go && pos < end;
+            else if (!f) {                                                                        // an end-of-block code (D6)
+                const uint32_t hdr3 = (x >> 7) & 7u;
+                const bool on = eob_goes_on(emode, hdr3);
+                const uint32_t k = atomicAdd(&a.ctl[C_NCROSS], 1u);
+                if (k < MAXCROSS) { uint32_t* cr = a.cross + 4u * k; cr[0] = pos; cr[1] = P; cr[2] = c; cr[3] = n | (hdr3 << 24) | (on ? 1u << 27 : 0u); }
+                if (on) { pos += 10u; bb >>= 10; bc -= 10u; }
+                else stop = true;
+            }
+            if (f) { nfail = n; atomicMax(&a.ctl[C_FAILF], ~c); }                                  // (rare: the lowest failing sub-piece, as ~index: 0 = none)
+            run = !stop && pos < end;
         }
     }
-    if (have) a.ntok[c] = n;
-    if (ballot64(bad) != 0ull && lane == 0u) atomicExch(&a.ctl[C_FALLBACK], 1u);
+    if (have) { a.ntok[c] = n; a.nfail[c] = nfail; }
+}
+
+// ---- 3a'. the true end of the stream: the first end-of-block code, in stream order, that ends a block whose BFINAL was set.  One
+// workgroup: the listed codes ranked by bit position, one thread walks them with the BFINAL state (the stream's first header, then the
+// header behind every code that is passed); everything behind the end is cut off (pieces, sub-pieces, the end sub-piece's tokens); a
+// check that failed IN FRONT of the end -- or a block of another type, or no end at all -- is the fallback
+__global__ __launch_bounds__(256) void k_par_ends(ParArgs a_) {
+    const ParArgs a = of_stream(a_);
+    __shared__ uint32_t spos[MAXCROSS], sw3[MAXCROSS];
+    __shared__ uint32_t s_end, s_bad;
+    const uint32_t tid = threadIdx.x;
+    if (a.ctl[C_FALLBACK] != 0u) return;
+    const uint32_t n = a.ctl[C_NCROSS];
+    if (n > MAXCROSS || n == 0u) { if (tid == 0u) a.ctl[C_FALLBACK] = 1u; return; }      // (more blocks than the list holds / no end-of-block code at all)
+    if (tid == 0u) { s_end = NONE; s_bad = 0u; }
+    for (uint32_t k = tid; k < n; k += 256u) {                      // rank by position (all distinct)
+        const uint32_t p = a.cross[4u * k];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n; j++) r += a.cross[4u * j] < p ? 1u : 0u;
+        spos[r] = k; sw3[r] = a.cross[4u * k + 3u];
+    }
+    __syncthreads();
+    if (tid == 0u) {
+        uint32_t fin = ((uint32_t)a.z[2] & 1u) | ((a.flags & HDLZ_INFLATE_ONEBLOCK) ? 1u : 0u);
+        for (uint32_t r = 0; r < n; r++) {
+            const uint32_t w3 = sw3[r];
+            if (fin) { s_end = spos[r]; break; }
+            if (!((w3 >> 27) & 1u)) { s_bad = 1u; break; }          // the stream goes on with a block that is not fixed
+            fin = (w3 >> 24) & 1u;
+        }
+    }
+    __syncthreads();
+    const uint32_t ke = s_end;
+    if (ke == NONE || s_bad) { if (tid == 0u) a.ctl[C_FALLBACK] = 1u; return; }
+    const uint32_t* cr = a.cross + 4u * ke;
+    const uint32_t f_end = cr[2], n_end = cr[3] & 0xFFFFFFu, total = cr[1];
+    if (f_end >= a.nchunks * a.sub || n_end > a.tcap) { if (tid == 0u) a.ctl[C_FALLBACK] = 1u; return; }      // (cannot happen)
+    if (tid == 0u) {
+        const uint32_t fm = a.ctl[C_FAILF], failmin = fm ? ~fm : NONE;          // the lowest sub-piece with a failed check
+        if (failmin < f_end || a.nfail[f_end] < n_end || total > a.cap || total > a.srcn) { a.ctl[C_FALLBACK] = 1u; return; }
+        a.ctl[C_TOTAL] = total;
+        a.ctl[C_NUSED] = f_end / a.sub + 1u;
+        a.ctl[C_FNUSED] = f_end + 1u;
+        a.ntok[f_end] = n_end;
+    }
 }
 
 // ---- 3b. the bytes: one wave per piece, 64 tokens at a time.  A wave scan gives every token its output position; then the batch is
@@ -829,7 +910,7 @@ struct Layout {
     uint32_t chbits, nchunks, sub, ngroups;
     uint64_t cap64, srcn;
     size_t o_ctl, o_ex, o_nb, o_en, o_op, o_gx, o_gs, o_gn, o_ge, o_go, o_mx, o_mn, o_fe, o_fo, o_tk, o_nt, o_sa, o_me, o_rp, o_cp, o_cx, o_cn,
-           o_cmx, o_cmn, o_any, any_bytes, stride;
+           o_cmx, o_cmn, o_cr, o_nf, o_any, any_bytes, stride;
     bool ok;
 };
 static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch, uint32_t flags) {
@@ -860,6 +941,7 @@ static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch, uint32_t
     L.o_me = take((size_t)nchunks * 4u);
     L.o_rp = take((size_t)nchunks * 128u); L.o_cp = take((size_t)nchunks * 128u); L.o_cx = take((size_t)nchunks * 32u);
     L.o_cn = take((size_t)nchunks * 128u); L.o_cmx = take((size_t)nchunks * 32u * (sub - 1u)); L.o_cmn = take((size_t)nchunks * 128u * (sub - 1u));
+    L.o_cr = take((size_t)MAXCROSS * 16u); L.o_nf = take((size_t)nchunks * sub * 4u);
     // the chain for any block types: its own arrays behind these (it shares the marker words: one of the two chains writes them)
     L.any_bytes = any_work_bytes(zn, out_pitch, flags);
     L.o_any = take(L.any_bytes);
@@ -961,6 +1043,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                   reinterpret_cast<uint32_t*>(ws + o_go), reinterpret_cast<uint32_t*>(ws + o_tk), tmax_of(chbits / sub),
                   reinterpret_cast<uint32_t*>(ws + o_nt), reinterpret_cast<uint32_t*>(ws + o_sa), sub, ws + o_mx,
                   reinterpret_cast<uint32_t*>(ws + o_mn), (uint32_t)C_NUSED, reinterpret_cast<uint32_t*>(ws + o_me),
+                  reinterpret_cast<uint32_t*>(ws + L.o_cr), reinterpret_cast<uint32_t*>(ws + L.o_nf),
                   a.in_pitch, a.out_pitch, a.in_off, stride, nstr > 1u ? 1u : 0u};
         // fork: the chain for any block types on the side stream, beside this one
         const uint32_t* actl = nullptr;
@@ -1002,6 +1085,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
         if (pf.chbits <= CH_BITS_MAX / 2u)
             hipLaunchKernelGGL(k_par_tokens<true>, dim3((pf.nchunks + 63u) / 64u, nstr), dim3(64), 256u * (pf.chbits / 32u + 6u), stream, pf);
         else hipLaunchKernelGGL(k_par_tokens<false>, dim3((pf.nchunks + 63u) / 64u, nstr), dim3(64), 0, stream, pf);
+        hipLaunchKernelGGL(k_par_ends, dim3(1, nstr), dim3(256), 0, stream, p);
         ParArgs pe = p;                                                 // the emit: pieces, reading the sub-pieces' token lists
         pe.tokens = pf.tokens; pe.ntok = pf.ntok;
         hipLaunchKernelGGL(k_par_emit<false>, dim3(nchunks, nstr), dim3(64), 0, stream, pe);

@@ -345,6 +345,39 @@ def test_any_block_types_whole_gpu(engine, oracle):
         assert t_par * 5 < t_wave, (name, len(z), t_par, t_wave)
 
 
+def test_several_fixed_blocks_whole_gpu(engine, oracle):
+    """round 6: a stream of SEVERAL fixed blocks (zlib's Z_FIXED strategy closes a block every 16 K symbols; the DYNAMIC=False build reads
+    every block as fixed) takes the fixed-block chain: an end-of-block code + the next fixed header is passed like a token, the true end
+    is the first end-of-block code of a block whose BFINAL was set (k_par_ends).  Against the oracle, under the default flags and the
+    reference's build variants; the chain must have taken them (>= 5x one wave).  A stored block between fixed ones (a full flush), a
+    cut stream, damaged streams: the serial decoder's answers."""
+    big = _zfixed(_text(3000000, 95))                                          # ~60 fixed blocks
+    assert (big[2] & 7) == 2 and len(big) > 1 << 20                            # BFINAL = 0, BTYPE = 1: more blocks follow
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+    flushed = co.compress(_text(400000, 96)) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(_text(400000, 97)) + co.flush()
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+    synced = co.compress(_text(300000, 98)) + co.flush(zlib.Z_PARTIAL_FLUSH) + co.compress(_text(300000, 99)) + co.flush()     # an EMPTY fixed block in between
+    r = random.Random(9)
+    cases = [big, synced, flushed, big[: len(big) // 2], big[:-2]]
+    for _ in range(6):
+        zb = bytearray(big)
+        zb[r.randrange(2, len(zb))] ^= 1 << r.randrange(8)
+        cases.append(bytes(zb))
+    for k, z in enumerate(cases):
+        for flags, obsize in ((0, 0), (1, 0), (8, 0), (9, 0), (0, 1024)):
+            _check(engine, oracle, z, 1 << 22, flags=flags, obsize=obsize)
+    for z in (big, synced):
+        want = zlib.decompress(z)
+        cap = (len(want) + 64 + 15) // 16 * 16
+        assert engine.inflate_bytes(z, out_cap=cap) == (0, want)
+        t_par, t_wave = _timed(engine, z, cap, 0), _timed(engine, z, cap, 4)
+        assert t_par * 5 < t_wave, (len(z), t_par, t_wave)
+    # capacity exactly the output size (the chain of pieces runs on into the trailer: that must not count)
+    want = zlib.decompress(big)
+    for cap in (len(want) // 16 * 16, (len(want) + 15) // 16 * 16, len(want) + 4096):
+        _check(engine, oracle, big, cap)
+
+
 def test_one_fixed_block_hint(engine, oracle):
     """HDLZ_INFLATE_ONE_FIXED_BLOCK (128): only the fixed-block chain is launched -- same results for what STARTC writes, and a stream of
     other block types given with the hint is still decoded (by the serial pass)"""

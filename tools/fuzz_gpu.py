@@ -79,7 +79,7 @@ def main():
                 return 1
             if (hs == 0).all() and B >= 1:          # ... and inflated straight from it (ragged input = the archive's offsets)
                 capa = (int(lens.max()) + 15) // 16 * 16 + 16
-                ab, abl, abs_ = eng.inflate_batch(arc, in_off=aoff, out_pitch=capa, flags=int(rng.choice([0, 0, 2, 4, 34, 64])),
+                ab, abl, abs_ = eng.inflate_batch(arc, in_off=aoff, out_pitch=capa, flags=int(rng.choice([0, 0, 2, 4, 64, 128])),
                                                   in_len=[None, int(hl.max()), max(1, int(hl.max()) // 2)][int(rng.integers(0, 3))])   # (the caller's bound on the lengths: none / right / too small)
                 torch.cuda.synchronize()
                 hb, hbl, hbs = ab.cpu().numpy(), abl.cpu().numpy(), abs_.cpu().numpy()
@@ -92,7 +92,7 @@ def main():
         okb = hs == 0
         if okb.any():
             cap = (int(lens.max()) + 15) // 16 * 16 + 16
-            back, bl, bs = eng.inflate_batch(out, out_pitch=cap, flags=int(rng.choice([0, 2, 2, 4, 34, 64, 64])))   # default / lane / wave mapping
+            back, bl, bs = eng.inflate_batch(out, out_pitch=cap, flags=int(rng.choice([0, 2, 2, 4, 128, 64, 64])))   # default / lane / wave mapping
             torch.cuda.synchronize()
             hb, hbl, hbs = back.cpu().numpy(), bl.cpu().numpy(), bs.cpu().numpy()
             for b in np.nonzero(okb)[0][: 4000]:
@@ -117,7 +117,7 @@ def main():
                 zd.append(bytes(zb_))
             zoff = np.concatenate([[0], np.cumsum([len(z) for z in zd])]).astype(np.int64)
             zflat = np.frombuffer(b"".join(zd) + bytes(64), dtype=np.uint8).copy()
-            fl_ = int(rng.choice([0, 2, 2, 4, 34, 64, 64])) | int(rng.choice([0, 1, 8, 9]))
+            fl_ = int(rng.choice([0, 2, 2, 4, 128, 64, 64])) | int(rng.choice([0, 1, 8, 9]))
             ob_ = int(rng.choice([0, 0, 512, 4096, 32768]))
             capd = (int(lens[selb].max()) + 300 + 15) // 16 * 16
             zb, zl, zst = eng.inflate_batch(torch.from_numpy(zflat).cuda(), in_off=torch.from_numpy(zoff).cuda(), out_pitch=capd, flags=fl_,
@@ -149,7 +149,7 @@ def main():
                 zflat = np.frombuffer(b"".join(zs) + bytes(64), dtype=np.uint8).copy()
                 cap = (int(lens[sel].max()) + 15) // 16 * 16 + 16
                 zb, zl, zst = eng.inflate_batch(torch.from_numpy(zflat).cuda(), in_off=torch.from_numpy(zoff).cuda(), out_pitch=cap,
-                                                   flags=int(rng.choice([0, 2, 2, 4, 34, 64, 64])))
+                                                   flags=int(rng.choice([0, 2, 2, 4, 128, 64, 64])))
                 torch.cuda.synchronize()
                 hb, hbl, hbs = zb.cpu().numpy(), zl.cpu().numpy(), zst.cpu().numpy()
                 for k, b in enumerate(sel):
@@ -167,7 +167,7 @@ def main():
                     zd.append(bytes(zb_))
                 zoff = np.concatenate([[0], np.cumsum([len(z) for z in zd])]).astype(np.int64)
                 zflat = np.frombuffer(b"".join(zd) + bytes(64), dtype=np.uint8).copy()
-                fl_ = int(rng.choice([0, 2, 2, 4, 34, 64, 64])) | (1 if rng.random() < 0.25 else 0)      # (now and then as the DYNAMIC=False build: every block decoded as fixed)
+                fl_ = int(rng.choice([0, 2, 2, 4, 128, 64, 64])) | (1 if rng.random() < 0.25 else 0)      # (now and then as the DYNAMIC=False build: every block decoded as fixed)
                 zb, zl, zst = eng.inflate_batch(torch.from_numpy(zflat).cuda(), in_off=torch.from_numpy(zoff).cuda(), out_pitch=cap, flags=fl_)
                 torch.cuda.synchronize()
                 hb, hbl, hbs = zb.cpu().numpy(), zl.cpu().numpy(), zst.cpu().numpy()
