@@ -201,7 +201,10 @@ hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int 
     const uint32_t Rb = (a.in_len + 31u) >> 5;
     const uint64_t G = 64u / Rb;
     uint64_t groups = (a.nblocks + G - 1u) / G;
-    uint64_t grid = (uint64_t)ncu * 256u;       // (see launch_compress: short-lived waves, short tail)
+#ifndef HDLZ_SMALL_GRID
+#define HDLZ_SMALL_GRID 256
+#endif
+    uint64_t grid = (uint64_t)ncu * HDLZ_SMALL_GRID;       // (see launch_compress: short-lived waves, short tail)
     if (grid > groups) grid = groups;
     const dim3 g((unsigned)grid), b(64);
     if (a.in_off) {

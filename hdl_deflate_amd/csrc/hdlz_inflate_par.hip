@@ -399,14 +399,14 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a_) {
     __shared__ __attribute__((aligned(16))) uint8_t stp[GROUP * 32];
     __shared__ uint8_t ent[GROUP];
     __shared__ uint32_t op[GROUP];
-    __shared__ uint32_t sh_stop, sh_e, sh_bad, sh_nused, sh_cnt;          // (sh_bad: why the chain of pieces ended -- of no consequence since round 6)
+    __shared__ uint32_t sh_stop, sh_e, sh_nused, sh_cnt;                  // (WHY the chain of pieces ended is of no consequence since round 6: k_par_ends)
     __shared__ uint64_t sh_acc;
     __shared__ uint8_t pathb[8][32][8], segmap[8][32], segstop[8][32], segent[8];
     const uint32_t lane = threadIdx.x;                     // (256 threads: staging, and 8 segments x 32 entry offsets for the walk)
     // the stream must be one fixed block (or be read as one: the DYNAMIC=False / ONEBLOCK builds)
     if (!one_fixed_block(a)) { if (lane == 0u) { a.ctl[C_FALLBACK] = 1u; a.ctl[C_NOTFIXED] = 1u; } return; }
     const uint32_t ngroups = (a.nchunks + GROUP - 1u) / GROUP;
-    if (lane == 0u) { sh_stop = 0; sh_e = 0; sh_bad = 0; sh_nused = 0; sh_acc = 0; }
+    if (lane == 0u) { sh_stop = 0; sh_e = 0; sh_nused = 0; sh_acc = 0; }
     __syncthreads();
     for (uint32_t base = 0; base < ngroups && sh_stop == 0u; base += GROUP) {
         const uint32_t cnt = min(GROUP, ngroups - base);
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a_) {
                 const uint32_t m = segmap[sg][e], sk = segstop[sg][e];
                 if (sk != 0xFFu) {
                     const uint32_t j = sg * 8u + sk;
-                    sh_stop = 1u; sh_bad = m & X_BAD; sh_nused = (base + j) * GROUP + stp[j * 32u + pathb[sg][e][sk]] + 1u;
+                    sh_stop = 1u; sh_nused = (base + j) * GROUP + stp[j * 32u + pathb[sg][e][sk]] + 1u;
                     walked = j + 1u;
                     break;
                 }
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a_) {
             const bool over = lane < walked && before + mine > 0xFFFFFFFFull;
             if (ballot64(over) != 0ull && lane == 0u) {            // positions beyond 2^32 (only behind the true end, or the stream is not decodable here)
                 const uint32_t fo = (uint32_t)__builtin_ctzll(ballot64(over));
-                if (sh_stop == 0u || (base + fo) * GROUP < sh_nused) { sh_stop = 1u; sh_bad = 1u; sh_nused = (base + fo) * GROUP; }
+                if (sh_stop == 0u || (base + fo) * GROUP < sh_nused) { sh_stop = 1u; sh_nused = (base + fo) * GROUP; }
             }
             if (lane == 63u) sh_acc += incl;
         }
@@ -824,7 +824,8 @@ __global__ __launch_bounds__(64) void k_par_jump(ParArgs a_, uint32_t pass) {
     if (ext == 0u) continue;
     const uint32_t p0 = a.opos[c];
     // What a walk from marker m found is kept for the piece's later bytes (a direct-mapped table in LDS, key and result in one 8-byte
-    // entry): the markers of a piece share few targets -- the bytes in front of it --, and in a run or a short period (zeros: EVERY
+    // entry -- written with ONE ds_write_b64 per lane: lanes of an instruction that hit the same slot are applied one after the other,
+    // whole, so a slot always holds one lane's pair (a reader only takes an entry whose key is its own marker)): the markers of a piece share few targets -- the bytes in front of it --, and in a run or a short period (zeros: EVERY
     // byte of every piece is a marker of the byte in front of the piece) they all share one to `period` of them: 64 MiB of zeros
     // 10.1 -> 1.6 ms, 256 MiB 36.5 -> 4.1 ms (profiles/r05_single_stream_inflate.txt).  (One wave per piece: its LDS accesses are in program order.)
     for (uint32_t k = threadIdx.x; k < 256u; k += 64u) memo[k] = ~0ull;          // (no marker is NONE)

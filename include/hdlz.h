@@ -128,7 +128,8 @@ int hdlz_compress_batch(const uint8_t* d_in, const uint64_t* d_in_off, uint64_t 
  * back-references may reach at most obsize bytes and a stored block's LEN is taken modulo
  * 2^floor(log2(obsize)) because the reference's `length` register is LOBSIZE bits wide
  * (deflate.py:329, :714).  obsize == 0 = RFC1951 behaviour (32 KiB history, 16-bit LEN).
- * Ragged input: in_len, if not 0, is the caller's UPPER BOUND on the stream lengths (the whole-GPU path sizes its pieces from it;
+ * Ragged input: in_len, if not 0, is the caller's UPPER BOUND on the stream lengths (the whole-GPU path sizes its pieces, its grids AND
+ * its scratch from it -- per stream, whatever the streams' real lengths: state a TIGHT bound, or 0 for batches of many short streams;
  * a stream longer than the bound is still decoded, by the serial pass).
  *
  * hdlz_inflate_batch_ws: the call with CALLER-OWNED scratch.  d_work: device memory, 256-byte aligned, work_bytes long, used only
