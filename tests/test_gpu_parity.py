@@ -1185,6 +1185,32 @@ def test_port_adapter_on_gpu_modes(engine):
         run_mode_flow(rec, engine)
 
 
+def test_port_startd_of_a_stock_zlib_stream_and_startc_back(engine):
+    """the reference's own use, at a size its default build handles (DYNAMIC=True, deflate.py:32): STARTD of ONE stock-zlib level-6 stream
+    through the ten ports -- 48 KB of dynamic-tree blocks: hdlz_inflate_any.hip on the whole GPU behind the adapter -- and STARTC of what
+    came out, on the same DUT, read back and inflated by stock zlib (test_deflate.py:115-286, the harness body of tests/port_harness.py)"""
+    import time
+    from test_port_protocol import make_dut, stream_leg, STARTC, STARTD
+    r = random.Random(21)
+    words = [bytes(r.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(r.randint(2, 9))) for _ in range(400)]
+    plain = bytearray()
+    while len(plain) < 120000:
+        plain += r.choice(words) + b" "
+    plain = bytes(plain[:120000])
+    z = zlib.compress(plain, 6)
+    assert len(z) >= 16384 and (z[2] >> 1) & 3 == 2                  # a dynamic first block: the chain for any block types
+    dut, s = make_dut(engine)
+    inf, total = stream_leg(dut, s, z, STARTD)
+    assert inf == plain and total == len(plain)
+    comp, total = stream_leg(dut, s, plain, STARTC)
+    assert total == len(comp) and zlib.decompress(comp) == plain
+    # ... and the engine call behind STARTD took the whole-GPU path: one wave needs ~10 ms for these 120 KB
+    st, got = engine.inflate_bytes(z)
+    t0 = time.time()
+    st, got = engine.inflate_bytes(z)
+    assert (st, got) == (0, plain) and time.time() - t0 < 0.006
+
+
 def test_inflate_oneblock_lowlut_builds_and_empty_distance_code(engine):
     """ONEBLOCK / LOWLUT reference builds (variants_vectors.json, oracle/gen_golden_r2.py) through both decoders; a dynamic
     block with an empty distance code (RFC1951 3.2.7) is accepted like zlib accepts it"""
