@@ -332,6 +332,11 @@ def test_any_block_types_whole_gpu(engine, oracle):
                                (_text(100000, 63), 1, zlib.Z_DEFAULT_STRATEGY), (b"x", 6, zlib.Z_FIXED)])[0]))
     streams.append(("a deflate stream inside stored blocks", _segments([(_text(100000, 64), 6, zlib.Z_DEFAULT_STRATEGY), (inner, 0, zlib.Z_DEFAULT_STRATEGY),
                                                                         (_text(100000, 65), 6, zlib.Z_DEFAULT_STRATEGY)])[0]))
+    # literal-dense data: ~6-bit codes, 340 tokens per 2048-bit piece -- more than one token list holds, EVERY piece continues in a second one
+    import base64
+    streams.append(("base64 (6-bit literals), 2048-bit pieces", zlib.compress(base64.b64encode(_rand(4800000, 66)), 6)))
+    streams.append(("float32 random walk", zlib.compress(np.cumsum(np.random.default_rng(67).normal(size=1200000)).astype(np.float32).tobytes(), 6)))
+    assert len(streams[-2][1]) >= 4 << 20
     for name, z in streams:
         want = zlib.decompress(z)
         cap = (len(want) + 64 + 15) // 16 * 16

@@ -81,4 +81,29 @@ if which in ("all", "big"):
     d = text(16 << 20, 9)
     allok &= run("text 16 MiB level 6", zlib.compress(d, 6), d)
     allok &= run("text 16 MiB level 1", zlib.compress(d, 1), d)
+if which in ("all", "kinds"):
+    # data of other compressibility: many short codes per piece (long token lists), long matches (few tokens, many bytes), sparse data
+    r = random.Random(77)
+    n = 16 << 20
+    def logs():
+        out = bytearray(); t = 1700000000
+        hosts = ["web-%02d" % i for i in range(12)]; paths = ["/api/v1/items/%d" % i for i in range(40)] + ["/index.html", "/static/app.js", "/health"]
+        while len(out) < n:
+            t += r.randint(0, 3)
+            out += ("%d %s GET %s %d %d \"Mozilla/5.0 (X11; Linux x86_64)\" rt=%.3f\n" % (t, r.choice(hosts), r.choice(paths), r.choice([200, 200, 200, 304, 404, 500]), r.randint(100, 90000), r.random())).encode()
+        return bytes(out[:n])
+    def dna():
+        return bytes(r.choice(b"ACGT") for _ in range(1 << 16)) * 4 + np.random.default_rng(3).choice(np.frombuffer(b"ACGT", dtype=np.uint8), n - (1 << 18)).tobytes()
+    def sparse():
+        a = np.zeros(n, dtype=np.uint8); idx = np.random.default_rng(4).integers(0, n, n // 64); a[idx] = np.random.default_rng(5).integers(1, 256, idx.size, dtype=np.uint8)
+        return a.tobytes()
+    def floats():
+        return np.cumsum(np.random.default_rng(6).normal(size=n // 4)).astype(np.float32).tobytes()
+    def b64():
+        import base64
+        return base64.b64encode(np.random.default_rng(8).integers(0, 256, n, dtype=np.uint8).tobytes())[:n]
+    for name, f in (("logs", logs), ("dna", dna), ("sparse", sparse), ("float32 walk", floats), ("base64", b64)):
+        d = f()
+        for lvl in (1, 6, 9):
+            allok &= run("%s 16 MiB level %d" % (name, lvl), zlib.compress(d, lvl), d)
 print("ALL OK" if allok else "FAILURES")
