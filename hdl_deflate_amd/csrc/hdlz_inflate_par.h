@@ -86,7 +86,7 @@ __host__ inline uint32_t passes_for(uint32_t nitems) {                 // chains
 // the chain for streams of any block types (hdlz_inflate_any.hip).  Scratch of ONE stream: any_work_bytes (0: not for this shape);
 // its kernels return at once for a stream that is one fixed block (the other chain's: the same test on the stream's third byte), and
 // leave their verdict in their own control words (C_FALLBACK / C_OK / C_TOTAL / C_MARK / C_PASS0 ..)
-size_t any_work_bytes(uint32_t in_len, uint64_t out_pitch, uint32_t flags);
+size_t any_work_bytes(uint32_t in_len, uint64_t out_pitch, uint32_t flags, uint32_t nstreams);
 // (ws: stream 0's scratch; ws_off / sa_off: where this chain's part and the marker words lie in it; its control words are the first
 //  par::C_WORDS words of its part -- read by k_par_finish)
 hipError_t launch_inflate_any(const InflateArgs& a, uint32_t nstr, uint8_t* ws, size_t ws_stride, size_t ws_off, size_t sa_off,

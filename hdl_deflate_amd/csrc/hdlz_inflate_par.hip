@@ -914,7 +914,8 @@ struct Layout {
            o_cmx, o_cmn, o_cr, o_nf, o_any, any_bytes, stride;
     bool ok;
 };
-static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch, uint32_t flags) {
+// (`batch`: the streams of the whole call when this launch is one GROUP of it -- the choice of chains is the call's, not the group's)
+static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch, uint32_t flags, uint32_t batch = 0) {
     Layout L;
     memset(&L, 0, sizeof(L));
     L.cap64 = out_pitch > 0xFFFFFE00ull ? 0xFFFFFE00ull : out_pitch;
@@ -944,7 +945,7 @@ static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch, uint32_t
     L.o_cn = take((size_t)nchunks * 128u); L.o_cmx = take((size_t)nchunks * 32u * (sub - 1u)); L.o_cmn = take((size_t)nchunks * 128u * (sub - 1u));
     L.o_cr = take((size_t)MAXCROSS * 16u); L.o_nf = take((size_t)nchunks * sub * 4u);
     // the chain for any block types: its own arrays behind these (it shares the marker words: one of the two chains writes them)
-    L.any_bytes = any_work_bytes(zn, out_pitch, flags);
+    L.any_bytes = any_work_bytes(zn, out_pitch, flags, batch ? batch : nstr);
     L.o_any = take(L.any_bytes);
     L.stride = off;
     L.ok = true;
@@ -975,13 +976,17 @@ static hipStream_t side_stream() {
     return side[dev];
 }
 
+static hipError_t launch_inflate_par_group(const InflateArgs& a, hipStream_t stream, bool* used, const Work& w, uint32_t batch);
 hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* used, const Work& w) {
+    return launch_inflate_par_group(a, stream, used, w, a.nstreams > 65535u ? 0u : (uint32_t)a.nstreams);
+}
+static hipError_t launch_inflate_par_group(const InflateArgs& a, hipStream_t stream, bool* used, const Work& w, uint32_t batch) {
     using namespace par;
     *used = false;
     const uint32_t zn = a.in_len;
     const uint32_t nstr = (uint32_t)a.nstreams;
     if (a.nstreams == 0 || a.nstreams > 65535u) return hipSuccess;
-    const Layout L = layout_of(zn, nstr, a.out_pitch, a.flags);
+    const Layout L = layout_of(zn, nstr, a.out_pitch, a.flags, batch);
     if (!L.ok) return hipSuccess;
     const uint64_t cap64 = L.cap64, srcn = L.srcn;
     const uint32_t chbits = L.chbits, nchunks = L.nchunks, sub = L.sub, ngroups = L.ngroups;
@@ -998,8 +1003,8 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
     if (nstr > 1u && stride * (size_t)nstr > BUDGET) {
         uint32_t gs = (uint32_t)(BUDGET / stride);
         // (a smaller group may be cut into smaller pieces with more lists per byte: shrink until the group's own layout fits)
-        while (gs > 1u && layout_of(zn, gs, a.out_pitch, a.flags).stride * (size_t)gs > BUDGET) gs = gs * 3u / 4u;
-        if (gs == 0u || layout_of(zn, gs, a.out_pitch, a.flags).stride * (size_t)gs > BUDGET) return hipSuccess;
+        while (gs > 1u && layout_of(zn, gs, a.out_pitch, a.flags, batch).stride * (size_t)gs > BUDGET) gs = gs * 3u / 4u;
+        if (gs == 0u || layout_of(zn, gs, a.out_pitch, a.flags, batch).stride * (size_t)gs > BUDGET) return hipSuccess;
         if (gs < nstr) {
             for (uint32_t s0 = 0; s0 < nstr; s0 += gs) {
                 InflateArgs g = a;
@@ -1010,7 +1015,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                 g.status = a.status + s0;
                 g.nstreams = nstr - s0 < gs ? nstr - s0 : gs;
                 // (the last, smaller group could be laid out with smaller pieces and need more per stream than fits)
-                if (layout_of(zn, (uint32_t)g.nstreams, a.out_pitch, a.flags).stride * (size_t)g.nstreams > BUDGET) {
+                if (layout_of(zn, (uint32_t)g.nstreams, a.out_pitch, a.flags, batch).stride * (size_t)g.nstreams > BUDGET) {
                     if (s0 == 0) return hipSuccess;
                     // hand the rest to the batch kernels: mark them as the chain's give-ups
                     hipLaunchKernelGGL(k_par_flag_rest, dim3((unsigned)((g.nstreams + 63u) / 64u)), dim3(64), 0, stream, g.out_len, g.status, (uint32_t)g.nstreams);
@@ -1020,7 +1025,7 @@ hipError_t launch_inflate_par(const InflateArgs& a, hipStream_t stream, bool* us
                     continue;
                 }
                 bool u = false;
-                const hipError_t eg = launch_inflate_par(g, stream, &u, w);
+                const hipError_t eg = launch_inflate_par_group(g, stream, &u, w, batch);
                 if (eg != hipSuccess) return eg;
                 // (a first group without scratch: the caller's batch kernels redo the whole batch, which is harmless)
                 if (!u) {

@@ -466,3 +466,31 @@ def test_any_block_types_in_batches_and_graphs(engine, oracle):
         g.replay()
         torch.cuda.synchronize()
         verify(bl, bs, "graph launch %d" % rep)
+
+
+def test_many_zlib_streams_keep_the_batch_kernels(engine, oracle):
+    """the chain for any block types inflates 7..9 GB/s of 48..64 KiB streams however many there are; a wave per stream needs ~90 us per
+    KiB of ONE stream: from ~550 such streams on the waves win (profiles/r06_any_batches.txt), so a call with more streams than
+    ANY_BATCH_MAX (512; 1024 for streams of 96 KiB and more) is decoded as before round 6.  600 stock-zlib streams of ~21 KB in one
+    call: results against the oracle / zlib, and the default mapping is not slower than 1.5x the wave-per-stream mapping (with the
+    chain it was 4 ms against 4.5 for 512 streams, 29 against 6.8 for 4096)"""
+    import torch
+    kinds = [zlib.compress(_text(64 << 10, 300 + k), 6) for k in range(6)]
+    n = 600
+    pitch = (max(len(z) for z in kinds) + 64 + 15) // 16 * 16
+    assert min(len(z) for z in kinds) >= 16384
+    host = np.zeros((n, pitch), np.uint8)
+    for k in range(n):
+        z = kinds[k % len(kinds)]
+        host[k, : len(z)] = np.frombuffer(z, np.uint8)
+    cap = (64 << 10) + 64
+    zin = torch.from_numpy(host).cuda()
+    back, bl, bs = engine.inflate_batch(zin, out_pitch=cap)
+    hb, hl, hs = back.cpu().numpy(), bl.cpu().numpy(), bs.cpu().numpy()
+    for k in range(len(kinds)):
+        rc, ref = oracle.inflate(host[k].tobytes(), out_cap=cap)
+        assert rc == 0 and ref == zlib.decompress(kinds[k])
+        for j in range(k, n, len(kinds)):
+            assert hs[j] == 0 and hb[j, : hl[j]].tobytes() == ref, j
+    t_auto, t_wave = _timed_batch(engine, zin, cap, 0), _timed_batch(engine, zin, cap, 4)
+    assert t_auto < 1.5 * t_wave, (t_auto, t_wave)

@@ -106,4 +106,40 @@ if which in ("all", "kinds"):
         d = f()
         for lvl in (1, 6, 9):
             allok &= run("%s 16 MiB level %d" % (name, lvl), zlib.compress(d, lvl), d)
+if which in ("batch",):
+    # batches of stock-zlib streams in ONE call (fixed pitch): the whole-GPU chains against a wave per stream
+    shapes = ((16, 1 << 20), (64, 1 << 20), (256, 1 << 20), (64, 256 << 10), (1024, 64 << 10), (16, 16 << 20))
+    if len(sys.argv) > 2 and sys.argv[2] == "sweep":
+        shapes = [(ns, n) for n in (48 << 10, 64 << 10, 256 << 10, 1 << 20) for ns in (64, 128, 256, 512, 1024, 2048, 4096) if ns * n <= (1 << 30)]
+    for nstr, n in shapes:
+        zs, wants = [], []
+        for k in range(min(nstr, 8)):
+            d = text(n, 100 + k) if k % 2 == 0 else make_blocks(n // 2048, 2048, "cpu", seed=10 + k).numpy().tobytes()
+            zs.append(zlib.compress(d, 6)); wants.append(d)
+        zmax = max(len(z) for z in zs)
+        pitch = (zmax + 64 + 15) // 16 * 16
+        cap = (n + 64 + 15) // 16 * 16
+        zin = torch.zeros((nstr, pitch), dtype=torch.uint8)
+        for s_ in range(nstr):
+            z = zs[s_ % len(zs)]
+            zin[s_, :len(z)] = torch.frombuffer(bytearray(z), dtype=torch.uint8)
+        zin = zin.cuda()
+        out = torch.zeros((nstr, cap), dtype=torch.uint8, device="cuda")
+        res = {}
+        for name, flags in (("auto", 0), ("wave", 4)):
+            wb = L.hdlz_inflate_work_bytes(nstr, zmax, cap, flags, 0)
+            work = torch.zeros(wb, dtype=torch.uint8, device="cuda")
+            ts = []
+            for _ in range(3 if name == "auto" else 1):
+                torch.cuda.synchronize(); t0 = time.time()
+                _, ol, st = eng.inflate_batch(zin, in_len=zmax, out_pitch=cap, out=out, flags=flags, work=work)
+                torch.cuda.synchronize(); ts.append(time.time() - t0)
+            ok = bool((st == 0).all()) and bool((ol == n).all())
+            for s_ in (0, 1, nstr - 1):
+                ok &= out[s_, :n].cpu().numpy().tobytes() == wants[s_ % len(zs)]
+            allok &= ok
+            res[name] = (min(ts), wb, ok)
+        print("%5d x %8d bytes (z <= %8d): auto %8.3f ms %8.1f GB/s scratch %7.1f MB %s | wave per stream %9.3f ms %s" % (
+            nstr, n, zmax, res["auto"][0] * 1e3, nstr * n / res["auto"][0] / 1e9, res["auto"][1] / 1e6, "OK" if res["auto"][2] else "BAD",
+            res["wave"][0] * 1e3, "OK" if res["wave"][2] else "BAD"), flush=True)
 print("ALL OK" if allok else "FAILURES")
