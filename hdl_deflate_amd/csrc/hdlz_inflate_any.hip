@@ -34,6 +34,8 @@
 // Whatever this chain cannot do -- more candidates, items or stored blocks than its lists hold, a fixed block of more than
 // FIX_MAX_BITS, a failed check, an inconsistency -- sets its fallback flag and the serial decoder (k_inflate_dyn) redoes the
 // stream: statuses and bytes are the serial decoder's by construction, this path only ever reports HDLZ_OK.
+// Whose stream: one that does NOT start with a fixed block (those are hdlz_inflate_par.hip's), or one that starts with a SHORT fixed block
+// followed by a block of another type (k_any_zero; view()).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -62,9 +64,10 @@ constexpr uint32_t OB = 12u, NBB = 30u - OB, NBM = (1u << NBB) - 1u, OFM = (1u <
 static_assert(PB_MAX + 15u <= OFM, "map entry fields");
 constexpr uint32_t LB = 11, DB = 9;           // bits of the two primary look-up tables
 constexpr uint32_t FIX_MAX_BITS = 16384;      // a fixed block behind a dynamic one is decoded by ONE lane: up to this many bits
+constexpr uint32_t FIRST_FIX_BITS = 4096;     // a FIRST block that is fixed: this chain's if it ends within so many bits and a block of another type follows (k_any_zero)
 constexpr uint32_t NO_OWNER = 0xFFFFu;
 constexpr uint32_t N_END = 0xFFFFFFFEu, N_BAD = 0xFFFFFFFFu;      // successor of a node: the stream ends / no valid successor
-enum { A_NCAND = par::C_ANY0, A_NBLK, A_NX, A_NS, A_OVER, A_WHY, A_NREQ, A_NREQP };       // this chain's counters in its control words; A_WHY: bits of W_* (diagnostics)
+enum { A_NCAND = par::C_ANY0, A_NBLK, A_NX, A_NS, A_OVER, A_WHY, A_NREQ, A_NREQP, A_OPEN };       // this chain's counters in its control words; A_WHY: bits of W_* (diagnostics)
 enum { W_OVER = 1, W_NODE = 2, W_NEXT = 4, W_CAP = 8, W_CYCLE = 16, W_ITEMS = 32, W_TOKEN = 64, W_TCAP = 128, W_WALK_OWNER = 256, W_WALK_MAP = 512,
        W_WALK_HDR = 1024, W_WALK_STORED = 2048, W_WALK_FIX = 4096, W_WALK_TOK = 8192, W_VERIFY = 16384 };
 
@@ -131,11 +134,13 @@ __device__ __forceinline__ View view(const Args& a) {
     v.ctl = reinterpret_cast<uint32_t*>(w);
     v.pb = a.pb;
     // the gate: a stream that STARTS with a fixed block is the other chain's (hdlz_inflate_par.hip: one_fixed_block -- the same test on
-    // the same byte, so the two chains need nothing from each other and run side by side; it also takes streams of SEVERAL fixed blocks,
-    // and gives a fixed block followed by blocks of other types to the serial decoder); this one is only launched for the default
-    // build's flags
+    // the same byte, so the two chains need nothing from each other and run side by side; it also takes streams of SEVERAL fixed
+    // blocks) -- unless that block is SHORT and a block of another type follows it (a header written and flushed in front of the data:
+    // zlib closes so small a block as a fixed one): the other chain gives those up at that block, k_any_zero opens this one
+    // (A_OPEN), and the walk from the stream's first header decodes the fixed block like one between dynamic blocks.  This chain is
+    // only launched for the default build's flags
     const uint32_t hdr = v.zn >= 5u ? (uint32_t)v.z[2] : 0u;
-    v.run = v.zn >= 5u && ((hdr >> 1) & 3u) != 1u && v.ctl[C_FALLBACK] == 0u;
+    v.run = v.zn >= 5u && (((hdr >> 1) & 3u) != 1u || v.ctl[A_OPEN] != 0u) && v.ctl[C_FALLBACK] == 0u;
     v.cand = at<uint32_t>(w, a.o_cand); v.blk = at<Blk>(w, a.o_blk); v.blen = at<uint8_t>(w, a.o_blen); v.shdr = at<uint32_t>(w, a.o_shdr);
     v.spay = at<uint32_t>(w, a.o_spay); v.sidx = at<uint32_t>(w, a.o_sidx); v.tab = at<Tab>(w, a.o_tab); v.owner = at<uint16_t>(w, a.o_owner);
     v.map = at<uint32_t>(w, a.o_map); v.pent = at<uint8_t>(w, a.o_pent); v.prel = at<uint32_t>(w, a.o_prel); v.pnode = at<uint16_t>(w, a.o_pnode);
@@ -1049,9 +1054,56 @@ __global__ __launch_bounds__(256) void k_any_stored(Args a) {
     }
 }
 
+// a stream whose FIRST block is fixed with more blocks behind it (BFINAL = 0): does that block end within FIRST_FIX_BITS, in front of a
+// stored or a dynamic block?  One lane reads the fixed code by its arithmetic (RFC 1951 3.2.6: 7 bits 256..279, 8 bits 0..143 and
+// 280..287, 9 bits 144..255; distances 5 bits) -- lengths only, nothing is produced or checked: whatever it gets wrong costs the
+// fallback (the real decode checks everything), never a byte
+__device__ bool short_fixed_block_first(const uint8_t* z, uint32_t zn) {
+    const uint32_t nbits = 8u * zn;
+    Bits rd;
+    rd.init(z, zn, 16u + 3u);
+    while (rd.pos < 16u + 3u + FIRST_FIX_BITS && rd.pos + 7u <= nbits) {
+        rd.refill();
+        const uint32_t r9 = __builtin_bitreverse32((uint32_t)rd.bb) >> 23;        // the next 9 bits as an MSB-first code
+        uint32_t sym, n;
+        if ((r9 >> 2) < 24u) { sym = 256u + (r9 >> 2); n = 7u; }
+        else if ((r9 >> 1) < 0xC0u) { sym = (r9 >> 1) - 0x30u; n = 8u; }
+        else if ((r9 >> 1) < 0xC8u) { sym = 280u + (r9 >> 1) - 0xC0u; n = 8u; }
+        else { sym = 144u + r9 - 0x190u; n = 9u; }
+        if (sym < 256u) { rd.take(n); continue; }
+        if (sym == 256u) {
+            rd.take(n);
+            if (rd.pos + 3u > nbits) return false;
+            rd.refill();
+            const uint32_t btype = ((uint32_t)rd.bb >> 1) & 3u;
+            return btype == 0u || btype == 2u;
+        }
+        if (sym > 285u) return false;
+        const uint32_t ls = sym - 257u, leb = (ls < 8u || ls == 28u) ? 0u : (ls >> 2) - 1u;
+        rd.take(n + leb);
+        rd.refill();
+        const uint32_t d = __builtin_bitreverse32((uint32_t)rd.bb) >> 27;
+        if (d > 29u) return false;
+        rd.take(5u + (d < 4u ? 0u : (d >> 1) - 1u));
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(64) void k_any_zero(Args a) {
-    uint32_t* ctl = reinterpret_cast<uint32_t*>(a.ws + (size_t)blockIdx.y * a.stride);
-    if (threadIdx.x < par::C_WORDS) ctl[threadIdx.x] = 0u;
+    const uint32_t s = blockIdx.y;
+    uint32_t* ctl = reinterpret_cast<uint32_t*>(a.ws + (size_t)s * a.stride);
+    uint32_t open = 0u;
+    if (threadIdx.x == 0u) {
+        const uint8_t* z;
+        uint32_t zn;
+        if (a.in_off) {
+            const uint64_t o0 = a.in_off[s], n64 = a.in_off[s + 1u] - o0;
+            z = a.z + o0; zn = n64 > (uint64_t)a.zn ? 0u : (uint32_t)n64;
+        } else { z = a.z + (uint64_t)s * a.in_pitch; zn = a.zn; }
+        if (zn >= 5u && (z[2] & 7u) == 2u) open = short_fixed_block_first(z, zn) ? 1u : 0u;      // BFINAL = 0, BTYPE = 01
+    }
+    open = (uint32_t)__builtin_amdgcn_readfirstlane((int)open);
+    if (threadIdx.x < par::C_WORDS) ctl[threadIdx.x] = threadIdx.x == (uint32_t)A_OPEN ? open : 0u;
 }
 
 constexpr uint32_t ANY_MIN = 16384;           // streams below this stay with the serial decoder (the chain of launches costs ~0.1 ms)

@@ -867,7 +867,8 @@ __global__ __launch_bounds__(64) void k_par_finish(ParArgs a_, uint32_t passes, 
     const uint32_t left = a.ctl[C_MARK] == 0u ? 0u : a.ctl[C_PASS0 + passes - 1u];
     bool ok = a.ctl[C_FALLBACK] == 0u && left == 0u;
     uint32_t total = a.ctl[C_TOTAL];
-    if (!ok && actl && a.ctl[C_NOTFIXED] != 0u) {
+    // (the other chain's result: the stream was its from the first header on, or it opened for a short fixed block in front of other types)
+    if (!ok && actl) {
         actl = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(actl) + (size_t)blockIdx.y * a_.ws_stride);
         const uint32_t aleft = actl[C_MARK] == 0u ? 0u : actl[C_PASS0 + apasses - 1u];
         ok = actl[C_FALLBACK] == 0u && actl[C_OK] != 0u && aleft == 0u;

@@ -332,6 +332,13 @@ def test_any_block_types_whole_gpu(engine, oracle):
                                (_text(100000, 63), 1, zlib.Z_DEFAULT_STRATEGY), (b"x", 6, zlib.Z_FIXED)])[0]))
     streams.append(("a deflate stream inside stored blocks", _segments([(_text(100000, 64), 6, zlib.Z_DEFAULT_STRATEGY), (inner, 0, zlib.Z_DEFAULT_STRATEGY),
                                                                         (_text(100000, 65), 6, zlib.Z_DEFAULT_STRATEGY)])[0]))
+    # a short header written and flushed in front of the data: zlib closes so small a block as a FIXED one, then an empty stored block
+    # (the sync marker), then dynamic blocks -- the fixed-block chain gives the stream up at the second block, the other one opens for it
+    for k, head in enumerate((b"format=v1;name=whatever;fields=12\n", bytes(range(64)) * 3)):
+        co = zlib.compressobj(6)
+        z = co.compress(head) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(_text(500000, 71 + k)) + co.flush()
+        assert (z[2] & 7) == 2                                                  # BFINAL = 0, BTYPE = 01
+        streams.append(("short fixed block first %d" % k, z))
     # literal-dense data: ~6-bit codes, 340 tokens per 2048-bit piece -- more than one token list holds, EVERY piece continues in a second one
     import base64
     streams.append(("base64 (6-bit literals), 2048-bit pieces", zlib.compress(base64.b64encode(_rand(4800000, 66)), 6)))

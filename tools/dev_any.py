@@ -106,6 +106,13 @@ if which in ("all", "kinds"):
         d = f()
         for lvl in (1, 6, 9):
             allok &= run("%s 16 MiB level %d" % (name, lvl), zlib.compress(d, lvl), d)
+if which in ("huge",):
+    for mib in (64, 256):
+        d = (text(16 << 20, 9) * (mib // 16))[: mib << 20] if mib <= 64 else make_blocks((mib << 20) // 2048, 2048, "cpu", seed=6).numpy().tobytes()
+        allok &= run("%s %d MiB level 6" % ("text x4" if mib <= 64 else "families", mib), zlib.compress(d, 6), d, reps=2)
+        if mib == 64:
+            d2 = np.random.default_rng(8).integers(0, 64, mib << 20, dtype=np.uint8).tobytes()
+            allok &= run("6-bit random %d MiB level 6" % mib, zlib.compress(d2, 6), d2, reps=2)
 if which in ("batch",):
     # batches of stock-zlib streams in ONE call (fixed pitch): the whole-GPU chains against a wave per stream
     shapes = ((16, 1 << 20), (64, 1 << 20), (256, 1 << 20), (64, 256 << 10), (1024, 64 << 10), (16, 16 << 20))

@@ -48,7 +48,12 @@ def stream(rng):
         if strat == zlib.Z_FIXED and n > 20000:
             strat = zlib.Z_DEFAULT_STRATEGY
         co = zlib.compressobj(level, zlib.DEFLATED, -int(rng.choice([9, 12, 15])), int(rng.choice([8, 8, 8, 9, 1])), strat)
-        body = co.compress(data)
+        body = b""
+        if rng.random() < 0.15:                # a short header flushed in front of the data (zlib: a small FIXED block, then the sync marker)
+            head = gen(rng, int(rng.choice([5, 40, 300, 900])))
+            body = co.compress(head) + co.flush(zlib.Z_SYNC_FLUSH)
+            data = head + data
+        body += co.compress(data[len(data) - n:])
         if rng.random() < 0.2 and len(data) > 1000:
             body += co.flush(zlib.Z_SYNC_FLUSH) + co.compress(data[:777])
             data = data + data[:777]
