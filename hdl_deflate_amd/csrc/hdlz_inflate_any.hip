@@ -1106,8 +1106,11 @@ __global__ __launch_bounds__(64) void k_any_zero(Args a) {
     if (threadIdx.x < par::C_WORDS) ctl[threadIdx.x] = threadIdx.x == (uint32_t)A_OPEN ? open : 0u;
 }
 
-constexpr uint32_t ANY_MIN = 16384;           // streams below this stay with the serial decoder (the chain of launches costs ~0.1 ms)
-constexpr uint32_t ANY_BATCH_MAX = 512, ANY_BATCH_LONG = 96u << 10, ANY_BATCH_MAX_LONG = 1024;      // streams per call: any_work_bytes()
+// streams below ANY_MIN bytes stay with the serial decoder: the chain of launches takes 0.55 ms whatever the stream, one wave 0.2 ms per
+// KB of compressed bytes (0.96 ms at 4.7 KB, 1.64 at 8.9 KB).  Streams per call (any_work_bytes): the more streams, the longer each
+// must be for the chain to beat a wave per stream (profiles/r06_any_batches.txt)
+constexpr uint32_t ANY_MIN = 4096;
+__host__ inline uint32_t any_batch_max(uint32_t in_len) { return in_len >= (96u << 10) ? 1024u : in_len >= 16384u ? 512u : in_len >= 8192u ? 256u : 64u; }
 struct Lay {
     uint32_t nchunks, candcap, maxb, maxx, maxs, tcap, maxreq, mapcap, pb;
     size_t o_cand, o_blk, o_blen, o_shdr, o_spay, o_sidx, o_tab, o_owner, o_map, o_pent, o_prel, o_pnode, o_node, o_xitem, o_sitem,
@@ -1148,10 +1151,11 @@ static Lay lay_of(uint32_t zn) {
 
 }  // namespace any
 
-// 0 = this chain is not launched for the call.  `nstreams`: the streams of the whole call.  The chain inflates 7 .. 9 GB/s of streams of
-// 48 .. 64 KiB, 15 of 256 KiB, 19 of 1 MiB whatever their number, a wave per stream (what its give-ups get) takes ~90 us per KiB of ONE
-// stream up to a few thousand of them: from ~550 streams of 48 KiB, ~750 of 64 KiB, ~1300 of 256 KiB, ~1700 of 1 MiB on the waves win
-// (profiles/r06_any_batches.txt) -- above the limits below a batch of zlib streams is decoded as it was before round 6
+// 0 = this chain is not launched for the call.  `nstreams`: the streams of the whole call.  The chain inflates 2.4 .. 3.7 GB/s of streams
+// of 8 .. 16 KiB, 7 .. 9 of 48 .. 64 KiB, 15 of 256 KiB, 19 of 1 MiB whatever their number, a wave per stream (what its give-ups get)
+// takes ~90 us per KiB of ONE stream up to a few thousand of them: from ~200 streams of 8 KiB, ~400 of 16 KiB, ~550 of 48 KiB, ~750 of
+// 64 KiB, ~1300 of 256 KiB, ~1700 of 1 MiB on the waves win (profiles/r06_any_batches.txt) -- above any_batch_max() a batch of zlib
+// streams is decoded as it was before round 6
 size_t any_work_bytes(uint32_t in_len, uint64_t out_pitch, uint32_t flags, uint32_t nstreams) {
     (void)out_pitch;
 #ifdef HDLZ_ANY_OFF                            // (A/B build: what the chain costs a stream that is not its)
@@ -1159,7 +1163,7 @@ size_t any_work_bytes(uint32_t in_len, uint64_t out_pitch, uint32_t flags, uint3
 #endif
     // (those builds read every block as fixed / stop at the first one; the hint: the caller knows the streams are single fixed blocks)
     if (in_len < any::ANY_MIN || (flags & (HDLZ_INFLATE_ASSUME_FIXED | HDLZ_INFLATE_ONEBLOCK | HDLZ_INFLATE_ONE_FIXED_BLOCK))) return 0;
-    if (nstreams > (in_len >= any::ANY_BATCH_LONG ? any::ANY_BATCH_MAX_LONG : any::ANY_BATCH_MAX)) return 0;
+    if (nstreams > any::any_batch_max(in_len)) return 0;
     return any::lay_of(in_len).bytes;
 }
 

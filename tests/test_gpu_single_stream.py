@@ -478,7 +478,7 @@ def test_any_block_types_in_batches_and_graphs(engine, oracle):
 def test_many_zlib_streams_keep_the_batch_kernels(engine, oracle):
     """the chain for any block types inflates 7..9 GB/s of 48..64 KiB streams however many there are; a wave per stream needs ~90 us per
     KiB of ONE stream: from ~550 such streams on the waves win (profiles/r06_any_batches.txt), so a call with more streams than
-    ANY_BATCH_MAX (512; 1024 for streams of 96 KiB and more) is decoded as before round 6.  600 stock-zlib streams of ~21 KB in one
+    any_batch_max() (512 for these; 64 .. 1024 by stream length) is decoded as before round 6.  600 stock-zlib streams of ~21 KB in one
     call: results against the oracle / zlib, and the default mapping is not slower than 1.5x the wave-per-stream mapping (with the
     chain it was 4 ms against 4.5 for 512 streams, 29 against 6.8 for 4096)"""
     import torch

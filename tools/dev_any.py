@@ -116,12 +116,14 @@ if which in ("huge",):
 if which in ("batch",):
     # batches of stock-zlib streams in ONE call (fixed pitch): the whole-GPU chains against a wave per stream
     shapes = ((16, 1 << 20), (64, 1 << 20), (256, 1 << 20), (64, 256 << 10), (1024, 64 << 10), (16, 16 << 20))
+    if len(sys.argv) > 2 and sys.argv[2] == "small":
+        shapes = [(ns, n) for n in (8 << 10, 12 << 10, 16 << 10, 24 << 10, 32 << 10, 48 << 10) for ns in (1, 16, 64, 256, 512)]
     if len(sys.argv) > 2 and sys.argv[2] == "sweep":
         shapes = [(ns, n) for n in (48 << 10, 64 << 10, 256 << 10, 1 << 20) for ns in (64, 128, 256, 512, 1024, 2048, 4096) if ns * n <= (1 << 30)]
     for nstr, n in shapes:
         zs, wants = [], []
         for k in range(min(nstr, 8)):
-            d = text(n, 100 + k) if k % 2 == 0 else make_blocks(n // 2048, 2048, "cpu", seed=10 + k).numpy().tobytes()
+            d = text(n, 100 + k) if k % 2 == 0 else make_blocks(max(1, n // 2048), 2048, "cpu", seed=10 + k).numpy().tobytes()
             zs.append(zlib.compress(d, 6)); wants.append(d)
         zmax = max(len(z) for z in zs)
         pitch = (zmax + 64 + 15) // 16 * 16
@@ -142,7 +144,7 @@ if which in ("batch",):
                 _, ol, st = eng.inflate_batch(zin, in_len=zmax, out_pitch=cap, out=out, flags=flags, work=work)
                 torch.cuda.synchronize(); ts.append(time.time() - t0)
             ok = bool((st == 0).all()) and bool((ol == n).all())
-            for s_ in (0, 1, nstr - 1):
+            for s_ in sorted({0, min(1, nstr - 1), nstr - 1}):
                 ok &= out[s_, :n].cpu().numpy().tobytes() == wants[s_ % len(zs)]
             allok &= ok
             res[name] = (min(ts), wb, ok)
