@@ -1126,14 +1126,15 @@ static Lay lay_of(uint32_t zn) {
     L.maxb = zn / 1024u < 64u ? 64u : zn / 1024u > 8000u ? 8000u : zn / 1024u;      // (zlib's blocks hold 16 K symbols, ~20 KB; small memLevels and flushes make many small ones)
     L.maxreq = 2u * L.maxb;
     L.mapcap = L.nchunks / 16u + 1024u;                             // pieces decoded a second time, on request (false positives: ~one per 4 MB, ~120 pieces each)
+    if (L.mapcap > 2u * L.nchunks + 64u) L.mapcap = 2u * L.nchunks + 64u;      // (a small stream cannot ask for more than its pieces, once per round that asks)
     // extra items: every piece decoded on request is one, + a partial piece per block, + the fixed blocks' pieces -- and one per `tcap`
     // tokens a piece holds beyond its own list.  A piece of literals with 6-bit codes (base64, float data) is 341 tokens per 2048 bits:
     // with lists of 256 tokens EVERY piece of such a stream needed a second list and the stream fell back to the one-wave decoder
-    // (7.6 MB/s; round 6, first cut).  So a list holds a token per 4 bits of its piece, and an eighth of the pieces may go on beyond
+    // (7.6 MB/s; round 6, first cut).  So a list holds a token per 2.67 bits of its piece, and an eighth of the pieces may go on beyond
     // that (items are launched as workgroups whether used or not: as many more as there are pieces cost the other streams 8 %)
     L.maxx = 2u * L.maxb + 256u + L.mapcap + L.nchunks / 8u;
     L.maxs = zn / 512u + 256u;
-    L.tcap = L.pb / 4u;
+    L.tcap = 3u * L.pb / 8u;                                        // (hex text: 16 symbols, codes of 4 bits and a few of 5 -- a list per 4 bits overflowed in every third piece)
     size_t off = 256;                                               // the control words in front
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
     const size_t items = (size_t)L.nchunks + L.maxx;

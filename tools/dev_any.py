@@ -102,7 +102,9 @@ if which in ("all", "kinds"):
     def b64():
         import base64
         return base64.b64encode(np.random.default_rng(8).integers(0, 256, n, dtype=np.uint8).tobytes())[:n]
-    for name, f in (("logs", logs), ("dna", dna), ("sparse", sparse), ("float32 walk", floats), ("base64", b64)):
+    def hexs():
+        return np.random.default_rng(9).integers(0, 256, n // 2, dtype=np.uint8).tobytes().hex().encode()[:n]
+    for name, f in (("logs", logs), ("dna", dna), ("sparse", sparse), ("float32 walk", floats), ("base64", b64), ("hex", hexs)):
         d = f()
         for lvl in (1, 6, 9):
             allok &= run("%s 16 MiB level %d" % (name, lvl), zlib.compress(d, lvl), d)

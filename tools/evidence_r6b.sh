@@ -15,6 +15,8 @@ bash tools/prof_single.sh ev_single > "$out/pmc_single.txt" 2>&1
 PROF_MODE=few bash tools/prof_single.sh ev_few > "$out/pmc_few.txt" 2>&1
 PROF_MODE=zlib bash tools/prof_single.sh ev_zlib > "$out/pmc_zlib.txt" 2>&1
 HDLZ_LIB=$PWD/hdl_deflate_amd/lib/libhdlz_dbg.so python tools/dev_any.py all > "$out/any_streams.txt" 2>&1
+HDLZ_LIB=$PWD/hdl_deflate_amd/lib/libhdlz_dbg.so python tools/dev_any.py huge >> "$out/any_streams.txt" 2>&1
+(python tools/dev_any.py batch sweep; python tools/dev_any.py batch small) > "$out/any_batches.txt" 2>&1
 python tools/bench_single_stream.py 1 4 16 64 256 > "$out/single_stream.txt" 2>&1
 HDLZ_LIB=$PWD/hdl_deflate_amd/lib/libhdlz_dbg.so python tools/fuzz_any.py --seconds 200 --seed 7 > "$out/fuzz_any.txt" 2>&1
 for d in gpurun_out/prof_ev_*; do find "$d" -name "*.csv" -not -name "*kernel_stats.csv" -delete; done
