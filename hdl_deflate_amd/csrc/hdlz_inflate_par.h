@@ -64,7 +64,10 @@ struct ParArgs {
 constexpr uint32_t MAXCROSS = 4096;           // end-of-block codes (blocks) of a stream of fixed blocks the chain can list
 constexpr uint32_t TOK_LIT = 0x80000000u;     // a token: TOK_LIT | byte, or length | distance << 9
 __host__ __device__ inline uint32_t tmax_of(uint32_t chbits) { return chbits / 8u + 2u; }      // fixed blocks: the shortest token is 8 bits long
-constexpr uint32_t HOPS = 256;                // marker chain steps per pass of k_par_jump
+#ifndef HDLZ_HOPS
+#define HDLZ_HOPS 32
+#endif
+constexpr uint32_t HOPS = HDLZ_HOPS;           // marker chain steps per pass of k_par_jump
 
 // the last kernels of either chain, for the items (pieces) the arguments describe: bytes + markers, the marker passes
 hipError_t par_launch_emit_jump(const ParArgs& p, uint32_t nitems, uint32_t passes, uint32_t nstr, hipStream_t stream);
@@ -78,7 +81,7 @@ __host__ inline uint32_t grid_cap(uint64_t work, uint32_t nstr) {
 __host__ inline uint32_t passes_for(uint32_t nitems) {                 // chains of up to `nitems` hops, HOPS-fold shorter per pass
     uint32_t passes = 1;
     for (uint64_t reach = 1; reach < (uint64_t)nitems + 1u; reach *= HOPS) passes++;
-    return passes > (uint32_t)(C_WORDS - C_PASS0) ? (uint32_t)(C_WORDS - C_PASS0) : passes;
+    return passes > (uint32_t)(C_ANY0 - C_PASS0) ? (uint32_t)(C_ANY0 - C_PASS0) : passes;       // (a counter per pass: control words C_PASS0 .. C_ANY0 - 1)
 }
 
 }  // namespace par

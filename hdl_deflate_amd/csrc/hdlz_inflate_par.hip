@@ -805,7 +805,12 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a_) {
 // a launch) or the new one -- is a valid ancestor.  The one thing a reader must not do is take the BYTE of a position that was resolved
 // in the launch it runs in (that store may not be visible yet): a resolved position keeps ROOT | r, r = the byte of the emit its chain
 // ends in -- final since the emit -- and a chain that arrives there takes out[r], not out[p].
-// (HOPS, hdlz_inflate_par.h: 8 in round 2 -- a pass that finds nothing left still costs a launch, 4.5 us; three passes of 256 cover 65536 pieces)
+// (HOPS, hdlz_inflate_par.h: 8 in round 2, 256 up to round 6 -- a pass that finds nothing left still costs a launch, 4.5 us.  But a lane
+//  that follows a deep chain holds its whole wave, and the chains of zlib's level 1 (copies of copies of copies) ARE deep: the first
+//  pass of a 16 MiB level-1 stream ran 1.4 .. 2.2 ms with 256 steps against 0.43 at level 6.  With 32 steps the rest is left to the next
+//  pass, which finds most of it resolved by then: DNA / logs at level 1 3.58 / 2.55 -> 1.99 / 1.77 ms, a ramp with CWINDOW 256 2.66 ->
+//  1.90, everything else within 2 % -- except pure runs (every byte of every piece a marker): 64 MiB of zeros 1.52 -> 1.60 ms, 256 MiB
+//  3.96 -> 4.34; 16 steps: 1.90 / 1.67, but zeros 1.69 / 4.83.  profiles/r06_marker_hops_ab.txt)
 constexpr uint32_t JUMP_GRID = 8192;          // workgroups of the passes behind the first one (they mostly find nothing left)
 constexpr uint32_t ROOT = 0x80000000u;        // src word: ROOT | r = resolved, the byte is out[r] (NONE: a byte of the emit, its own root); positions are < 2^30
 __global__ __launch_bounds__(64) void k_par_jump(ParArgs a_, uint32_t pass) {

@@ -105,8 +105,12 @@ if which in ("all", "kinds"):
     def hexs():
         return np.random.default_rng(9).integers(0, 256, n // 2, dtype=np.uint8).tobytes().hex().encode()[:n]
     for name, f in (("logs", logs), ("dna", dna), ("sparse", sparse), ("float32 walk", floats), ("base64", b64), ("hex", hexs)):
+        if len(sys.argv) > 2 and sys.argv[2] != name:
+            continue
         d = f()
-        for lvl in (1, 6, 9):
+        if len(sys.argv) > 2 and sys.argv[2] != name:
+            continue
+        for lvl in ((1, 6, 9) if len(sys.argv) <= 3 else (int(sys.argv[3]),)):
             allok &= run("%s 16 MiB level %d" % (name, lvl), zlib.compress(d, lvl), d)
 if which in ("huge",):
     for mib in (64, 256):
