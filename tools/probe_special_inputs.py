@@ -25,6 +25,37 @@ for n, nb in ((2048, B), (65536, B // 32)):
             "period3": lambda: (torch.arange(total, device="cuda") % 3 + 65).to(torch.uint8),
             "random": lambda: torch.randint(0, 256, (total,), dtype=torch.uint8, device="cuda"),
             "ramp": lambda: (torch.arange(total, device="cuda") % 251).to(torch.uint8)}
+    if len(sys.argv) > 2 and sys.argv[2] == "kinds":
+        # kinds of real data (16 MiB made on the host, tiled: CWINDOW = 32 does not see the repeat)
+        import random, base64
+        import numpy as np
+        r = random.Random(77)
+        m = 16 << 20
+        def logs():
+            out = bytearray(); t = 1700000000
+            hosts = ["web-%02d" % i for i in range(12)]; paths = ["/api/v1/items/%d" % i for i in range(40)] + ["/index.html", "/static/app.js", "/health"]
+            while len(out) < m:
+                t += r.randint(0, 3)
+                out += ("%d %s GET %s %d %d \"Mozilla/5.0 (X11; Linux x86_64)\" rt=%.3f\n" % (t, r.choice(hosts), r.choice(paths), r.choice([200, 200, 200, 304, 404, 500]), r.randint(100, 90000), r.random())).encode()
+            return bytes(out[:m])
+        def words():
+            ws = [bytes(r.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(r.randint(2, 9))) for _ in range(3000)]
+            out = bytearray()
+            while len(out) < m:
+                out += r.choice(ws) + b" "
+            return bytes(out[:m])
+        host = {"logs": logs, "words": words,
+                "dna": lambda: np.random.default_rng(3).choice(np.frombuffer(b"ACGT", dtype=np.uint8), m).tobytes(),
+                "sparse": lambda: (np.random.default_rng(4).integers(1, 256, m, dtype=np.uint8) * (np.random.default_rng(5).random(m) < 1 / 64)).astype(np.uint8).tobytes(),
+                "float32": lambda: np.cumsum(np.random.default_rng(6).normal(size=m // 4)).astype(np.float32).tobytes(),
+                "base64": lambda: base64.b64encode(np.random.default_rng(8).integers(0, 256, m, dtype=np.uint8).tobytes())[:m],
+                "hex": lambda: np.random.default_rng(9).integers(0, 256, m // 2, dtype=np.uint8).tobytes().hex().encode()[:m]}
+        def tiled(f):
+            def g():
+                t = torch.frombuffer(bytearray(f()), dtype=torch.uint8).cuda()
+                return t.repeat((total + m - 1) // m)[:total].contiguous()
+            return g
+        gens = {k: tiled(f) for k, f in host.items()}
     for name, g in gens.items():
         d = g().reshape(nb, n)
         ms_c, (zo, zl, st) = timed(lambda: e.compress_batch(d, cwindow=32, maxmatch=10))
