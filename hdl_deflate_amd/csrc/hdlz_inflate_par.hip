@@ -812,6 +812,11 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a_) {
 //  1.90, everything else within 2 % -- except pure runs (every byte of every piece a marker): 64 MiB of zeros 1.52 -> 1.60 ms, 256 MiB
 //  3.96 -> 4.34; 16 steps: 1.90 / 1.67, but zeros 1.69 / 4.83.  profiles/r06_marker_hops_ab.txt)
 constexpr uint32_t JUMP_GRID = 8192;          // workgroups of the passes behind the first one (they mostly find nothing left)
+// (... of ALL streams of the launch together: 196 streams x 8192 workgroups that find nothing left took 49 us per pass)
+__host__ inline uint32_t later_grid(uint32_t items, uint32_t nstr) {
+    const uint32_t g = JUMP_GRID / (nstr ? nstr : 1u) < 64u ? 64u : JUMP_GRID / (nstr ? nstr : 1u);
+    return items < g ? items : g;
+}
 constexpr uint32_t ROOT = 0x80000000u;        // src word: ROOT | r = resolved, the byte is out[r] (NONE: a byte of the emit, its own root); positions are < 2^30
 __global__ __launch_bounds__(64) void k_par_jump(ParArgs a_, uint32_t pass) {
     const ParArgs a = of_stream(a_);
@@ -903,7 +908,7 @@ hipError_t par::par_launch_emit_jump(const ParArgs& p, uint32_t nitems, uint32_t
     const uint32_t gx = grid_cap(nitems, nstr);
     if (gx < nitems) hipLaunchKernelGGL(k_par_emit<true>, dim3(gx, nstr), dim3(64), 0, stream, p);
     else hipLaunchKernelGGL(k_par_emit<false>, dim3(gx, nstr), dim3(64), 0, stream, p);
-    for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(j == 0u || gx < JUMP_GRID ? gx : JUMP_GRID, nstr), dim3(64), 0, stream, p, j);
+    for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(j == 0u ? gx : later_grid(gx, nstr), nstr), dim3(64), 0, stream, p, j);
     return hipGetLastError();
 }
 
@@ -934,8 +939,11 @@ static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch, uint32_t
     const uint64_t ztot = (uint64_t)zn * nstr;
     const uint32_t chbits = ztot < (5u << 18) ? CH_BITS_MAX / 8u : ztot < (3u << 20) ? CH_BITS_MAX / 4u : ztot < (24u << 20) ? CH_BITS_MAX / 2u : CH_BITS_MAX;
     const uint32_t nchunks = (8u * zn - FIRST_BIT + chbits - 1u) / chbits;
-    // streams that do not fill the GPU with one lane per piece (the port's: LMAX = 24 bits = 16 MiB) decode sub-pieces
-    const uint32_t sub = ztot < (24u << 20) ? SUB : 1u;
+    // the real decode always runs on sub-pieces (up to round 6 only below 24 MiB: "streams that do not fill the GPU with one lane per
+    // piece") -- a lane of k_par_tokens<false> on an 8192-bit piece is a serial chain of ~900 tokens read straight from memory: 1.30 of
+    // the 3.7 ms of 196 x 1 MiB; on 2048-bit sub-pieces from LDS rows 0.76.  256 MiB 4.54 -> 4.03 ms, 256 x 1 MiB 5.16 -> 4.65,
+    // 1024 x 1 MiB 19.6 -> 17.4 (4096-bit pieces instead of 8192 as well: 5.10 / 5.36 / 20.8)
+    const uint32_t sub = SUB;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
     const uint32_t ngroups = (nchunks + GROUP - 1u) / GROUP;
@@ -1101,7 +1109,7 @@ static hipError_t launch_inflate_par_group(const InflateArgs& a, hipStream_t str
         ParArgs pe = p;                                                 // the emit: pieces, reading the sub-pieces' token lists
         pe.tokens = pf.tokens; pe.ntok = pf.ntok;
         hipLaunchKernelGGL(k_par_emit<false>, dim3(nchunks, nstr), dim3(64), 0, stream, pe);
-        for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(j == 0u || nchunks < JUMP_GRID ? nchunks : JUMP_GRID, nstr), dim3(64), 0, stream, p, j);
+        for (uint32_t j = 0; j < passes; j++) hipLaunchKernelGGL(k_par_jump, dim3(j == 0u ? nchunks : later_grid(nchunks, nstr), nstr), dim3(64), 0, stream, p, j);
         e = hipGetLastError();
         // join: the verdict looks at both chains' control words
         if (ev_join) {
