@@ -331,7 +331,7 @@ hipError_t launch_compress(const CompressArgs& a, hipStream_t stream) {
     }
     // small blocks (the reference's own input scale): several blocks per wave-tile -- uniform 16-byte aligned batches,
     // or ragged ones whose caller states an upper bound on the block lengths in in_len
-    if (a.cwindow <= 32 && a.in_len >= 5u && a.in_len <= 1024u && a.out_pitch >= (uint64_t)out_bound(a.in_len) &&
+    if (a.cwindow <= 256 && a.in_len >= 5u && a.in_len <= 1024u && a.out_pitch >= (uint64_t)out_bound(a.in_len) &&
         (a.in_off || ((a.in_pitch & 15u) == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0)))
         return launch_compress_small(a, stream, ncu);
     // (round 5: 256 waves queued per CU instead of 64 -- a wave's blocks all belong to one family when the families alternate with a

@@ -1,4 +1,4 @@
-// hdlz_compress_small.hip -- STARTC for batches of SMALL blocks (N <= 1024, CWINDOW <= 32), uniform or ragged.
+// hdlz_compress_small.hip -- STARTC for batches of SMALL blocks (N <= 1024), uniform or ragged.
 //
 // The general kernel (hdlz_compress.hip) gives every block a whole 2048-position wave-tile, so a 256-byte
 // block keeps 8 of 64 lanes busy (38 GB/s measured).  Sub-KiB inputs are the reference's own scale
@@ -16,6 +16,7 @@
 // output stores of the previous group, three times per group.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "hdlz_device.h"
 #include "hdlz_compress_common.h"
 
@@ -35,10 +36,16 @@ struct __attribute__((aligned(16))) SmallLds {
 
 static_assert(sizeof(SmallLds) >= GATHER_SPAN && offsetof(SmallLds, in) == 0, "make_tokens: masked gather inside the LDS block");
 
-template <bool RAGGED, bool FULLWIN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLZ_WS, HDLZ_WS))) void k_compress_small(CompressArgs a) {
-    constexpr int NCH = 1;
+// NCH = ceil(cwindow / 32) as in k_compress: 1, or 2 / 8 with the window-independent finder (round 6: up to then a small block with a
+// window above 32 had a whole tile of the general kernel to itself -- 12.5 ns per block whatever its size: 256-byte blocks at
+// CWINDOW 256 20 GB/s against 390 at CWINDOW 32).  The finder works on the packed tile as on any other: it returns the NEAREST
+// earlier position with the same three bytes, and if that one lies in the block in front (distance > position: make_tokens drops
+// it) no nearer one exists in the block itself.
+template <int NCH> constexpr int small_waves() { return NCH == 1 ? HDLZ_WS : waves_eu<NCH>(); }
+template <bool RAGGED, bool FULLWIN, int NCH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(small_waves<NCH>(), small_waves<NCH>()))) void k_compress_small(CompressArgs a) {
     __shared__ SmallLds lds;
+    __shared__ typename std::conditional<(NCH > 1), HashLds<NCH>, uint32_t>::type hl;
     const uint32_t lane = threadIdx.x;
     fill_luts<NCH>(lds.lut, lane);
     __syncthreads();
@@ -125,8 +132,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLZ_WS, HDL
         const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);   // dword index of the run in lds.in
         uint32_t best[RUN], tok[RUN], code[RUN];
         __builtin_amdgcn_s_setprio(0);                         // (the search at the lowest priority, every other phase above it: hdlz_compress.hip)
-        match_search<NCH, NCH == 1>(lds.in, run_dw, best);     // 2. R3/R4 (candidate keys by DPP: a run in front of a block's first run belongs to
-                                                               //    another block -- or is lane 63 -- and only yields distances beyond the position)
+        if constexpr (NCH > 1) match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);      // 2. R3/R4, windows above 32
+        else match_search<NCH, NCH == 1>(lds.in, run_dw, best);    // 2. R3/R4 (candidate keys by DPP: a run in front of a block's first run belongs to
+                                                                   //    another block -- or is lane 63 -- and only yields distances beyond the position)
         {
             uint32_t ow[12];                                          // own 32 bytes + 16 look-ahead (reloaded: see match_search)
             load_own(lds.in, run_dw, ow);
@@ -192,11 +200,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HDLZ_WS, HDL
     }
 }
 
-template __global__ void k_compress_small<false, false>(CompressArgs);
-template __global__ void k_compress_small<false, true>(CompressArgs);
-template __global__ void k_compress_small<true, false>(CompressArgs);
-template __global__ void k_compress_small<true, true>(CompressArgs);
-
 hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int ncu) {
     const uint32_t Rb = (a.in_len + 31u) >> 5;
     const uint64_t G = 64u / Rb;
@@ -207,13 +210,15 @@ hipError_t launch_compress_small(const CompressArgs& a, hipStream_t stream, int 
     uint64_t grid = (uint64_t)ncu * HDLZ_SMALL_GRID;       // (see launch_compress: short-lived waves, short tail)
     if (grid > groups) grid = groups;
     const dim3 g((unsigned)grid), b(64);
-    if (a.in_off) {
-        if (a.cwindow == 32) hipLaunchKernelGGL((k_compress_small<true, true>), g, b, 0, stream, a);
-        else hipLaunchKernelGGL((k_compress_small<true, false>), g, b, 0, stream, a);
-    } else {
-        if (a.cwindow == 32) hipLaunchKernelGGL((k_compress_small<false, true>), g, b, 0, stream, a);
-        else hipLaunchKernelGGL((k_compress_small<false, false>), g, b, 0, stream, a);
-    }
+    const bool rag = a.in_off != nullptr;
+#define SMALL_LAUNCH(R, F, N) hipLaunchKernelGGL((k_compress_small<R, F, N>), g, b, 0, stream, a)
+#define SMALL_BY_NCH(N, full) do { if (rag) { if (full) SMALL_LAUNCH(true, true, N); else SMALL_LAUNCH(true, false, N); } \
+                                   else { if (full) SMALL_LAUNCH(false, true, N); else SMALL_LAUNCH(false, false, N); } } while (0)
+    if (a.cwindow <= 32) SMALL_BY_NCH(1, a.cwindow == 32);
+    else if (a.cwindow <= 64) SMALL_BY_NCH(2, a.cwindow == 64);
+    else SMALL_BY_NCH(8, a.cwindow == 256);
+#undef SMALL_BY_NCH
+#undef SMALL_LAUNCH
     return hipGetLastError();
 }
 

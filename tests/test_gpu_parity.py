@@ -425,18 +425,25 @@ def test_api_edge_cases(engine, oracle):
 
 def test_compress_small_blocks_packed_kernel(engine, oracle):
     """uniform blocks of 5..1024 bytes take the packed kernel (several blocks per wave-tile): every block
-    against the oracle, block counts that leave partial groups, MATCH10 on/off, windows <= 32"""
+    against the oracle, block counts that leave partial groups, MATCH10 on/off, windows of 7 .. 256"""
     import torch
     from hdl_deflate_amd.data import make_blocks
     for n, B, cw, mm in [(5, 300, 32, 10), (6, 65, 32, 10), (31, 777, 32, 10), (32, 1000, 32, 10), (33, 513, 32, 5),
                          (100, 777, 32, 10), (255, 640, 16, 10), (256, 4096, 32, 10), (257, 333, 32, 10),
-                         (500, 1001, 32, 10), (512, 2048, 7, 5), (1000, 130, 32, 10), (1024, 511, 32, 10)]:
+                         (500, 1001, 32, 10), (512, 2048, 7, 5), (1000, 130, 32, 10), (1024, 511, 32, 10),
+                         # round 6: windows above 32 are packed too (the hashed finder on the packed tile)
+                         (5, 300, 256, 10), (33, 513, 64, 10), (40, 777, 256, 10), (100, 777, 48, 10), (255, 640, 256, 5),
+                         (256, 4096, 256, 10), (257, 333, 64, 10), (300, 900, 100, 10), (500, 1001, 256, 10), (512, 2048, 33, 10),
+                         (777, 300, 200, 10), (1000, 130, 64, 5), (1024, 511, 256, 10)]:
         pitch = (n + 15) // 16 * 16
         raw = make_blocks(B, max(n, 64), "cuda", seed=n)[:, :pitch if pitch <= max(n, 64) else n]
         d = torch.zeros((B, pitch), dtype=torch.uint8, device="cuda")
         d[:, :n] = raw[:, :n]
         if n % 7 == 3:
             d[:, :n] = (d[:, :n] % 3) + 48            # match-dense variant
+        if cw > 32 and n % 2 == 0:
+            d[1::2] = d[0::2][: d[1::2].shape[0]]     # every second block repeats the one in front: the nearest candidate of its first
+                                                      # positions lies in ANOTHER block of the packed tile and must not be taken
         out, ol, st = engine.compress_batch(d, in_len=n, cwindow=cw, maxmatch=mm)
         torch.cuda.synchronize()
         h, ho, hl, hs = d.cpu().numpy(), out.cpu().numpy(), ol.cpu().numpy(), st.cpu().numpy()
@@ -457,7 +464,8 @@ def test_compress_small_ragged_blocks_packed_kernel(engine, oracle):
     import torch
     rng = np.random.default_rng(21)
     for maxlen, B, cw, mm, mis in [(40, 3000, 32, 10, 0), (300, 5000, 32, 10, 3), (700, 2000, 16, 5, 1), (1024, 1500, 32, 10, 7),
-                                   (33, 4000, 5, 10, 2)]:
+                                   (33, 4000, 5, 10, 2), (40, 3000, 256, 10, 1), (300, 5000, 64, 10, 2), (700, 2000, 256, 5, 3),
+                                   (1024, 1500, 100, 10, 5)]:
         lens = rng.integers(0, maxlen + 1, size=B)
         lens[:8] = [0, 1, 4, 5, 6, maxlen, maxlen, 31]
         total = int(lens.sum())
