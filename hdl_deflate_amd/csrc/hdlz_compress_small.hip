@@ -35,6 +35,19 @@ struct __attribute__((aligned(16))) SmallLds {
 };
 
 static_assert(sizeof(SmallLds) >= GATHER_SPAN && offsetof(SmallLds, in) == 0, "make_tokens: masked gather inside the LDS block");
+// windows above 32: the bit buffer lives in the finder's table / transposition buffer, which is dead once best[] is in registers (as in
+// k_compress: 13.6 instead of 16.4 KB per wave -- the LDS, not the registers, bounded the waves per CU)
+struct __attribute__((aligned(16))) SmallLdsNoOut {
+    uint32_t in[IN_BYTES / 4];
+    uint32_t lut[LUT_LIT + LUT_MATCH + LUT_LEN];
+    uint32_t ad[2][64];
+};
+static_assert(sizeof(SmallLdsNoOut) >= GATHER_SPAN && offsetof(SmallLdsNoOut, in) == 0, "make_tokens: masked gather inside the LDS block");
+__device__ __forceinline__ uint32_t* small_out(SmallLds& l, uint32_t&) { return l.out; }
+template <int NCH> __device__ __forceinline__ uint32_t* small_out(SmallLdsNoOut&, HashLds<NCH>& h) {
+    static_assert(sizeof(h.T) >= sizeof(uint32_t) * SMALL_OUT_WORDS, "the bit buffer overlays T / D");
+    return h.T;
+}
 
 // NCH = ceil(cwindow / 32) as in k_compress: 1, or 2 / 8 with the window-independent finder (round 6: up to then a small block with a
 // window above 32 had a whole tile of the general kernel to itself -- 12.5 ns per block whatever its size: 256-byte blocks at
@@ -44,8 +57,9 @@ static_assert(sizeof(SmallLds) >= GATHER_SPAN && offsetof(SmallLds, in) == 0, "m
 template <int NCH> constexpr int small_waves() { return NCH == 1 ? HDLZ_WS : waves_eu<NCH>(); }
 template <bool RAGGED, bool FULLWIN, int NCH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(small_waves<NCH>(), small_waves<NCH>()))) void k_compress_small(CompressArgs a) {
-    __shared__ SmallLds lds;
+    __shared__ typename std::conditional<(NCH > 1), SmallLdsNoOut, SmallLds>::type lds;
     __shared__ typename std::conditional<(NCH > 1), HashLds<NCH>, uint32_t>::type hl;
+    uint32_t* const lout = small_out(lds, hl);
     const uint32_t lane = threadIdx.x;
     fill_luts<NCH>(lds.lut, lane);
     __syncthreads();
@@ -61,7 +75,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(small_waves<
     const uint32_t p_run = r * RUN;                               // block-relative position of the run
     uint8_t* lin8 = reinterpret_cast<uint8_t*>(lds.in);
     const uint8_t* lut8 = reinterpret_cast<const uint8_t*>(lds.lut);
-    uint8_t* out8 = reinterpret_cast<uint8_t*>(lds.out);
+    uint8_t* out8 = reinterpret_cast<uint8_t*>(lout);
     const uint64_t ngroups = (a.nblocks + G - 1u) / G;
 
     for (uint64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -122,17 +136,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(small_waves<
             if (lane < LOOKAHEAD / 4) lds.in[(HALO + TILE) / 4 + lane] = 0;    // look-ahead behind lane 63
         }
         static_assert(SMALL_OUT_WORDS % 4 == 0, "16-byte stores");
-        for (uint32_t q = lane; q < (uint32_t)SMALL_OUT_WORDS / 4u; q += 64) *reinterpret_cast<uint4*>(&lds.out[4u * q]) = make_uint4(0, 0, 0, 0);
-        wave_lds_order();
-        if (lane_ok && r == 0u) lds.out[g * Wb] = 0x78u | (0x9Cu << 8) | (0x3u << 16);   // R1 per block
-        wave_lds_order();
+        auto clear_out = [&]() {
+            for (uint32_t q = lane; q < (uint32_t)SMALL_OUT_WORDS / 4u; q += 64) *reinterpret_cast<uint4*>(&lout[4u * q]) = make_uint4(0, 0, 0, 0);
+            wave_lds_order();
+            if (lane_ok && r == 0u) lout[g * Wb] = 0x78u | (0x9Cu << 8) | (0x3u << 16);   // R1 per block
+            wave_lds_order();
+        };
+        if constexpr (NCH == 1) clear_out();
+        else wave_lds_order();
 
         // -------------------------------------------------------------- 2..5: the shared tile phases (hdlz_compress_common.h);
         // positions are block-relative: a block's first run has no history (d <= p)
         const uint32_t run_dw = (HALO / 4) + lane * (RUN / 4);   // dword index of the run in lds.in
         uint32_t best[RUN], tok[RUN], code[RUN];
         __builtin_amdgcn_s_setprio(0);                         // (the search at the lowest priority, every other phase above it: hdlz_compress.hip)
-        if constexpr (NCH > 1) match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);      // 2. R3/R4, windows above 32
+        if constexpr (NCH > 1) {
+            match_search_hash<NCH>(lds.in, hl, lane, (uint32_t)a.cwindow, best);                         // 2. R3/R4, windows above 32
+            pin(best);
+            wave_lds_order();
+            clear_out();                                                                                 // (the finder's buffers are dead: the bit buffer)
+        }
         else match_search<NCH, NCH == 1>(lds.in, run_dw, best);    // 2. R3/R4 (candidate keys by DPP: a run in front of a block's first run belongs to
                                                                    //    another block -- or is lane 63 -- and only yields distances beyond the position)
         {
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(small_waves<
             if (b2 >= a.nblocks) break;
             const uint32_t words = ((uint32_t)__builtin_amdgcn_readlane((int)total, (int)(gg * Rb)) + 3u) >> 2;
             uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.out + b2 * a.out_pitch);
-            for (uint32_t w = lane; w < words; w += 64) dst[w] = lds.out[gg * Wb + w];
+            for (uint32_t w = lane; w < words; w += 64) dst[w] = lout[gg * Wb + w];
         }
     }
 }
