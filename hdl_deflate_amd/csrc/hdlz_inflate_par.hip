@@ -196,7 +196,12 @@ __global__ __launch_bounds__(64) void k_par_spec(ParArgs a_) {
 //   k_par_resolve  every (piece, offset) takes its chain's results (+ its own bytes of the head) -- the arrays k_par_scan_* read.
 // Nothing is assumed about the data: a stream whose chains never merge (a period of a few tokens) lists 32 chains per piece and costs
 // what k_par_spec cost, plus the head.  Ordinary data lists two or three.
-constexpr uint32_t HEAD_BITS = 256;
+#ifndef HDLZ_HEAD_MAX
+#define HDLZ_HEAD_MAX 256
+#endif
+constexpr uint32_t HEAD_MAX = HDLZ_HEAD_MAX;     // bits of a piece all 32 offsets decode (never beyond the piece's first sub-boundary: the tail records those)
+// (512 / 1024 bits: fewer chains are left for the tail, but 32 lanes wide costs more than it saves -- 16 MiB 0.524 -> 0.538 / 0.564 ms,
+//  256 MiB 4.07 -> 4.14 / 4.40, 256 x 1 MiB 4.52 -> 4.57 / 4.79)
 struct Chains {
     uint32_t* rep;              // [nchunks][32]  the chain of (piece, offset); NONE: ended inside the head (its maps are final)
     uint32_t* cpos;             // [chains]  bit position at which the chain stands behind the head
@@ -244,13 +249,14 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a_, Chains
     const Chains ch = of_stream(ch_, a_.ws_stride);
     if (!one_fixed_block(a)) return;
     const uint32_t emode = eob_mode(a);
-    __shared__ uint32_t lit[512], dst[32], win[HEAD_WAVES][2][HEAD_BITS / 32 + 8], first[HEAD_WAVES][2][32], slotof[HEAD_WAVES][2][32];
+    __shared__ uint32_t lit[512], dst[32], win[HEAD_WAVES][2][HEAD_MAX / 32 + 8], first[HEAD_WAVES][2][32], slotof[HEAD_WAVES][2][32];
     __shared__ uint32_t wcount[HEAD_WAVES], wbase[HEAD_WAVES];
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u, half = lane >> 5, e = lane & 31u;
     fill_tables(lit, dst, tid, 64u * HEAD_WAVES);
     first[wv][half][e] = 0xFFFFFFFFu;
     const uint32_t c = (blockIdx.x * HEAD_WAVES + wv) * 2u + half;
     const bool have = c < a.nchunks;
+    const uint32_t HEAD_BITS = min(HEAD_MAX, a.chbits / a.sub);
     const uint32_t b_c = FIRST_BIT + c * a.chbits, hb = b_c + HEAD_BITS;
     if (have) stage_window(win[wv][half], a.z, a.zn, b_c, HEAD_BITS, e, 32u);
     __syncthreads();
