@@ -14,21 +14,26 @@
 //      k_any_headers  one LANE per survivor decodes the code lengths and applies the rest of the rules: the CANDIDATE blocks;
 //      k_any_sort     ... ordered by position;   k_any_tables: one workgroup per candidate builds its decode tables (an 11-bit
 //                     and a 9-bit look-up table + the canonical lists for longer codes), slot `maxb` holds the fixed code's;
-//   2. k_any_owner    every piece of the stream (1024 bits) belongs to the last candidate whose payload starts in front of it;
-//      k_any_spec     one WAVE per piece decodes it with its owner's tables from the 64 bit offsets a token can start at behind
-//                     its first bit (a token is at most 15 + 5 + 15 + 13 = 48 bits long): exit offset / end-of-block position and
-//                     the bytes produced, for every entry offset (the maps of hdlz_inflate_par.hip, per block);
-//   3. k_any_walk     one LANE per candidate walks its block: the first partial piece serially, then through the maps to the
-//                     block's end-of-block code; behind it the blocks that cannot be found by search are followed serially --
-//                     stored blocks (a length and a jump), fixed blocks (decoded by this lane: they are short in streams that
-//                     also hold dynamic blocks; long ones give up) -- up to the next dynamic header, which must be a candidate
-//                     (binary search): the block's successor.  A pseudo-node does the same from the stream's first header;
+//   2. k_any_owner    every piece of the stream (1024 bits; 2048 from 4 MiB on) belongs to the last candidate whose payload starts in
+//                     front of it;
+//      k_any_spec     one WAVE per piece decodes its first 256 bits with its owner's tables from the 64 bit offsets a token can start
+//                     at behind its first bit (a token is at most 15 + 5 + 15 + 13 = 48 bits long); the lanes that stand at the same
+//                     bit afterwards are ONE chain (up to 8 per piece are listed);  k_any_tail: one lane per listed chain decodes the
+//                     rest of its piece;  k_any_resolve: exit offset / end-of-block position and the bytes produced, for every
+//                     entry offset (the maps of hdlz_inflate_par.hip, per block);
+//   3. k_any_walk     one WAVE per candidate walks its block: the first partial piece by decoding, then through the maps (64 pieces
+//                     staged in LDS at a time) to the block's end-of-block code; behind it the blocks that cannot be found by search
+//                     are followed serially -- stored blocks (a length and a jump), fixed blocks (decoded here: they are short in
+//                     streams that also hold dynamic blocks; more than FIX_MAX_BITS give up) -- up to the next dynamic header, which
+//                     must be a candidate (binary search): the block's successor.  A pseudo-node does the same from the stream's
+//                     first header.  A walk that meets pieces decoded for ANOTHER candidate (a false positive inside its block) asks
+//                     for them again with its own tables (k_any_spec2) and goes on in the next round;
 //      k_any_rank     one thread follows the successors from the pseudo-node: the TRUE chain of blocks, every block's output
 //                     position, the total length.  A candidate that is not on the chain (a false positive, or a header-like
-//                     pattern inside stored data) is simply never visited; a piece that was decoded for the wrong owner is an
-//                     inconsistency the walk notices -> fallback;
-//   4. k_any_tokens   one LANE per piece (and per partial piece / fixed-block piece the walks listed) decodes for real, with the
-//                     reference's checks, into a token list;  k_any_stored copies the stored blocks;
+//                     pattern inside stored data) is simply never visited;
+//   4. k_any_tokens   one LANE per piece (and per partial piece / fixed-block piece / requested piece the walks listed) decodes for
+//                     real, with the reference's checks, into a token list -- and verifies that the item ends at the bit and with
+//                     the byte count the walk promised;  k_any_stored copies the stored blocks;
 //      k_par_emit / k_par_jump (hdlz_inflate_par.hip) turn the token lists into bytes: history that is not there yet becomes
 //                     markers, pointer jumping resolves them.
 // Whatever this chain cannot do -- more candidates, items or stored blocks than its lists hold, a fixed block of more than
