@@ -138,7 +138,7 @@ __device__ __forceinline__ View view(const Args& a) {
     uint8_t* w = a.ws + (size_t)s * a.stride;
     v.ctl = reinterpret_cast<uint32_t*>(w);
     v.pb = a.pb;
-    // the gate: a stream that STARTS with a fixed block is the other chain's (hdlz_inflate_par.hip: one_fixed_block -- the same test on
+    // the gate: a stream that STARTS with a fixed block is the other chain's (hdlz_inflate_par.hip: starts_fixed -- the same test on
     // the same byte, so the two chains need nothing from each other and run side by side; it also takes streams of SEVERAL fixed
     // blocks) -- unless that block is SHORT and a block of another type follows it (a header written and flushed in front of the data:
     // zlib closes so small a block as a fixed one): the other chain gives those up at that block, k_any_zero opens this one

@@ -21,7 +21,7 @@
 //   4. k_par_jump    pointer jumping over the markers IN PLACE: src[p] <- up to HOPS steps along its chain, until the source is a byte
 //                    (one launch per pass, log_HOPS(pieces) + 1 passes at most; a pass with nothing left returns at once).
 //   3'. k_par_ends   (round 6) streams of SEVERAL fixed blocks: the chains pass "end-of-block + next fixed header" like a token; the
-//                    true end is the first listed end-of-block code of a block whose BFINAL was set (see one_fixed_block below);
+//                    true end is the first listed end-of-block code of a block whose BFINAL was set (see starts_fixed below);
 // Anything else -- a block of another type (a stream that does not even start with a fixed block: hdlz_inflate_any.hip), a failed check
 // (NO EOF, bad symbol, bad distance, capacity) -- sets
 // a fallback flag on the device and k_inflate_dyn redoes the stream from its first byte (it is launched behind the chain and
@@ -65,7 +65,7 @@ __device__ __forceinline__ ParArgs of_stream(ParArgs a) {
     if (a.in_off) {
         const uint64_t o0 = a.in_off[s], n64 = a.in_off[s + 1u] - o0;
         a.z += o0;
-        a.zn = n64 > (uint64_t)a.zn ? 0xFFFFFFFFu : (uint32_t)n64;      // longer than the stated bound: one_fixed_block() sends it to the serial pass
+        a.zn = n64 > (uint64_t)a.zn ? 0xFFFFFFFFu : (uint32_t)n64;      // longer than the stated bound: starts_fixed() sends it to the serial pass
     } else a.z += (uint64_t)s * a.in_pitch;
     if (s == 0u) return a;
     a.out += (uint64_t)s * a.out_pitch;
@@ -106,7 +106,7 @@ __device__ __forceinline__ uint64_t bits_at(const uint32_t* win, uint32_t b_c, u
 // finds the first one that ends a block whose BFINAL was set: the true end, the total length; what lies behind it is cut off.
 // k_par_scan_top gives the first verdict (not this chain's stream at all); the kernels in front of it only SKIP such a stream -- a batch
 // of small dynamic-tree streams must not pay a speculative fixed-Huffman decode of every stream before another path takes them.
-__device__ __forceinline__ bool one_fixed_block(const ParArgs& a) {           // (the name of rounds 3..5: a stream that starts with a fixed block)
+__device__ __forceinline__ bool starts_fixed(const ParArgs& a) {
     const uint32_t hdr = (a.zn >= 5u && a.zn != 0xFFFFFFFFu) ? (uint32_t)a.z[2] : 0u;
     const bool fixed = (a.flags & HDLZ_INFLATE_ASSUME_FIXED) || ((hdr >> 1) & 3u) == 1u;
     return a.zn >= 5u && a.zn != 0xFFFFFFFFu && fixed;
@@ -247,7 +247,7 @@ constexpr uint32_t HEAD_WAVES = 8;            // waves per workgroup of k_par_he
 __global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a_, Chains ch_) {
     const ParArgs a = of_stream(a_);
     const Chains ch = of_stream(ch_, a_.ws_stride);
-    if (!one_fixed_block(a)) return;
+    if (!starts_fixed(a)) return;
     const uint32_t emode = eob_mode(a);
     __shared__ uint32_t lit[512], dst[32], win[HEAD_WAVES][2][HEAD_MAX / 32 + 8], first[HEAD_WAVES][2][32], slotof[HEAD_WAVES][2][32];
     __shared__ uint32_t wcount[HEAD_WAVES], wbase[HEAD_WAVES];
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void k_par_head(ParArgs a_, Chains
 __global__ __launch_bounds__(64) void k_par_tail(ParArgs a_, Chains ch_) {
     const ParArgs a = of_stream(a_);
     const Chains ch = of_stream(ch_, a_.ws_stride);
-    if (!one_fixed_block(a)) return;
+    if (!starts_fixed(a)) return;
     const uint32_t emode = eob_mode(a);
     __shared__ uint32_t lit[512], dst[32];
     const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64) void k_par_tail(ParArgs a_, Chains ch_) {
 __global__ __launch_bounds__(256) void k_par_resolve(ParArgs a_, Chains ch_) {
     const ParArgs a = of_stream(a_);
     const Chains ch = of_stream(ch_, a_.ws_stride);
-    if (!one_fixed_block(a)) return;
+    if (!starts_fixed(a)) return;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= a.nchunks * 32u) return;
     const uint32_t r = ch.rep[t];
@@ -382,7 +382,7 @@ __device__ __forceinline__ uint32_t stage_group(GroupLds& L, const ParArgs& a, u
 }
 __global__ __launch_bounds__(64) void k_par_scan_groups(ParArgs a_) {
     const ParArgs a = of_stream(a_);
-    if (!one_fixed_block(a)) return;
+    if (!starts_fixed(a)) return;
     __shared__ GroupLds L;
     const uint32_t lane = threadIdx.x, g = blockIdx.x;
     const uint32_t cnt = stage_group(L, a, g, lane);
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a_) {
     __shared__ uint8_t pathb[8][32][8], segmap[8][32], segstop[8][32], segent[8];
     const uint32_t lane = threadIdx.x;                     // (256 threads: staging, and 8 segments x 32 entry offsets for the walk)
     // the stream must be one fixed block (or be read as one: the DYNAMIC=False / ONEBLOCK builds)
-    if (!one_fixed_block(a)) { if (lane == 0u) { a.ctl[C_FALLBACK] = 1u; a.ctl[C_NOTFIXED] = 1u; } return; }
+    if (!starts_fixed(a)) { if (lane == 0u) { a.ctl[C_FALLBACK] = 1u; a.ctl[C_NOTFIXED] = 1u; } return; }
     const uint32_t ngroups = (a.nchunks + GROUP - 1u) / GROUP;
     if (lane == 0u) { sh_stop = 0; sh_e = 0; sh_nused = 0; sh_acc = 0; }
     __syncthreads();
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void k_par_scan_top(ParArgs a_) {
     }
     if (lane == 0u) {
         // (round 6) where the chain of pieces ends is NOT where the stream ends: it runs through the true end into the trailer (see
-        // one_fixed_block); the pieces up to there are decoded, k_par_ends finds the true end among the end-of-block codes and gives the
+        // starts_fixed); the pieces up to there are decoded, k_par_ends finds the true end among the end-of-block codes and gives the
         // verdict.  A chain that never stopped (garbage up to the last piece): all pieces.
         a.ctl[C_NUSED] = sh_stop != 0u ? sh_nused : a.nchunks;
         a.ctl[C_TOTAL] = 0u;
