@@ -431,6 +431,26 @@ def test_any_block_types_give_ups_and_bad_streams(engine, oracle):
     for flags in (1, 8, 9):
         _check(engine, oracle, good, 1 << 20, flags=flags)
         _check(engine, oracle, cases[0], 1 << 20, flags=flags)
+    # streams of 4 .. 16 KiB of compressed bytes (the chain's since the end of round 6; one wave before): good, cut, damaged; and the
+    # stream with a short fixed block in front, cut inside that block / behind it / damaged in its first bytes
+    for n, lvl in ((12000, 6), (16000, 1), (24000, 9), (36000, 6), (50000, 1)):
+        z = zlib.compress(_text(n, 200 + n), lvl)
+        assert 4096 <= len(z) < 24000, len(z)
+        for zz in (z, z[:-4], z[: len(z) // 2]):
+            _check(engine, oracle, zz, 1 << 16)
+        for _ in range(3):
+            zb = bytearray(z)
+            zb[r.randrange(2, len(zb))] ^= 1 << r.randrange(8)
+            _check(engine, oracle, bytes(zb), 1 << 16)
+    co = zlib.compressobj(6)
+    hz = co.compress(b"format=v1;name=whatever;fields=12\n") + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(_text(200000, 77)) + co.flush()
+    assert (hz[2] & 7) == 2
+    for zz in (hz[:20], hz[:60], hz[:5000], hz[:-2]):
+        _check(engine, oracle, zz, 1 << 18)
+    for k in (2, 3, 10, 30, 41, 45, 50):
+        zb = bytearray(hz)
+        zb[k] ^= 1 << r.randrange(8)
+        _check(engine, oracle, bytes(zb), 1 << 18)
 
 
 def test_any_block_types_in_batches_and_graphs(engine, oracle):
