@@ -846,27 +846,41 @@ __global__ __launch_bounds__(64) void k_par_jump(ParArgs a_, uint32_t pass) {
     // 10.1 -> 1.6 ms, 256 MiB 36.5 -> 4.1 ms (profiles/r05_single_stream_inflate.txt).  (One wave per piece: its LDS accesses are in program order.)
     for (uint32_t k = threadIdx.x; k < 256u; k += 64u) memo[k] = ~0ull;          // (no marker is NONE)
     wave_lds_order();
-    for (uint32_t q = p0; q < p0 + ext; q += 64u) {
-        const uint32_t p = q + threadIdx.x;
-        uint32_t m = p < p0 + ext ? s[p] : NONE;
-        if (m & ROOT) continue;               // (past the extent;) a byte: the emit's, or resolved by an earlier pass
-        const uint32_t m0 = m;
-        const unsigned long long e = memo[m0 & 255u];
-        uint32_t r;
-        if ((uint32_t)e == m0) r = (uint32_t)(e >> 32);
-        else {
-            r = m;
+    // TWO slices of the piece per step, their loads issued side by side: a step is a chain of dependent loads (the marker, its source's
+    // word, the byte), and the slices of a piece need nothing from each other (a marker points in front of the piece).  (Worth 3 % on
+    // pure runs -- 256 MiB of zeros 4.52 -> 4.38 ms --, nothing on zlib streams: the pass is bound by the memory system's rate of
+    // scattered words, not by a wave's latency)
+    const uint32_t end = p0 + ext;
+    for (uint32_t q = p0; q < end; q += 128u) {
+        const uint32_t pA = q + threadIdx.x, pB = pA + 64u;
+        uint32_t mA = pA < end ? s[pA] : NONE, mB = pB < end ? s[pB] : NONE;
+        const bool actA = !(mA & ROOT), actB = !(mB & ROOT);          // (past the extent;) a byte: the emit's, or resolved by an earlier pass
+        const uint32_t m0A = mA, m0B = mB;
+        const unsigned long long eA = memo[m0A & 255u], eB = memo[m0B & 255u];
+        const bool hitA = actA && (uint32_t)eA == m0A, hitB = actB && (uint32_t)eB == m0B;
+        uint32_t rA = hitA ? (uint32_t)(eA >> 32) : mA, rB = hitB ? (uint32_t)(eB >> 32) : mB;
+        bool runA = actA && !hitA, runB = actB && !hitB;
 #pragma unroll 1
-            for (uint32_t h = 0; h < HOPS; h++) {
-                const uint32_t m2 = s[m];
-                if (m2 & ROOT) { r = ROOT | (m2 == NONE ? m : (m2 & ~ROOT)); break; }
-                m = m2; r = m2;
+        for (uint32_t h = 0; h < HOPS && (runA || runB); h++) {
+            const uint32_t m2A = runA ? s[mA] : 0u, m2B = runB ? s[mB] : 0u;
+            if (runA) {
+                if (m2A & ROOT) { rA = ROOT | (m2A == NONE ? mA : (m2A & ~ROOT)); runA = false; }
+                else { mA = m2A; rA = m2A; }
             }
-            memo[m0 & 255u] = (unsigned long long)m0 | ((unsigned long long)r << 32);
+            if (runB) {
+                if (m2B & ROOT) { rB = ROOT | (m2B == NONE ? mB : (m2B & ~ROOT)); runB = false; }
+                else { mB = m2B; rB = m2B; }
+            }
         }
-        if (r & ROOT) a.out[p] = a.out[r & ~ROOT];                            // (a byte of the emit: nobody writes it now)
-        else left++;
-        s[p] = r;
+        if (actA && !hitA) memo[m0A & 255u] = (unsigned long long)m0A | ((unsigned long long)rA << 32);
+        if (actB && !hitB) memo[m0B & 255u] = (unsigned long long)m0B | ((unsigned long long)rB << 32);
+        const bool doneA = actA && (rA & ROOT), doneB = actB && (rB & ROOT);
+        const uint8_t vA = doneA ? a.out[rA & ~ROOT] : (uint8_t)0, vB = doneB ? a.out[rB & ~ROOT] : (uint8_t)0;      // (bytes of the emit: nobody writes them now)
+        if (doneA) a.out[pA] = vA;
+        if (doneB) a.out[pB] = vB;
+        left += (actA && !doneA ? 1u : 0u) + (actB && !doneB ? 1u : 0u);
+        if (actA) s[pA] = rA;
+        if (actB) s[pB] = rB;
     }
     wave_lds_order();
     }
@@ -945,11 +959,13 @@ static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch, uint32_t
     const uint64_t ztot = (uint64_t)zn * nstr;
     const uint32_t chbits = ztot < (5u << 18) ? CH_BITS_MAX / 8u : ztot < (3u << 20) ? CH_BITS_MAX / 4u : ztot < (24u << 20) ? CH_BITS_MAX / 2u : CH_BITS_MAX;
     const uint32_t nchunks = (8u * zn - FIRST_BIT + chbits - 1u) / chbits;
-    // the real decode always runs on sub-pieces (up to round 6 only below 24 MiB: "streams that do not fill the GPU with one lane per
-    // piece") -- a lane of k_par_tokens<false> on an 8192-bit piece is a serial chain of ~900 tokens read straight from memory: 1.30 of
-    // the 3.7 ms of 196 x 1 MiB; on 2048-bit sub-pieces from LDS rows 0.76.  256 MiB 4.54 -> 4.03 ms, 256 x 1 MiB 5.16 -> 4.65,
-    // 1024 x 1 MiB 19.6 -> 17.4 (4096-bit pieces instead of 8192 as well: 5.10 / 5.36 / 20.8)
-    const uint32_t sub = SUB;
+    // the real decode runs on sub-pieces (staged in LDS rows) where one lane per PIECE is too few lanes -- below 24 MiB -- and, since
+    // round 6, from 128 MiB on: there a lane of k_par_tokens<false> on an 8192-bit piece is a serial chain of ~900 tokens read straight
+    // from memory (1.30 of the 3.7 ms of 196 x 1 MiB; on 2048-bit sub-pieces from LDS rows 0.76): 256 MiB 4.54 -> 4.03 ms, 256 x 1 MiB
+    // 5.16 -> 4.65, 1024 x 1 MiB 19.6 -> 17.4, 200 MiB of random bytes 6.02 -> 5.17.  In between the sub-boundary maps cost more than
+    // they save on literal-heavy streams (64 MiB of random bytes 1.87 -> 2.08 ms, text 1.65 -> 1.81, families the same): one lane per
+    // piece stays.  (4096-bit pieces instead of 8192 as well: 5.10 / 5.36 / 20.8)
+    const uint32_t sub = (ztot < (24u << 20) || ztot >= (128u << 20)) ? SUB : 1u;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
     const uint32_t ngroups = (nchunks + GROUP - 1u) / GROUP;

@@ -3,7 +3,7 @@ import torch, time, numpy as np
 from hdl_deflate_amd import Engine
 from hdl_deflate_amd.data import make_blocks
 e = Engine()
-n = 64 << 20
+n = (int(sys.argv[1]) if len(sys.argv) > 1 else 64) << 20
 def text(n):
     rng = np.random.default_rng(5)
     words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(2000)]
@@ -25,5 +25,5 @@ for name, g in cases.items():
             back, bl, bs = e.inflate_batch(zin, out_pitch=n + 64)
             torch.cuda.synchronize(); dt = time.time() - t0
         ok = int(bs[0].item()) == 0 and int(bl[0].item()) == n and torch.equal(back[0, :n], d[:n])
-        print("%-9s cw %3d: 64 MiB -> %9d bytes, STARTD %.3f ms = %5.1f GB/s  round trip %s" % (name, cw, zn, dt * 1e3, n / dt / 1e9, ok), flush=True)
+        print("%-9s cw %3d: %d MiB -> %9d bytes, STARTD %.3f ms = %5.1f GB/s  round trip %s" % (name, cw, n >> 20, zn, dt * 1e3, n / dt / 1e9, ok), flush=True)
         del d, out, back, zin; torch.cuda.empty_cache()
