@@ -1059,6 +1059,7 @@ __global__ __launch_bounds__(64) void k_any_tokens(Args a) {
         if (have) v.opos[i] = P;
         Bits rd;
         rd.init(v.z, v.zn, have ? start : 16u);
+        uint4 q = make_uint4(0, 0, 0, 0);                            // the last (up to) four tokens
         auto decode = [&](const Tab* t) {
             while (have && rd.pos < limit) {
                 const uint32_t p0 = rd.pos;
@@ -1082,7 +1083,12 @@ __global__ __launch_bounds__(64) void k_any_tokens(Args a) {
                     }
                 }
                 if (f) { bad = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_TOKEN); break; }
-                tk[nt++] = k.kind == 0u ? (TOK_LIT | k.lit) : (k.length | (k.dist << 9));
+                {   // (four tokens per store, as k_par_tokens: tcap is a multiple of 4, so a list that is full has just been written)
+                    const uint32_t w = k.kind == 0u ? (TOK_LIT | k.lit) : (k.length | (k.dist << 9)), k4 = nt & 3u;
+                    q.x = k4 == 0u ? w : q.x; q.y = k4 == 1u ? w : q.y; q.z = k4 == 2u ? w : q.z; q.w = k4 == 3u ? w : q.w;
+                    if (k4 == 3u) *reinterpret_cast<uint4*>(tk + (nt & ~3u)) = q;
+                    nt++;
+                }
                 P += made;
             }
         };
@@ -1091,6 +1097,7 @@ __global__ __launch_bounds__(64) void k_any_tokens(Args a) {
         // the item must end where the walk -- the speculative maps -- said it would, with the bytes it said: whatever goes wrong in the
         // speculation can cost the fallback, never a wrong byte
         if (have && !bad && (rd.pos != want_end || P - (nd.obase + rel) != want_made)) { bad = true; atomicOr(&v.ctl[A_WHY], (uint32_t)W_VERIFY); }
+        if (have && (nt & 3u) != 0u) *reinterpret_cast<uint4*>(tk + (nt & ~3u)) = q;
         if (have) v.ntok[icur] = nt;
     }
     if (ballot64(bad) != 0ull && lane == 0u) give_up(v);
@@ -1190,6 +1197,7 @@ static Lay lay_of(uint32_t zn) {
     // that (items are launched as workgroups whether used or not: as many more as there are pieces cost the other streams 8 %)
     L.maxx = 2u * L.maxb + 256u + L.mapcap + L.nchunks / 8u;
     L.maxs = zn / 512u + 256u;
+    static_assert((3u * 1024u / 8u) % 4u == 0u, "token lists are written 16 bytes at a time");
     L.tcap = 3u * L.pb / 8u;                                        // (hex text: 16 symbols, codes of 4 bits and a few of 5 -- a list per 4 bits overflowed in every third piece)
     size_t off = 256;                                               // the control words in front
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };

@@ -63,7 +63,7 @@ struct ParArgs {
 };
 constexpr uint32_t MAXCROSS = 4096;           // end-of-block codes (blocks) of a stream of fixed blocks the chain can list
 constexpr uint32_t TOK_LIT = 0x80000000u;     // a token: TOK_LIT | byte, or length | distance << 9
-__host__ __device__ inline uint32_t tmax_of(uint32_t chbits) { return chbits / 8u + 2u; }      // fixed blocks: the shortest token is 8 bits long
+__host__ __device__ inline uint32_t tmax_of(uint32_t chbits) { return (chbits / 8u + 2u + 3u) & ~3u; }      // fixed blocks: the shortest token is 8 bits long (a multiple of 4: the lists are written 16 bytes at a time)
 #ifndef HDLZ_HOPS
 #define HDLZ_HOPS 32
 #endif

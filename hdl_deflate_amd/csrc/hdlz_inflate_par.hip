@@ -578,6 +578,7 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a_) {
     // as the stream's verdict: this lane may be decoding the trailer behind the true end.  k_par_ends sorts it out.
     bool run = have;
     uint32_t nfail = NONE;
+    uint4 q = make_uint4(0, 0, 0, 0);                        // the last (up to) four tokens
     while (ballot64(run) != 0ull) {
         if (run) {
             if (bc <= 32u) {
@@ -603,7 +604,14 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a_) {
                           ((int32_t)((pos + used) >> 3) >= isize - 2));                           // COPY hold (deflate.py:1600)
             const bool go = !(f | iseob);
             bool stop = f;
-            if (go) { tk[n] = islit ? (TOK_LIT | code) : (tl | (D << 9)); n++; P += made; pos += used; bb >>= used; bc -= used; }
+            // (the token list is written FOUR tokens at a time: a store per token and lane is 64 requests of 4 bytes to 64 different lines
+            //  per wave instruction -- 0.80 of the kernel's 1.39 ms at 256 MiB went with the stores)
+            if (go) {
+                const uint32_t w = islit ? (TOK_LIT | code) : (tl | (D << 9)), k4 = n & 3u;
+                q.x = k4 == 0u ? w : q.x; q.y = k4 == 1u ? w : q.y; q.z = k4 == 2u ? w : q.z; q.w = k4 == 3u ? w : q.w;
+                if (k4 == 3u) *reinterpret_cast<uint4*>(tk + (n & ~3u)) = q;
+                n++; P += made; pos += used; bb >>= used; bc -= used;
+            }
             else if (!f) {                                                                        // an end-of-block code (D6)
                 const uint32_t hdr3 = (x >> 7) & 7u;
                 const bool on = eob_goes_on(emode, hdr3);
@@ -616,6 +624,7 @@ __global__ __launch_bounds__(64) void k_par_tokens(ParArgs a_) {
             run = !stop && pos < end;
         }
     }
+    if (have && (n & 3u) != 0u) *reinterpret_cast<uint4*>(tk + (n & ~3u)) = q;          // (the rest of the last four: tcap is a multiple of 4)
     if (have) { a.ntok[c] = n; a.nfail[c] = nfail; }
 }
 
@@ -959,13 +968,13 @@ static Layout layout_of(uint32_t zn, uint32_t nstr, uint64_t out_pitch, uint32_t
     const uint64_t ztot = (uint64_t)zn * nstr;
     const uint32_t chbits = ztot < (5u << 18) ? CH_BITS_MAX / 8u : ztot < (3u << 20) ? CH_BITS_MAX / 4u : ztot < (24u << 20) ? CH_BITS_MAX / 2u : CH_BITS_MAX;
     const uint32_t nchunks = (8u * zn - FIRST_BIT + chbits - 1u) / chbits;
-    // the real decode runs on sub-pieces (staged in LDS rows) where one lane per PIECE is too few lanes -- below 24 MiB -- and, since
-    // round 6, from 128 MiB on: there a lane of k_par_tokens<false> on an 8192-bit piece is a serial chain of ~900 tokens read straight
-    // from memory (1.30 of the 3.7 ms of 196 x 1 MiB; on 2048-bit sub-pieces from LDS rows 0.76): 256 MiB 4.54 -> 4.03 ms, 256 x 1 MiB
-    // 5.16 -> 4.65, 1024 x 1 MiB 19.6 -> 17.4, 200 MiB of random bytes 6.02 -> 5.17.  In between the sub-boundary maps cost more than
-    // they save on literal-heavy streams (64 MiB of random bytes 1.87 -> 2.08 ms, text 1.65 -> 1.81, families the same): one lane per
-    // piece stays.  (4096-bit pieces instead of 8192 as well: 5.10 / 5.36 / 20.8)
-    const uint32_t sub = (ztot < (24u << 20) || ztot >= (128u << 20)) ? SUB : 1u;
+    // the real decode ALWAYS runs on sub-pieces staged in LDS rows (up to round 6 only below 24 MiB: above, a lane of k_par_tokens<false>
+    // decoded an 8192-bit piece -- ~900 tokens -- straight from memory: 1.30 of the 3.7 ms of 196 x 1 MiB).  With the token lists written
+    // 16 bytes at a time (k_par_tokens) it wins at every size: 32 / 64 / 100 MiB of random bytes 1.35 / 1.77 / 2.40 -> 1.14 / 1.58 /
+    // 2.14 ms, 64 MiB of families / text 1.70 / 1.68 -> 1.43 / 1.44, 256 MiB 4.54 -> 3.28, 256 x 1 MiB 5.16 -> 4.32, 1024 x 1 MiB
+    // 19.6 -> 15.3.  (While a token was a 4-byte store the sub-boundary maps cost literal-heavy streams of 24 .. 128 MiB more than they
+    // saved: 64 MiB of random bytes 1.87 -> 2.08; 4096-bit pieces instead of 8192 as well: worse throughout.)
+    const uint32_t sub = SUB;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255u) & ~(size_t)255u; return o; };
     const uint32_t ngroups = (nchunks + GROUP - 1u) / GROUP;
