@@ -716,6 +716,8 @@ __global__ __launch_bounds__(64) void k_par_emit(ParArgs a_) {
         const uint32_t n = a.ntok[f];
         const uint32_t* tk = a.tokens + (size_t)f * a.tcap;
         // (the piece's tokens staged in LDS first -- no global load in front of a batch -- cost more in occupancy than it saved: 245 -> 301 us)
+        // (... and the next batch's tokens requested a batch ahead, kept in registers: nothing -- 256 MiB 3.24 -> 3.31 ms; the batches of a
+        //  piece are not what the kernel waits for)
         for (uint32_t base = 0; base < n;) {
             const uint32_t k = base + lane;
             const uint32_t t = k < n ? tk[k] : 0u;
